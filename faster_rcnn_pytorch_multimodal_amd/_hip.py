@@ -1,0 +1,78 @@
+"""ctypes binding of libfrcnn_hip.so (the C ABI declared in include/frcnn_hip.h).
+
+There is no fallback: if the library is missing or a call fails, an exception is raised.  The library is
+built by ``faster_rcnn_pytorch_multimodal_amd.build.build()`` (``__graft_entry__.build()``).
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint8, c_void_p
+
+from .build import LIB_PATH
+
+_LIB = None
+
+c_float_p = c_void_p  # device pointers travel as integers
+_P = c_void_p
+
+# name -> (restype, argtypes); mirrors include/frcnn_hip.h one to one.
+PROTOTYPES = {
+    "frcnn_version": (c_int, []),
+    "frcnn_last_error": (c_char_p, []),
+    "frcnn_conv2d_fwd_ws_bytes": (c_size_t, [c_int] * 10),
+    "frcnn_conv2d_fwd": (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 11 + [_P, c_size_t, _P]),
+    "frcnn_maxpool3x3s2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "frcnn_pad_channels": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
+    "frcnn_generate_anchors": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "frcnn_rpn_decode_clip": (c_int, [_P, c_int, _P, _P, _P, POINTER(c_float), c_int, c_int, _P, _P, _P]),
+    "frcnn_bbox_transform_inv": (c_int, [_P, c_int, _P, c_int, c_int, c_float, _P, _P]),
+    "frcnn_clip_boxes": (c_int, [_P, c_int, POINTER(c_float), _P, _P]),
+    "frcnn_sort_topk_desc_ws_bytes": (c_size_t, [c_int, c_int]),
+    "frcnn_sort_topk_desc": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "frcnn_gather_rows": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
+    "frcnn_nms_ws_bytes": (c_size_t, [c_int]),
+    "frcnn_nms": (c_int, [_P, _P, c_int, c_float, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "frcnn_make_rois": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P]),
+    "frcnn_roi_align_fwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_float, c_int, _P, c_int, _P, _P]),
+    "frcnn_head_fc_softmax_decode": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, POINTER(c_float),
+                                             POINTER(c_float), c_float, _P, _P, _P, _P, _P, _P]),
+    "frcnn_filter_per_class_ws_bytes": (c_size_t, [c_int, c_int]),
+    "frcnn_filter_per_class": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int,
+                                       c_int, _P, _P, _P, c_size_t, _P]),
+}
+
+
+class HipError(RuntimeError):
+    """A libfrcnn_hip.so entry point returned a negative status."""
+
+
+def library_path():
+    return LIB_PATH
+
+
+def load():
+    """dlopen libfrcnn_hip.so and type every exported entry point.  Raises if the library is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libfrcnn_hip.so is not built (%s). Run `python -m faster_rcnn_pytorch_multimodal_amd.build` "
+            "or __graft_entry__.build(); this package has no non-HIP execution path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library disagree
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _LIB = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().frcnn_last_error()
+        raise HipError("%s failed (%d): %s" % (what, status, msg.decode() if msg else "?"))
+
+
+def float_array(values):
+    arr = (c_float * len(values))(*[float(v) for v in values])
+    return arr

@@ -1,0 +1,134 @@
+// Box arithmetic shared by the proposal / detection-tail kernels.  Every translation unit that includes
+// this header is compiled with -ffp-contract=off: the reference evaluates these expressions as separate
+// torch elementwise ops (one rounding per op), so no mul+add may fuse into an fma here.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace frcnn {
+
+// exp() rounded once from a double evaluation: within 1 ulp of any faithful fp32 expf (the CPU's
+// vectorised expf is not bit-reproducible across ISAs, so this is the best-defined target).
+__device__ __forceinline__ float exp_f32(float v) { return (float)exp((double)v); }
+
+// bbox_transform_inv for one (box, delta) pair — lib/model/bbox_transform.py:82-103.
+// The codec is non-standard: centre deltas are scaled by the box DIAGONAL sqrt(w^2+h^2) (:84,:94-95),
+// widths use the +1 convention (:82-83) and x2 = cx + 0.5*w' (no -1) (:99-103).
+__device__ __forceinline__ void decode_box(float x1, float y1, float x2, float y2, float dx, float dy, float dw,
+                                           float dh, float out[4]) {
+  const float w = x2 - x1 + 1.0f;
+  const float h = y2 - y1 + 1.0f;
+  const float diag = sqrtf(w * w + h * h);
+  const float cx = x1 + 0.5f * w;
+  const float cy = y1 + 0.5f * h;
+  const float pcx = dx * diag + cx;
+  const float pcy = dy * diag + cy;
+  const float pw = exp_f32(dw) * w;
+  const float ph = exp_f32(dh) * h;
+  out[0] = pcx - 0.5f * pw;
+  out[1] = pcy - 0.5f * ph;
+  out[2] = pcx + 0.5f * pw;
+  out[3] = pcy + 0.5f * ph;
+}
+
+// torch.clamp(v, lo, hi) = min(max(v, lo), hi)
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// IoU test of torchvision.ops.nms: areas (x2-x1)*(y2-y1) without +1, suppress when iou > thresh.
+__device__ __forceinline__ bool iou_gt(const float* a, const float* b, float thresh) {
+  const float xx1 = fmaxf(a[0], b[0]), yy1 = fmaxf(a[1], b[1]);
+  const float xx2 = fminf(a[2], b[2]), yy2 = fminf(a[3], b[3]);
+  const float w = fmaxf(xx2 - xx1, 0.f), h = fmaxf(yy2 - yy1, 0.f);
+  const float inter = w * h;
+  const float sa = (a[2] - a[0]) * (a[3] - a[1]);
+  const float sb = (b[2] - b[0]) * (b[3] - b[1]);
+  return inter / (sa + sb - inter) > thresh;
+}
+
+// fp32 -> u32 key whose ASCENDING order is DESCENDING score (-0 is folded into +0 first).
+__device__ __forceinline__ uint32_t desc_key(float s) {
+  if (s == 0.f) s = 0.f;
+  uint32_t u = __float_as_uint(s);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ~u;
+}
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
+  const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, l);
+  const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// In-LDS bitonic sort (ascending) of npad (power of two) u64 keys by the whole workgroup.
+__device__ __forceinline__ void block_bitonic_sort(uint64_t* keys, int npad) {
+  for (int k = 2; k <= npad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npad / 2; i += blockDim.x) {
+        // pair (a, a+j) where a has bit j clear
+        const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+        const int b = a | j;
+        const uint64_t ka = keys[a], kb = keys[b];
+        const bool up = (a & k) == 0;
+        if ((ka > kb) == up) {
+          keys[a] = kb;
+          keys[b] = ka;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Greedy scan over a precomputed suppression bit-matrix by ONE wave (lane = threadIdx.x & 63).
+// mask[i*nb + w] bit b set  <=>  box (w*64+b) has IoU > thresh with box i and (w*64+b) > i.
+// Boxes are in descending-score order.  Writes survivors' positions to keep_idx (first max_keep of them)
+// and optional per-box bytes to keep_mask (pre-zeroed by the caller).  nb <= 256.
+__device__ __forceinline__ int wave_nms_scan(const uint64_t* mask, int nb, int n, int max_keep, int64_t* keep_idx,
+                                             uint8_t* keep_mask) {
+  const int lane = threadIdx.x & 63;
+  uint64_t rm0 = 0, rm1 = 0, rm2 = 0, rm3 = 0;  // removed bits of words lane, lane+64, lane+128, lane+192
+  int count = 0;
+  for (int c = 0; c < nb && c * 64 < n && count < max_keep; ++c) {
+    const int i = c * 64 + lane;
+    const uint64_t d = (i < n) ? mask[(size_t)i * nb + c] : 0ull;
+    const int slot = c >> 6;
+    const uint64_t mine = slot == 0 ? rm0 : slot == 1 ? rm1 : slot == 2 ? rm2 : rm3;
+    const uint64_t rw = readlane_u64(mine, c & 63);
+    const int live = n - c * 64;
+    const uint64_t valid = live >= 64 ? ~0ull : ((1ull << live) - 1ull);
+    uint64_t alive = ~rw & valid;
+    uint64_t kept = 0;
+    int nk = 0;
+    while (alive != 0 && count + nk < max_keep) {
+      const int b = __builtin_ctzll(alive);
+      kept |= 1ull << b;
+      ++nk;
+      const uint64_t db = readlane_u64(d, b);
+      alive &= ~(db | (1ull << b));
+    }
+    if ((kept >> lane) & 1ull) {
+      const int pos = count + __builtin_popcountll(kept & ((1ull << lane) - 1ull));
+      keep_idx[pos] = i;
+      if (keep_mask) keep_mask[i] = 1;
+    }
+    count += nk;
+    if (count >= max_keep) break;
+    uint64_t todo = kept;
+    while (todo != 0) {
+      const int b = __builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      const uint64_t* row = mask + (size_t)(c * 64 + b) * nb;
+      int w = lane;
+      if (w > c && w < nb) rm0 |= row[w];
+      w += 64;
+      if (w > c && w < nb) rm1 |= row[w];
+      w += 64;
+      if (w > c && w < nb) rm2 |= row[w];
+      w += 64;
+      if (w > c && w < nb) rm3 |= row[w];
+    }
+  }
+  return count;
+}
+
+}  // namespace frcnn

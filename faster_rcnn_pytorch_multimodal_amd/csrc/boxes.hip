@@ -1,0 +1,545 @@
+// RPN proposal stage and per-class detection filter: anchors, decode + clip, top-k sort, NMS.
+// Built with -ffp-contract=off (see box_math.h).  These are HBM/latency-bound integer/bit kernels:
+// wave64 ballots/readlanes and LDS sorting, no matrix cores.
+#include "common.h"
+#include "box_math.h"
+
+using namespace frcnn;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// generate_anchors_pre — lib/layer_utils/snippets.py:27-37.  numpy adds the float64 base table to the
+// integer shift grid and casts ONCE to float32; do the same (double add, one rounding).
+// Layout (H, W, A) flattened, A fastest (snippets.py:35-37).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void anchors_kernel(const double* __restrict__ base, int A, int H, int W,
+                                                     int stride, float* __restrict__ out) {
+  const int total = H * W * A;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int a = i % A;
+    const int pix = i / A;
+    const int x = pix % W, y = pix / W;
+    const double sx = (double)(x * stride), sy = (double)(y * stride);
+    float4 v;
+    v.x = (float)(base[a * 4 + 0] + sx);
+    v.y = (float)(base[a * 4 + 1] + sy);
+    v.z = (float)(base[a * 4 + 2] + sx);
+    v.w = (float)(base[a * 4 + 3] + sy);
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// proposal_layer.py:32-36: fg score, bbox_transform_inv, clip_boxes for anchor i = pix*A + a.
+// ------------------------------------------------------------------------------------------------
+struct ClipInfo {
+  float x_lo, x_hi, y_lo, y_hi;
+};
+
+__global__ __launch_bounds__(256) void rpn_decode_clip_kernel(const float* __restrict__ rpn, int ld,
+                                                             const float* __restrict__ probs_in,
+                                                             const float* __restrict__ deltas_in,
+                                                             const float* __restrict__ anchors, ClipInfo clip,
+                                                             int total, int A, float* __restrict__ scores,
+                                                             float* __restrict__ proposals) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int a = i % A;
+    const int pix = i / A;
+    float score;
+    if (probs_in) {
+      score = probs_in[i];
+    } else {
+      // 2-way softmax over (bg, fg) exactly as torch.softmax: subtract max, exp, divide by the sum
+      const float bg = rpn[(size_t)pix * ld + a], fg = rpn[(size_t)pix * ld + A + a];
+      const float m = fmaxf(bg, fg);
+      const float eb = exp_f32(bg - m), ef = exp_f32(fg - m);
+      score = ef / (eb + ef);
+    }
+    float4 d;
+    if (deltas_in) d = reinterpret_cast<const float4*>(deltas_in)[i];
+    else {
+      const float* p = rpn + (size_t)pix * ld + 2 * A + a * 4;
+      d = make_float4(p[0], p[1], p[2], p[3]);
+    }
+    const float4 an = reinterpret_cast<const float4*>(anchors)[i];
+    float o[4];
+    decode_box(an.x, an.y, an.z, an.w, d.x, d.y, d.z, d.w, o);
+    float4 r;
+    r.x = clampf(o[0], clip.x_lo, clip.x_hi);
+    r.y = clampf(o[1], clip.y_lo, clip.y_hi);
+    r.z = clampf(o[2], clip.x_lo, clip.x_hi);
+    r.w = clampf(o[3], clip.y_lo, clip.y_hi);
+    scores[i] = score;
+    reinterpret_cast<float4*>(proposals)[i] = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Top-k of n scores in the total order (score desc, index asc), one 1024-thread workgroup:
+//   1. 4-pass 8-bit radix select of the top_n-th key (LDS histogram),
+//   2. compaction of keys < kth (any order) and of the lowest-index ties == kth (ordered scan),
+//   3. bitonic sort of the <= 16384 u64 (key<<32 | index) candidates in LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int SORT_THREADS = 1024;
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_topk_desc_kernel(const float* __restrict__ scores, int n,
+                                                                      int top_n, int npad,
+                                                                      int64_t* __restrict__ order_out,
+                                                                      float* __restrict__ scores_out,
+                                                                      int* __restrict__ count_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sort_smem[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(sort_smem);             // [npad]
+  uint32_t* hist = reinterpret_cast<uint32_t*>(keys + npad);           // [256]
+  uint32_t* scan = hist + 256;                                         // [SORT_THREADS]
+  __shared__ uint32_t s_prefix, s_need, s_fill;
+  const int t = threadIdx.x;
+  const int take = min(n, top_n);
+
+  for (int i = t; i < npad; i += SORT_THREADS) keys[i] = ~0ull;
+  if (t == 0) { s_prefix = 0; s_need = (uint32_t)take; s_fill = 0; }
+  __syncthreads();
+
+  uint32_t kth = 0xFFFFFFFFu;  // every key <= kth is a candidate when n <= top_n
+  uint32_t need_eq = 0;        // how many keys == kth to take (lowest indices first)
+  if (n > top_n) {
+    // radix select: after the loop s_prefix = kth key, s_need = rank of kth among keys with that value
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      for (int i = t; i < 256; i += SORT_THREADS) hist[i] = 0;
+      __syncthreads();
+      const uint32_t prefix = s_prefix;
+      const uint32_t himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+      for (int i = t; i < n; i += SORT_THREADS) {
+        const uint32_t k = desc_key(scores[i]);
+        if ((k & himask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (t == 0) {
+        uint32_t need = s_need, acc = 0;
+        int b = 0;
+        for (; b < 256; ++b) {
+          if (acc + hist[b] >= need) break;
+          acc += hist[b];
+        }
+        s_prefix = prefix | ((uint32_t)b << shift);
+        s_need = need - acc;
+      }
+      __syncthreads();
+    }
+    kth = s_prefix;
+    need_eq = s_need;
+  }
+  __syncthreads();
+
+  // compaction.  Thread t owns the contiguous index range [lo, hi) so ties are taken in index order.
+  const int per = (n + SORT_THREADS - 1) / SORT_THREADS;
+  const int lo = min(t * per, n), hi = min(lo + per, n);
+  uint32_t my_eq = 0;
+  for (int i = lo; i < hi; ++i) {
+    const uint32_t k = desc_key(scores[i]);
+    if (k < kth || (n <= top_n)) {
+      const uint32_t pos = atomicAdd(&s_fill, 1u);
+      keys[pos] = ((uint64_t)k << 32) | (uint32_t)i;
+    } else if (k == kth) {
+      ++my_eq;
+    }
+  }
+  scan[t] = my_eq;
+  __syncthreads();
+  if (n > top_n) {
+    // exclusive scan of tie counts (Hillis-Steele in LDS)
+    for (int off = 1; off < SORT_THREADS; off <<= 1) {
+      const uint32_t v = t >= off ? scan[t - off] : 0u;
+      __syncthreads();
+      scan[t] += v;
+      __syncthreads();
+    }
+    uint32_t rank = scan[t] - my_eq;  // ties before this thread's range
+    const uint32_t base = (uint32_t)take - need_eq;  // number of keys < kth
+    for (int i = lo; i < hi && rank < need_eq; ++i) {
+      const uint32_t k = desc_key(scores[i]);
+      if (k == kth) {
+        keys[base + rank] = ((uint64_t)k << 32) | (uint32_t)i;
+        ++rank;
+      }
+    }
+  }
+  __syncthreads();
+
+  block_bitonic_sort(keys, npad);
+
+  for (int i = t; i < take; i += SORT_THREADS) {
+    const uint32_t idx = (uint32_t)(keys[i] & 0xFFFFFFFFu);
+    order_out[i] = (int64_t)idx;
+    scores_out[i] = scores[idx];
+  }
+  if (t == 0) count_out[0] = take;
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ rows,
+                                                         const int64_t* __restrict__ order,
+                                                         const int* __restrict__ count, int max_count, int width,
+                                                         float* __restrict__ out) {
+  const int cnt = count ? min(*count, max_count) : max_count;
+  const int total = max_count * width;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int r = i / width, c = i - r * width;
+    out[i] = r < cnt ? rows[order[r] * width + c] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NMS (torchvision.ops.nms semantics) on score-ordered boxes: bit-matrix + single-wave greedy scan.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ n_dev,
+                                                     int n_max, int nb, float thresh, uint64_t* __restrict__ mask) {
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj < bi) return;  // only words on or right of the diagonal are ever read
+  const int n = n_dev ? min(*n_dev, n_max) : n_max;
+  if (bi * 64 >= n) return;
+  __shared__ float cols[64 * 4];
+  const int lane = threadIdx.x;
+  const int j0 = bj * 64;
+  if (j0 + lane < n) {
+    const float4 b = reinterpret_cast<const float4*>(boxes)[j0 + lane];
+    cols[lane * 4 + 0] = b.x; cols[lane * 4 + 1] = b.y; cols[lane * 4 + 2] = b.z; cols[lane * 4 + 3] = b.w;
+  }
+  __syncthreads();
+  const int i = bi * 64 + lane;
+  if (i >= n) return;
+  const float4 bq = reinterpret_cast<const float4*>(boxes)[i];
+  const float me[4] = {bq.x, bq.y, bq.z, bq.w};
+  uint64_t bits = 0;
+  const int jn = min(64, n - j0);
+  for (int b = 0; b < jn; ++b) {
+    if (j0 + b > i && iou_gt(me, &cols[b * 4], thresh)) bits |= 1ull << b;
+  }
+  mask[(size_t)i * nb + bj] = bits;
+}
+
+__global__ __launch_bounds__(64) void nms_scan_kernel(const uint64_t* __restrict__ mask, const int* __restrict__ n_dev,
+                                                     int n_max, int nb, int max_keep, int64_t* __restrict__ keep_idx,
+                                                     uint8_t* __restrict__ keep_mask, int* __restrict__ keep_count) {
+  const int n = n_dev ? min(*n_dev, n_max) : n_max;
+  const int cnt = wave_nms_scan(mask, nb, n, max_keep, keep_idx, keep_mask);
+  if (threadIdx.x == 0) keep_count[0] = cnt;
+}
+
+__global__ __launch_bounds__(256) void make_rois_kernel(const float* __restrict__ boxes, const float* __restrict__ scs,
+                                                       const int64_t* __restrict__ keep_idx,
+                                                       const int* __restrict__ keep_count, int max_keep,
+                                                       float* __restrict__ rois, float* __restrict__ roi_scores) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= max_keep) return;
+  const int cnt = min(*keep_count, max_keep);
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  float s = 0.f;
+  if (i < cnt) {
+    const int64_t k = keep_idx[i];
+    b = reinterpret_cast<const float4*>(boxes)[k];
+    s = scs[k];
+  }
+  float* r = rois + (size_t)i * 5;
+  r[0] = 0.f; r[1] = b.x; r[2] = b.y; r[3] = b.z; r[4] = b.w;
+  if (roi_scores) roi_scores[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// filter_and_draw_prep — lib/utils/filter_predictions.py:75-130 (+ test.py:210-221 max_dets cut).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void clamp_pred_boxes_kernel(float* __restrict__ boxes, int total_boxes, float x_hi,
+                                                              float y_hi) {
+  // filter_predictions.py:85-91: x1,y1 = clamp_min(0); x2 = clamp_max(frame_w/scale - 1); y2 likewise
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total_boxes; i += gridDim.x * blockDim.x) {
+    float4 b = reinterpret_cast<float4*>(boxes)[i];
+    b.x = fmaxf(b.x, 0.f);
+    b.y = fmaxf(b.y, 0.f);
+    b.z = fminf(b.z, x_hi);
+    b.w = fminf(b.w, y_hi);
+    reinterpret_cast<float4*>(boxes)[i] = b;
+  }
+}
+
+constexpr int FILTER_THREADS = 256;
+
+// One workgroup per foreground class.  ws per class: sorted boxes [R][4] floats, mask [R][nb] u64,
+// keep_idx [R] int64.
+__global__ __launch_bounds__(FILTER_THREADS) void filter_class_kernel(
+    const float* __restrict__ pred_boxes, const float* __restrict__ cls_prob, const int* __restrict__ roi_count,
+    int num_rois, int num_classes, float thresh, float nms_thresh, int max_dets, int max_out, int npad, int nb,
+    float* __restrict__ dets, int* __restrict__ det_count, unsigned char* __restrict__ ws, size_t ws_per_class) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char filt_smem[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(filt_smem);  // [npad]
+  __shared__ int s_n, s_keep;
+  const int cls = blockIdx.x + 1;
+  const int t = threadIdx.x;
+  const int R = roi_count ? min(*roi_count, num_rois) : num_rois;
+
+  unsigned char* my = ws + (size_t)blockIdx.x * ws_per_class;
+  float* sboxes = reinterpret_cast<float*>(my);
+  uint64_t* mask = reinterpret_cast<uint64_t*>(my + align_up((size_t)num_rois * 16, 16));
+  int64_t* keep_idx = reinterpret_cast<int64_t*>(reinterpret_cast<unsigned char*>(mask) + (size_t)num_rois * nb * 8);
+
+  if (t == 0) s_n = 0;
+  for (int i = t; i < npad; i += FILTER_THREADS) keys[i] = ~0ull;
+  __syncthreads();
+  // inds = scores[:, c] > thresh  (filter_predictions.py:46)
+  for (int r = t; r < R; r += FILTER_THREADS) {
+    const float s = cls_prob[(size_t)r * num_classes + cls];
+    if (s > thresh) {
+      const int pos = atomicAdd(&s_n, 1);
+      keys[pos] = ((uint64_t)desc_key(s) << 32) | (uint32_t)r;
+    }
+  }
+  __syncthreads();
+  const int n = s_n;
+  block_bitonic_sort(keys, npad);  // (score desc, roi index asc)
+  for (int i = t; i < n; i += FILTER_THREADS) {
+    const uint32_t r = (uint32_t)(keys[i] & 0xFFFFFFFFu);
+    reinterpret_cast<float4*>(sboxes)[i] =
+        *reinterpret_cast<const float4*>(pred_boxes + ((size_t)r * num_classes + cls) * 4);
+  }
+  __syncthreads();
+  // suppression bit-matrix (words on/right of the diagonal)
+  const int nbl = (n + 63) / 64;
+  for (int wi = t; wi < n * nbl; wi += FILTER_THREADS) {
+    const int i = wi / nbl, w = wi - i * nbl;
+    if (w < (i >> 6)) continue;
+    uint64_t bits = 0;
+    const int jn = min(64, n - w * 64);
+    for (int b = 0; b < jn; ++b) {
+      const int j = w * 64 + b;
+      if (j > i && iou_gt(&sboxes[i * 4], &sboxes[j * 4], nms_thresh)) bits |= 1ull << b;
+    }
+    mask[(size_t)i * nbl + w] = bits;
+  }
+  __syncthreads();
+  if (t < 64) {
+    const int cnt = wave_nms_scan(mask, nbl, n, n, keep_idx, nullptr);
+    if (t == 0) s_keep = cnt;
+  }
+  __syncthreads();
+  int kept = s_keep;
+  // test.py:213-221: if more than max_dets survive keep score >= the max_dets-th best (ties stay)
+  if (max_dets > 0 && kept > max_dets) {
+    const float cut = cls_prob[(size_t)(uint32_t)(keys[keep_idx[max_dets - 1]] & 0xFFFFFFFFu) * num_classes + cls];
+    int m = max_dets;
+    while (m < kept &&
+           cls_prob[(size_t)(uint32_t)(keys[keep_idx[m]] & 0xFFFFFFFFu) * num_classes + cls] >= cut)
+      ++m;
+    kept = m;
+  }
+  kept = min(kept, max_out);
+  float* out = dets + (size_t)cls * max_out * 5;
+  for (int i = t; i < max_out; i += FILTER_THREADS) {
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < kept) {
+      const int64_t k = keep_idx[i];
+      const uint32_t r = (uint32_t)(keys[k] & 0xFFFFFFFFu);
+      v[0] = sboxes[k * 4 + 0]; v[1] = sboxes[k * 4 + 1]; v[2] = sboxes[k * 4 + 2]; v[3] = sboxes[k * 4 + 3];
+      v[4] = cls_prob[(size_t)r * num_classes + cls];
+    }
+    for (int q = 0; q < 5; ++q) out[i * 5 + q] = v[q];
+  }
+  if (t == 0) det_count[cls] = kept;
+}
+
+// bbox_transform_inv for (N boxes) x (Kc classes) — lib/model/bbox_transform.py:75-105 — and clip_boxes
+// (:235-257) as stand-alone entry points (the proposal / head kernels fuse the same arithmetic).
+__global__ __launch_bounds__(256) void bbox_transform_inv_kernel(const float* __restrict__ boxes, int box_ld,
+                                                                const float* __restrict__ deltas, int n, int kc,
+                                                                float scale, int use_scale,
+                                                                float* __restrict__ out) {
+  const int total = n * kc;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int r = i / kc;
+    const float* b = boxes + (size_t)r * box_ld;
+    float x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3];
+    if (use_scale) { x1 = x1 / scale; y1 = y1 / scale; x2 = x2 / scale; y2 = y2 / scale; }
+    const float4 d = reinterpret_cast<const float4*>(deltas)[i];
+    float o[4];
+    decode_box(x1, y1, x2, y2, d.x, d.y, d.z, d.w, o);
+    reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void clip_boxes_kernel(const float* __restrict__ in, int total, ClipInfo clip,
+                                                        float* __restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    float4 b = reinterpret_cast<const float4*>(in)[i];
+    b.x = clampf(b.x, clip.x_lo, clip.x_hi);
+    b.y = clampf(b.y, clip.y_lo, clip.y_hi);
+    b.z = clampf(b.z, clip.x_lo, clip.x_hi);
+    b.w = clampf(b.w, clip.y_lo, clip.y_hi);
+    reinterpret_cast<float4*>(out)[i] = b;
+  }
+}
+
+int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+}  // namespace
+
+extern "C" int frcnn_generate_anchors(const double* base, int num_base, int height, int width, int feat_stride,
+                                      float* anchors, void* stream_) {
+  FRCNN_REQUIRE(base && anchors && num_base > 0 && height > 0 && width > 0 && feat_stride > 0,
+                "generate_anchors: bad arguments");
+  const int total = height * width * num_base;
+  hipLaunchKernelGGL(anchors_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), base, num_base, height, width, feat_stride, anchors);
+  return check_launch("anchors_kernel");
+}
+
+extern "C" int frcnn_rpn_decode_clip(const float* rpn, int ld, const float* probs_in, const float* deltas_in,
+                                     const float* anchors, const float* info_host, int hw, int num_anchors,
+                                     float* scores, float* proposals, void* stream_) {
+  FRCNN_REQUIRE(anchors && info_host && scores && proposals && hw > 0 && num_anchors > 0,
+                "rpn_decode_clip: bad arguments");
+  FRCNN_REQUIRE((rpn && ld >= 6 * num_anchors) || (probs_in && deltas_in),
+                "rpn_decode_clip: need the fused rpn tensor (ld >= 6A) or probs_in + deltas_in");
+  FRCNN_REQUIRE(rpn || (probs_in && deltas_in), "rpn_decode_clip: probs_in/deltas_in need each other without rpn");
+  // clip_boxes (bbox_transform.py:252-255): x in [info[0], info[1]-1], y in [info[2], info[3]-1], fp32 maths
+  ClipInfo clip{info_host[0], info_host[1] - 1.0f, info_host[2], info_host[3] - 1.0f};
+  const int total = hw * num_anchors;
+  hipLaunchKernelGGL(rpn_decode_clip_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), rpn, ld, probs_in, deltas_in, anchors, clip, total, num_anchors,
+                     scores, proposals);
+  return check_launch("rpn_decode_clip_kernel");
+}
+
+extern "C" size_t frcnn_sort_topk_desc_ws_bytes(int n, int top_n) {
+  (void)n; (void)top_n;
+  return 0;  // everything lives in LDS
+}
+
+extern "C" int frcnn_sort_topk_desc(const float* scores, int n, int top_n, int64_t* order_out, float* scores_out,
+                                    int* count_out, void* ws, size_t ws_bytes, void* stream_) {
+  (void)ws; (void)ws_bytes;
+  FRCNN_REQUIRE(scores && order_out && scores_out && count_out && n > 0 && top_n > 0, "sort_topk_desc: bad arguments");
+  FRCNN_REQUIRE(top_n <= 16384, "sort_topk_desc: top_n %d > 16384", top_n);
+  const int npad = next_pow2(std::max(std::min(n, top_n), 2));
+  const size_t lds = (size_t)npad * 8 + 256 * 4 + SORT_THREADS * 4;
+  static size_t configured = 0;
+  if (lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_topk_desc_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "sort_topk_desc: set LDS size: %s", hipGetErrorString(e));
+    configured = lds;
+  }
+  hipLaunchKernelGGL(sort_topk_desc_kernel, dim3(1), dim3(SORT_THREADS), lds, static_cast<hipStream_t>(stream_), scores,
+                     n, top_n, npad, order_out, scores_out, count_out);
+  return check_launch("sort_topk_desc_kernel");
+}
+
+extern "C" int frcnn_gather_rows(const float* rows, const int64_t* order, const int* count, int max_count, int width,
+                                 float* rows_out, void* stream_) {
+  FRCNN_REQUIRE(rows && order && rows_out && max_count > 0 && width > 0, "gather_rows: bad arguments");
+  const int total = max_count * width;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), rows, order, count, max_count, width, rows_out);
+  return check_launch("gather_rows_kernel");
+}
+
+extern "C" size_t frcnn_nms_ws_bytes(int n_max) {
+  if (n_max <= 0) return 0;
+  const size_t nb = (size_t)(n_max + 63) / 64;
+  return (size_t)n_max * nb * sizeof(uint64_t);
+}
+
+extern "C" int frcnn_nms(const float* boxes, const int* n_dev, int n_max, float thresh, int max_keep,
+                         int64_t* keep_idx, uint8_t* keep_mask, int* keep_count, void* ws, size_t ws_bytes,
+                         void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FRCNN_REQUIRE(boxes && keep_idx && keep_count && n_max > 0 && max_keep > 0, "nms: bad arguments");
+  FRCNN_REQUIRE(n_max <= 16384, "nms: n_max %d > 16384", n_max);
+  const int nb = (n_max + 63) / 64;
+  const size_t need = frcnn_nms_ws_bytes(n_max);
+  if (!ws || ws_bytes < need) return fail(FRCNN_ERR_WS, "nms: workspace %zu < %zu bytes", ws_bytes, need);
+  uint64_t* mask = static_cast<uint64_t*>(ws);
+  if (keep_mask) {
+    hipError_t e = hipMemsetAsync(keep_mask, 0, (size_t)n_max, stream);
+    if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "nms: memset: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb), dim3(64), 0, stream, boxes, n_dev, n_max, nb, thresh, mask);
+  int rc = check_launch("nms_mask_kernel");
+  if (rc != FRCNN_OK) return rc;
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, stream, mask, n_dev, n_max, nb, std::min(max_keep, n_max),
+                     keep_idx, keep_mask, keep_count);
+  return check_launch("nms_scan_kernel");
+}
+
+extern "C" int frcnn_make_rois(const float* sorted_boxes, const float* sorted_scores, const int64_t* keep_idx,
+                               const int* keep_count, int max_keep, float* rois, float* roi_scores, void* stream_) {
+  FRCNN_REQUIRE(sorted_boxes && sorted_scores && keep_idx && keep_count && rois && max_keep > 0,
+                "make_rois: bad arguments");
+  hipLaunchKernelGGL(make_rois_kernel, dim3((max_keep + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     sorted_boxes, sorted_scores, keep_idx, keep_count, max_keep, rois, roi_scores);
+  return check_launch("make_rois_kernel");
+}
+
+static size_t filter_ws_per_class(int num_rois) {
+  const size_t nb = (size_t)(num_rois + 63) / 64;
+  return align_up(align_up((size_t)num_rois * 16, 16) + (size_t)num_rois * nb * 8 + (size_t)num_rois * 8, 16);
+}
+
+extern "C" size_t frcnn_filter_per_class_ws_bytes(int num_rois, int num_classes) {
+  if (num_rois <= 0 || num_classes <= 1) return 0;
+  return filter_ws_per_class(num_rois) * (size_t)(num_classes - 1);
+}
+
+extern "C" int frcnn_filter_per_class(float* pred_boxes, const float* cls_prob, const int* roi_count, int num_rois,
+                                      int num_classes, float frame_w, float frame_h, float scale, float thresh,
+                                      float nms_thresh, int max_dets, int max_out, float* dets, int* det_count,
+                                      void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FRCNN_REQUIRE(pred_boxes && cls_prob && dets && det_count && num_rois > 0 && num_classes > 1 && max_out > 0,
+                "filter_per_class: bad arguments");
+  FRCNN_REQUIRE(num_rois <= 8192, "filter_per_class: num_rois %d > 8192", num_rois);
+  const size_t need = frcnn_filter_per_class_ws_bytes(num_rois, num_classes);
+  if (!ws || ws_bytes < need) return fail(FRCNN_ERR_WS, "filter_per_class: workspace %zu < %zu bytes", ws_bytes, need);
+  // frame_width/scale - 1 evaluated in fp32 like the numpy float32 scalars of filter_predictions.py:77-91
+  const float x_hi = frame_w / scale - 1.0f, y_hi = frame_h / scale - 1.0f;
+  const int total_boxes = num_rois * num_classes;
+  hipLaunchKernelGGL(clamp_pred_boxes_kernel, dim3(std::min((total_boxes + 255) / 256, 1024)), dim3(256), 0, stream,
+                     pred_boxes, total_boxes, x_hi, y_hi);
+  int rc = check_launch("clamp_pred_boxes_kernel");
+  if (rc != FRCNN_OK) return rc;
+  const int npad = next_pow2(std::max(num_rois, 2));
+  const int nb = (num_rois + 63) / 64;
+  const size_t lds = (size_t)npad * 8;
+  static size_t configured = 0;
+  if (lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_class_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "filter_per_class: set LDS size: %s", hipGetErrorString(e));
+    configured = lds;
+  }
+  hipError_t e = hipMemsetAsync(det_count, 0, sizeof(int) * num_classes, stream);
+  if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "filter_per_class: memset: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(filter_class_kernel, dim3(num_classes - 1), dim3(FILTER_THREADS), lds, stream, pred_boxes, cls_prob,
+                     roi_count, num_rois, num_classes, thresh, nms_thresh, max_dets, max_out, npad, nb, dets, det_count,
+                     static_cast<unsigned char*>(ws), filter_ws_per_class(num_rois));
+  return check_launch("filter_class_kernel");
+}
+
+extern "C" int frcnn_bbox_transform_inv(const float* boxes, int box_ld, const float* deltas, int n, int num_classes,
+                                        float scale, float* out, void* stream_) {
+  FRCNN_REQUIRE(boxes && deltas && out && n > 0 && num_classes > 0 && box_ld >= 4, "bbox_transform_inv: bad arguments");
+  const int total = n * num_classes;
+  hipLaunchKernelGGL(bbox_transform_inv_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), boxes, box_ld, deltas, n, num_classes, scale, scale > 0.f ? 1 : 0,
+                     out);
+  return check_launch("bbox_transform_inv_kernel");
+}
+
+extern "C" int frcnn_clip_boxes(const float* boxes, int num_boxes, const float* info_host, float* out, void* stream_) {
+  FRCNN_REQUIRE(boxes && out && info_host && num_boxes > 0, "clip_boxes: bad arguments");
+  ClipInfo clip{info_host[0], info_host[1] - 1.0f, info_host[2], info_host[3] - 1.0f};
+  hipLaunchKernelGGL(clip_boxes_kernel, dim3(std::min((num_boxes + 255) / 256, 2048)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), boxes, num_boxes, clip, out);
+  return check_launch("clip_boxes_kernel");
+}

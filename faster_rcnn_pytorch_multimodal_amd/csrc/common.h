@@ -1,0 +1,28 @@
+// Shared host-side helpers of libfrcnn_hip.so (gfx950 only; no other backend is compiled in).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include "../../include/frcnn_hip.h"
+
+namespace frcnn {
+
+// Per-thread last error text (returned by frcnn_last_error()).
+char* error_buffer();
+int fail(int code, const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return FRCNN_OK;
+}
+
+__host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace frcnn
+
+#define FRCNN_REQUIRE(cond, ...)                                   \
+  do {                                                             \
+    if (!(cond)) return ::frcnn::fail(FRCNN_ERR_ARG, __VA_ARGS__); \
+  } while (0)

@@ -1,0 +1,437 @@
+// Implicit-GEMM convolution forward on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces the ATen/cuDNN conv2d + batch_norm(eval) + add + relu chain of the reference's
+// lib/nets/resnet.py:98-127 (Bottleneck.forward), :152-156 (stem), lib/nets/fpn.py:33-39 and the RPN
+// convs of the (missing) lib/nets/network.py.
+//
+// GEMM view:  M = N*Ho*Wo output pixels, N = K output channels, Kdim = R*S*C (tap-major, channel-minor).
+// Activations are NHWC and filters KRSC, so both operands are contiguous along Kdim: the global->LDS
+// staging moves 16-byte chunks along Kdim and the MFMA fragments are ds_read_b128 along Kdim.
+//
+// Workgroup = 256 threads = 4 waves in a 2x2 grid; each wave owns TM x TN tiles of 32x32 outputs
+// (block tile BM = 64*TM, BN = 64*TN), BK = 32.  LDS rows are padded to 36 floats: the 16-lane groups
+// of ds_read_b128 then hit 16 distinct 16-byte slots (36*m mod 64 = 4*(9m mod 16) is a bijection).
+// Double-buffered LDS with register staging: the global loads of K-step s+1 are issued before the
+// MFMAs of step s and written to the other buffer after them; one barrier per K-step.
+//
+// The MFMA computes an exact k-ordered fp32 fma chain, so results are deterministic and independent
+// of the tile configuration for split_k == 1.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;
+constexpr int LDS_PITCH = 36;  // floats per LDS row (32 + 4 pad)
+constexpr int NUM_CU = 256;
+
+struct ConvParams {
+  const float* x;
+  const float* w;
+  const float* scale;
+  const float* shift;
+  const float* res;
+  float* y;
+  float* partial;  // split-K slabs [splits][M][K] or nullptr
+  int H, W, C, K, R, S, stride, pad, Ho, Wo;
+  int M;     // N*Ho*Wo
+  int Ktot;  // R*S*C
+  int ksteps;
+  int steps_per_split;
+  int tiles_m, tiles_n;
+  int relu;
+};
+
+// XCD-aware bijective remap (guide T1): blocks b and b+8 share an XCD; give each XCD a contiguous
+// range of logical tiles so neighbouring tiles (shared A rows / B columns) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (b >> 3);
+}
+
+template <int TM, int TN, bool ALIGNED>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int PA = BM / 32, PB = BN / 32;  // 16-byte chunks per thread per K-step
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                        // [2][BM][36]
+  float* Bs = smem + 2 * BM * LDS_PITCH;   // [2][BN][36]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int step_begin = blockIdx.z * p.steps_per_split;
+  const int step_end = min(step_begin + p.steps_per_split, p.ksteps);
+
+  // ---- per-thread staging geometry: thread t moves chunk kc of rows (t>>3) + 32*i --------------
+  const int kc = t & 7, row0 = t >> 3;
+  int a_base[PA], a_hi0[PA], a_wi0[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int m = m0 + i * 32 + row0;
+    if (m < p.M) {
+      const int img = m / (p.Ho * p.Wo);
+      const int rem = m - img * p.Ho * p.Wo;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      a_hi0[i] = ho * p.stride - p.pad;
+      a_wi0[i] = wo * p.stride - p.pad;
+      a_base[i] = ((img * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.C;
+    } else {
+      a_hi0[i] = -(1 << 20);  // never in range
+      a_wi0[i] = 0;
+      a_base[i] = 0;
+    }
+  }
+
+  f32x4 ra[PA], rb[PB];
+  // tap state for the ALIGNED path (C % 32 == 0: a K-step never straddles a tap)
+  int tr = 0, ts = 0, tc = 0;
+  if (ALIGNED) {
+    const int kf = step_begin * BK;
+    const int tap = kf / p.C;
+    tc = kf - tap * p.C;
+    tr = tap / p.S;
+    ts = tap - tr * p.S;
+  }
+
+  auto load_tiles = [&](int step) {
+    const int kflat = step * BK + kc * 4;
+    if (ALIGNED) {
+      const int koff = (tr * p.W + ts) * p.C + tc + kc * 4;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int hi = a_hi0[i] + tr, wi = a_wi0[i] + ts;
+        const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        ra[i] = ok ? *reinterpret_cast<const f32x4*>(p.x + a_base[i] + koff) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      tc += BK;
+      if (tc == p.C) {
+        tc = 0;
+        if (++ts == p.S) { ts = 0; ++tr; }
+      }
+    } else {
+      const int tap = kflat / p.C;
+      const int c = kflat - tap * p.C;
+      const int r = tap / p.S, s = tap - r * p.S;
+      const int koff = (r * p.W + s) * p.C + c;
+      const bool kok = kflat < p.Ktot;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int hi = a_hi0[i] + r, wi = a_wi0[i] + s;
+        const bool ok = kok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        ra[i] = ok ? *reinterpret_cast<const f32x4*>(p.x + a_base[i] + koff) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const int n = n0 + j * 32 + row0;
+      const bool ok = n < p.K && kflat < p.Ktot;
+      rb[j] = ok ? *reinterpret_cast<const f32x4*>(p.w + (size_t)n * p.Ktot + kflat) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* a = As + buf * BM * LDS_PITCH + row0 * LDS_PITCH + kc * 4;
+    float* b = Bs + buf * BN * LDS_PITCH + row0 * LDS_PITCH + kc * 4;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4*>(a + i * 32 * LDS_PITCH) = ra[i];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) *reinterpret_cast<f32x4*>(b + j * 32 * LDS_PITCH) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets: lane (l&31) = row inside the 32x32 tile, (l>>5) selects k in {4h..4h+3}
+  const int frag = (lane & 31) * LDS_PITCH + 4 * (lane >> 5);
+  const int a_frag = (wr * TM * 32) * LDS_PITCH + frag;
+  const int b_frag = (wc * TN * 32) * LDS_PITCH + frag;
+
+  if (step_begin < step_end) {
+    load_tiles(step_begin);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int step = step_begin; step < step_end; ++step) {
+    const bool more = step + 1 < step_end;
+    if (more) load_tiles(step + 1);
+
+    const float* Ab = As + cur * BM * LDS_PITCH + a_frag;
+    const float* Bb = Bs + cur * BN * LDS_PITCH + b_frag;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_PITCH + kk * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_PITCH + kk * 8);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tiles(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ------------
+  const int col = lane & 31, rhalf = 4 * (lane >> 5);
+  if (p.partial != nullptr) {
+    float* slab = p.partial + (size_t)blockIdx.z * p.M * p.K;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wc * TN + j) * 32 + col;
+        if (n >= p.K) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+          if (m < p.M) slab[(size_t)m * p.K + n] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wc * TN + j) * 32 + col;
+    if (n >= p.K) continue;
+    const float sc = p.scale ? p.scale[n] : 1.f;
+    const float sh = p.shift ? p.shift[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+        if (m >= p.M) continue;
+        const size_t o = (size_t)m * p.K + n;
+        float v = acc[i][j][r] * sc + sh;
+        if (p.res) v += p.res[o];
+        if (p.relu) v = fmaxf(v, 0.f);
+        p.y[o] = v;
+      }
+    }
+  }
+}
+
+// Split-K second pass: y = act((sum_z partial[z]) * scale + shift + res), slabs summed in z order.
+__global__ __launch_bounds__(256) void conv_splitk_epilogue(const float* __restrict__ partial, int splits,
+                                                           size_t mk, int K, const float* scale,
+                                                           const float* shift, const float* res, float* y,
+                                                           int relu) {
+  for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < mk; o += (size_t)gridDim.x * blockDim.x) {
+    float v = partial[o];
+    for (int z = 1; z < splits; ++z) v += partial[(size_t)z * mk + o];
+    const int n = (int)(o % K);
+    v = v * (scale ? scale[n] : 1.f) + (shift ? shift[n] : 0.f);
+    if (res) v += res[o];
+    if (relu) v = fmaxf(v, 0.f);
+    y[o] = v;
+  }
+}
+
+struct Plan {
+  int tm, tn, splits, steps_per_split;
+};
+
+// Pick the block tile and the K split that minimise the estimated time on 256 CUs.  Units: MFMA
+// issue cycles of one SIMD (64 per v_mfma_f32_32x32x2_f32).
+Plan choose_plan(int M, int K, int ksteps, int forced_splits) {
+  static const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
+  static const int split_cand[] = {1, 2, 3, 4, 6, 8, 12, 16};
+  Plan best{2, 2, 1, ksteps};
+  double best_t = 1e300;
+  for (auto& c : cand) {
+    const int bm = 64 * c[0], bn = 64 * c[1];
+    const long tiles = (long)((M + bm - 1) / bm) * ((K + bn - 1) / bn);
+    for (int sp : split_cand) {
+      if (forced_splits > 0 && sp != forced_splits) continue;
+      if (forced_splits <= 0 && sp > 1 && ksteps / sp < 4) continue;
+      const int sps = (ksteps + sp - 1) / sp;
+      const int real_splits = (ksteps + sps - 1) / sps;
+      if (real_splits != sp && forced_splits <= 0) continue;
+      const long blocks = tiles * real_splits;
+      const long rounds = (blocks + NUM_CU - 1) / NUM_CU;
+      const double step_cyc = c[0] * c[1] * 16 * 64 + 400.0;
+      double tcyc = rounds * (sps * step_cyc + 4000.0);
+      if (real_splits > 1) {
+        // slab write + read-back at ~3 TB/s (2.4 GHz -> 1250 B/cycle) + one more launch
+        tcyc += (double)M * K * 4.0 * (real_splits + 1) / 1250.0 + 4000.0;
+      }
+      if (tcyc < best_t) {
+        best_t = tcyc;
+        best = Plan{c[0], c[1], real_splits, sps};
+      }
+    }
+  }
+  if (forced_splits > 0 && best_t == 1e300) {
+    const int sps = (ksteps + forced_splits - 1) / forced_splits;
+    best = Plan{1, 1, (ksteps + sps - 1) / sps, sps};
+  }
+  return best;
+}
+
+template <int TM, int TN, bool ALIGNED>
+int launch_conv(const ConvParams& p, int splits, hipStream_t stream) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_PITCH * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<TM, TN, ALIGNED>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return frcnn::fail(FRCNN_ERR_LAUNCH, "conv: set LDS size: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
+  hipLaunchKernelGGL((conv_igemm_f32<TM, TN, ALIGNED>), grid, dim3(256), lds, stream, p);
+  return frcnn::check_launch("conv_igemm_f32");
+}
+
+bool conv_args_ok(int n, int h, int w, int c, int k, int r, int s, int stride, int pad) {
+  return n > 0 && h > 0 && w > 0 && c > 0 && (c % 4) == 0 && k > 0 && r > 0 && s > 0 && stride > 0 && pad >= 0 &&
+         (h + 2 * pad - r) >= 0 && (w + 2 * pad - s) >= 0;
+}
+
+}  // namespace
+
+extern "C" size_t frcnn_conv2d_fwd_ws_bytes(int n, int h, int w, int c, int k, int r, int s, int stride, int pad,
+                                            int split_k) {
+  if (!conv_args_ok(n, h, w, c, k, r, s, stride, pad)) return 0;
+  const int ho = (h + 2 * pad - r) / stride + 1, wo = (w + 2 * pad - s) / stride + 1;
+  const long M = (long)n * ho * wo;
+  const int ksteps = (r * s * c + BK - 1) / BK;
+  const Plan pl = choose_plan((int)M, k, ksteps, split_k);
+  return pl.splits > 1 ? (size_t)pl.splits * M * k * sizeof(float) : 0;
+}
+
+extern "C" int frcnn_conv2d_fwd(const float* x, const float* wgt, const float* scale, const float* shift,
+                                const float* residual, float* y, int n, int h, int w, int c, int k, int r, int s,
+                                int stride, int pad, int relu, int split_k, void* ws, size_t ws_bytes,
+                                void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FRCNN_REQUIRE(x && wgt && y, "conv2d_fwd: null tensor");
+  FRCNN_REQUIRE(conv_args_ok(n, h, w, c, k, r, s, stride, pad),
+                "conv2d_fwd: bad shape n=%d h=%d w=%d c=%d k=%d r=%d s=%d stride=%d pad=%d (need c%%4==0)", n, h, w, c,
+                k, r, s, stride, pad);
+  ConvParams p;
+  p.x = x; p.w = wgt; p.scale = scale; p.shift = shift; p.res = residual; p.y = y; p.partial = nullptr;
+  p.H = h; p.W = w; p.C = c; p.K = k; p.R = r; p.S = s; p.stride = stride; p.pad = pad;
+  p.Ho = (h + 2 * pad - r) / stride + 1;
+  p.Wo = (w + 2 * pad - s) / stride + 1;
+  const long M = (long)n * p.Ho * p.Wo;
+  FRCNN_REQUIRE(M * (long)k < (1L << 31) && (long)n * h * w * c < (1L << 31), "conv2d_fwd: tensor too large for int32 indexing");
+  p.M = (int)M;
+  p.Ktot = r * s * c;
+  p.ksteps = (p.Ktot + BK - 1) / BK;
+  p.relu = relu;
+  const Plan pl = choose_plan(p.M, k, p.ksteps, split_k);
+  p.steps_per_split = pl.steps_per_split;
+  const int bm = 64 * pl.tm, bn = 64 * pl.tn;
+  p.tiles_m = (p.M + bm - 1) / bm;
+  p.tiles_n = (k + bn - 1) / bn;
+  if (pl.splits > 1) {
+    const size_t need = (size_t)pl.splits * M * k * sizeof(float);
+    if (!ws || ws_bytes < need)
+      return frcnn::fail(FRCNN_ERR_WS, "conv2d_fwd: workspace %zu < %zu bytes", ws_bytes, need);
+    p.partial = static_cast<float*>(ws);
+  }
+  const bool aligned = (c % BK) == 0;
+  int rc;
+#define FRCNN_CONV_CASE(TM_, TN_)                                                          \
+  rc = aligned ? launch_conv<TM_, TN_, true>(p, pl.splits, stream) : launch_conv<TM_, TN_, false>(p, pl.splits, stream)
+  if (pl.tm == 2 && pl.tn == 2) FRCNN_CONV_CASE(2, 2);
+  else if (pl.tm == 2 && pl.tn == 1) FRCNN_CONV_CASE(2, 1);
+  else if (pl.tm == 1 && pl.tn == 2) FRCNN_CONV_CASE(1, 2);
+  else FRCNN_CONV_CASE(1, 1);
+#undef FRCNN_CONV_CASE
+  if (rc != FRCNN_OK) return rc;
+  if (pl.splits > 1) {
+    const size_t mk = (size_t)M * k;
+    const int blocks = (int)std::min<size_t>((mk + 255) / 256, 2048);
+    hipLaunchKernelGGL(conv_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, p.partial, pl.splits, mk, k,
+                       scale, shift, residual, y, relu);
+    return frcnn::check_launch("conv_splitk_epilogue");
+  }
+  return FRCNN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPool 3x3 / stride 2 / pad 1, NHWC (lib/nets/resnet.py:156).  One thread = 4 channels of one
+// output pixel; consecutive threads walk the channel dimension -> 16-byte coalesced accesses.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const float* __restrict__ x, float* __restrict__ y, int N,
+                                                        int H, int W, int C4, int Ho, int Wo) {
+  const size_t total = (size_t)N * Ho * Wo * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    size_t pix = i / C4;
+    const int wo = (int)(pix % Wo);
+    pix /= Wo;
+    const int ho = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int hi = ho * 2 - 1 + dy;
+      if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int wi = wo * 2 - 1 + dx;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + hi) * W + wi) * C4 * 4 + c4 * 4);
+        m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+      }
+    }
+    *reinterpret_cast<f32x4*>(y + i * 4) = m;
+  }
+}
+
+__global__ __launch_bounds__(256) void pad_channels_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          size_t pixels, int c, int c_pad) {
+  const size_t total = pixels * c_pad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i / c_pad;
+    const int ch = (int)(i - pix * c_pad);
+    y[i] = ch < c ? x[pix * c + ch] : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int frcnn_maxpool3x3s2_fwd(const float* x, float* y, int n, int h, int w, int c, void* stream_) {
+  FRCNN_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "maxpool3x3s2_fwd: bad arguments (c%%4==0)");
+  const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  const size_t total = (size_t)n * ho * wo * (c / 4);
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048 * 4);
+  hipLaunchKernelGGL(maxpool3x3s2_nhwc, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), x, y, n, h, w,
+                     c / 4, ho, wo);
+  return frcnn::check_launch("maxpool3x3s2_nhwc");
+}
+
+extern "C" int frcnn_pad_channels(const float* x, float* y, int64_t pixels, int c, int c_pad, void* stream_) {
+  FRCNN_REQUIRE(x && y && pixels > 0 && c > 0 && c_pad >= c, "pad_channels: bad arguments");
+  const size_t total = (size_t)pixels * c_pad;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048 * 4);
+  hipLaunchKernelGGL(pad_channels_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), x, y,
+                     (size_t)pixels, c, c_pad);
+  return frcnn::check_launch("pad_channels_kernel");
+}

@@ -1,0 +1,17 @@
+"""Box codec on device tensors — counterpart of lib/model/bbox_transform.py (image detector part).
+
+Quirks kept from the reference: centre deltas are scaled by the box DIAGONAL sqrt(w^2+h^2) (:55,:84),
+widths use the +1 convention, decoded x2 = cx + 0.5*w' (no -1) (:99-103); clip uses ``info`` positions
+[x_min, x_max, y_min, y_max] (:252-255).  The arithmetic runs in libfrcnn_hip.so.
+"""
+from .. import ops
+
+
+def bbox_transform_inv(boxes, deltas, scales=None):
+    """boxes (N,4+) , deltas (N,4K) -> (N,4K).  lib/model/bbox_transform.py:75-105."""
+    return ops.bbox_transform_inv(boxes.contiguous(), deltas.contiguous(), scales)
+
+
+def clip_boxes(boxes, shape):
+    """Clamp x to [shape[0], shape[1]-1] and y to [shape[2], shape[3]-1].  bbox_transform.py:235-257."""
+    return ops.clip_boxes(boxes.contiguous(), [float(v) for v in list(shape)[:4]])

@@ -1,0 +1,244 @@
+"""``Network`` — base class of the detectors, rebuilt from the contract the reference's callers rely on.
+
+The reference's own ``lib/nets/network.py`` is absent from the snapshot; this class provides the surface
+that ``tools/test_net.py:265-290``, ``lib/model/test.py:68-93`` and ``lib/model/train_val.py:167-213,
+410-414,449,458`` call and that the subclasses ``lib/nets/imagenet.py:29-134`` / ``lib/nets/lidarnet.py``
+fill in:
+
+    create_architecture(num_classes, tag, anchor_scales, anchor_ratios)
+    _image_to_head / _anchor_component / _region_proposal / _crop_pool_layer / _head_to_tail /
+    _region_classification / _predict / forward / test_frame / set_e_num_sample
+    hooks implemented by subclasses: _init_head_tail(), init_weights(); attributes _feat_stride, _fpn_en,
+    _net_conv_channels, _roi_pooling_channels, _fc7_channels, _det_net_channels, ...
+
+Every tensor operation of the forward pass is a libfrcnn_hip.so kernel (see ``ops.py``); torch provides
+parameter storage, device memory and the stream only.  Tensors handed across the public methods are
+NCHW-shaped like the reference's (``net_conv`` is (1, C, H, W)) but physically NHWC (channels_last), so
+no layout transposition ever runs on the device.
+
+Choices the missing file leaves open, fixed here as named constants (documented in DESIGN.md):
+    ROI_ALIGN_SAMPLING_RATIO = 0  (adaptive ceil(roi/7); ancestor pytorch-faster-rcnn convention)
+    spatial_scale = 1 / _feat_stride;  RPN softmax pairs channel a (bg) with channel a+A (fg).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..layer_utils.proposal_layer import proposal_layer_device
+from ..layer_utils.snippets import generate_anchors_pre
+from ..model.config import cfg
+from . import resnet as custom_resnet
+from .hip_modules import conv_bn_act, pad4, to_nchw_view, to_nhwc
+
+ROI_ALIGN_SAMPLING_RATIO = 0
+
+
+class Network(nn.Module):
+    def __init__(self):
+        nn.Module.__init__(self)
+        self._predictions = {}
+        self._losses = {}
+        self._anchor_targets = {}
+        self._proposal_targets = {}
+        self._layers = {}
+        self._act_summaries = {}
+        self._score_summaries = {}
+        self._event_summaries = {}
+        self._gt_summaries = {}
+        self._variables_to_fix = {}
+        self._device = 'cuda'
+        self._e_num_sample = 1
+        self._frame_scale = 1.0
+        self.timers = {}
+        self._rpn_fused = None
+
+    # ------------------------------------------------------------------------------------------
+    # construction
+    # ------------------------------------------------------------------------------------------
+    def create_architecture(self, num_classes, tag=None, anchor_scales=(8, 16, 32), anchor_ratios=(0.5, 1, 2)):
+        self._tag = tag
+        self._num_classes = int(num_classes)
+        self._anchor_scales = [float(s) for s in np.asarray(anchor_scales).ravel()]
+        self._num_scales = len(self._anchor_scales)
+        self._anchor_ratios = [float(r) for r in np.asarray(anchor_ratios).ravel()]
+        self._num_ratios = len(self._anchor_ratios)
+        self._num_anchors = self._num_scales * self._num_ratios
+        assert tag is not None
+        self._init_modules()
+
+    def _bbox_elem(self):
+        return cfg[cfg.NET_TYPE.upper()].NUM_BBOX_ELEM if cfg.NET_TYPE in ('image', 'lidar') else 4
+
+    def _init_modules(self):
+        self._init_head_tail()
+        # RPN: names pinned by lib/nets/imagenet.py:66,83-84
+        self.rpn_net = nn.Conv2d(self._net_conv_channels, cfg.RPN_CHANNELS, kernel_size=3, padding=1)
+        self.rpn_cls_score_net = nn.Conv2d(cfg.RPN_CHANNELS, self._num_anchors * 2, kernel_size=1)
+        self.rpn_bbox_pred_net = nn.Conv2d(cfg.RPN_CHANNELS, self._num_anchors * 4, kernel_size=1)
+        # detection heads: lib/nets/imagenet.py:85-86
+        self.cls_score_net = nn.Linear(self._det_net_channels, self._num_classes)
+        self.bbox_pred_net = nn.Linear(self._det_net_channels, self._num_classes * self._bbox_elem())
+        self.init_weights()
+
+    def _build_resnet(self):
+        depth = self._num_resnet_layers
+        if depth == 50:
+            return custom_resnet.resnet50(dropout_en=self._dropout_en, drop_rate=self._resnet_drop_rate,
+                                          batchnorm_en=self._batchnorm_en)
+        if depth == 101:
+            return custom_resnet.resnet101(dropout_en=self._dropout_en, drop_rate=self._resnet_drop_rate,
+                                           batchnorm_en=self._batchnorm_en)
+        if depth == 152:
+            return custom_resnet.resnet152(dropout_en=self._dropout_en, drop_rate=self._resnet_drop_rate,
+                                           batchnorm_en=self._batchnorm_en)
+        raise NotImplementedError('resnet depth %s' % depth)
+
+    def set_e_num_sample(self, n):
+        self._e_num_sample = int(n)
+
+    # ------------------------------------------------------------------------------------------
+    # forward pieces (reference names).  Public tensors are NCHW-shaped views of NHWC storage.
+    # ------------------------------------------------------------------------------------------
+    def _image_to_head(self):
+        net_conv = self._layers['head'](to_nhwc(self._image))
+        self._act_summaries['conv'] = net_conv
+        return to_nchw_view(net_conv)
+
+    _input_to_head = _image_to_head  # name used by the other backbones of the reference (vgg16.py:49)
+
+    def _anchor_component(self, height, width):
+        anchors, length = generate_anchors_pre(height, width, self._feat_stride, self._anchor_scales,
+                                               self._anchor_ratios, self._frame_scale, device=self._image.device)
+        self._anchors = anchors
+        self._anchor_length = length
+        return anchors
+
+    def _fused_rpn_head(self):
+        """rpn_cls_score_net and rpn_bbox_pred_net share their input, so they run as ONE 1x1 conv with
+        the filters concatenated: output channels [0,2A) = class logits, [2A,6A) = box deltas."""
+        cls_net, box_net = self.rpn_cls_score_net, self.rpn_bbox_pred_net
+        key = tuple((t._version, t.data_ptr()) for t in (cls_net.weight, cls_net.bias, box_net.weight, box_net.bias))
+        if self._rpn_fused is None or self._rpn_fused[0] != key:
+            with torch.no_grad():
+                w = torch.cat((cls_net.weight.detach(), box_net.weight.detach()), 0)       # (6A, C, 1, 1)
+                w_krsc = w.permute(0, 2, 3, 1).contiguous()
+                b = torch.cat((cls_net.bias.detach(), box_net.bias.detach()), 0).contiguous()
+            self._rpn_fused = (key, w_krsc, b)
+        return self._rpn_fused[1], self._rpn_fused[2]
+
+    def _rpn_head(self, net_conv_nhwc):
+        """relu(rpn_net) then the fused cls+bbox 1x1.  Returns (H, W, 6A) NHWC logits|deltas."""
+        rpn = conv_bn_act(net_conv_nhwc, self.rpn_net, None, relu=True)
+        self._act_summaries['rpn'] = rpn
+        w, b = self._fused_rpn_head()
+        return ops.conv2d_nhwc(rpn, w, None, b, None, stride=1, pad=0, relu=False)
+
+    def _region_proposal(self, net_conv):
+        """RPN head -> proposal_layer.  Returns rois (post_nms_topN, 5) [0,x1,y1,x2,y2]; rows past
+        ``self._predictions['rois_count']`` (device int) are zero padding."""
+        x = to_nhwc(net_conv)
+        h, w = x.shape[1], x.shape[2]
+        self._anchor_component(h, w)
+        rpn_out = self._rpn_head(x)                                   # (1, H, W, 6A)
+        key = 'TRAIN' if self._mode == 'TRAIN' else 'TEST'
+        if cfg[key].get('MODE', 'nms') != 'nms' and key == 'TEST':
+            raise NotImplementedError("TEST.MODE='top' (proposal_top_layer) is not on the HIP path")
+        res = proposal_layer_device(self._anchors, self._info, self._num_anchors, cfg[key].RPN_PRE_NMS_TOP_N,
+                                    cfg[key].RPN_POST_NMS_TOP_N, cfg[key].RPN_NMS_THRESH,
+                                    rpn=rpn_out.view(h * w, rpn_out.shape[-1]))
+        self._predictions['rpn_out'] = rpn_out
+        self._predictions['rpn_scores'] = res.scores
+        self._predictions['rpn_proposals'] = res.proposals
+        self._predictions['rpn_order'] = res.order
+        self._predictions['rpn_keep'] = res.keep_idx
+        self._predictions['rois'] = res.rois
+        self._predictions['roi_scores'] = res.roi_scores
+        self._predictions['rois_count'] = res.count
+        return res.rois
+
+    def _crop_pool_layer(self, bottom, rois):
+        """RoIAlign 7x7 (POOLING_MODE 'align', lib/model/config.py:364).  (R, C, 7, 7) NCHW-shaped."""
+        pooled = ops.roi_align_nhwc(to_nhwc(bottom), rois.contiguous(), cfg.POOLING_SIZE, 1.0 / self._feat_stride,
+                                    ROI_ALIGN_SAMPLING_RATIO, roi_count=self._predictions.get('rois_count'))
+        return to_nchw_view(pooled)
+
+    def _layer4(self, pool5_nhwc):
+        return self.resnet.layer4(pool5_nhwc)
+
+    def _tail_kernel(self, x_nhwc, rois):
+        key = cfg.NET_TYPE.upper() if cfg.NET_TYPE in ('image', 'lidar') else 'IMAGE'
+        if key != 'IMAGE':
+            raise NotImplementedError("the fused detection tail handles the image detector (4-DoF boxes)")
+        return ops.head_fc_softmax_decode(
+            x_nhwc, self.cls_score_net.weight.detach(), self.cls_score_net.bias.detach(),
+            self.bbox_pred_net.weight.detach(), self.bbox_pred_net.bias.detach(), rois.contiguous(),
+            cfg.TRAIN[key].BBOX_NORMALIZE_STDS, cfg.TRAIN[key].BBOX_NORMALIZE_MEANS, self._frame_scale)
+
+    def _head_to_tail(self, pool5):
+        """layer4 on the pooled RoIs then ``.mean(3).mean(2)`` -> fc7 (R, 2048)."""
+        y = self._layer4(to_nhwc(pool5))
+        out = self._tail_kernel(y, self._predictions['rois'])
+        self._predictions['_tail'] = out
+        return out['fc7']
+
+    def _region_classification(self, fc7):
+        """cls_score_net + softmax, bbox_pred_net.  Returns (cls_prob, bbox_pred) like the ancestor."""
+        tail = self._predictions.get('_tail')
+        if tail is None or tail['fc7'] is not fc7:
+            r, c = fc7.shape
+            tail = self._tail_kernel(fc7.contiguous().view(r, 1, 1, c), self._predictions['rois'])
+        self._predictions['cls_score'] = tail['cls_score']
+        self._predictions['cls_prob'] = tail['cls_prob']
+        self._predictions['bbox_pred'] = tail['bbox_pred']
+        self._predictions['pred_boxes'] = tail['pred_boxes']
+        return tail['cls_prob'], tail['bbox_pred']
+
+    def _predict(self):
+        net_conv = self._image_to_head()
+        rois = self._region_proposal(net_conv)
+        pool5 = self._crop_pool_layer(net_conv, rois)
+        fc7 = self._head_to_tail(pool5)
+        cls_prob, bbox_pred = self._region_classification(fc7)
+        return rois, cls_prob, bbox_pred
+
+    def forward(self, image, info, gt_boxes=None, gt_boxes_dc=None, mode='TRAIN'):
+        """image: (1,H,W,C) float32 numpy blob (lib/roi_data_layer/minibatch.py:670) or device tensor of
+        that layout; info: 7-vector [x_min,x_max,y_min,y_max,z_min,z_max,scale]."""
+        if mode != 'TEST':
+            raise NotImplementedError("training forward/backward is not on the HIP path yet")
+        dev = torch.device(self._device)
+        if dev.type != 'cuda':
+            raise RuntimeError("faster_rcnn_pytorch_multimodal_amd runs on the MI355X only (net._device=%r); "
+                               "the CPU path of the reference is not part of this package" % (self._device,))
+        if isinstance(image, np.ndarray):
+            image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32)).to(dev, non_blocking=True)
+        self._info = np.asarray(info, dtype=np.float32)
+        self._frame_scale = float(self._info[6])
+        # keep the blob NHWC and pad channels to a multiple of 4 (16-byte pixels for the stem conv);
+        # self._image is the NCHW-shaped view the reference exposes
+        self._image = to_nchw_view(ops.pad_channels(image.contiguous(), pad4(image.shape[-1])))
+        self._mode = mode
+        self._predictions = {}
+        return self._predict()
+
+    # ------------------------------------------------------------------------------------------
+    # inference entry point used by lib/model/test.py:75
+    # ------------------------------------------------------------------------------------------
+    def test_frame(self, data, info):
+        """Returns (cls_score, cls_prob, pred_boxes, rois, uncertainties) as device tensors with exactly
+        ``n`` = number of proposals rows (one host sync to read n), like the reference."""
+        with torch.no_grad():
+            self.forward(data, info, None, None, mode='TEST')
+        p = self._predictions
+        n = int(p['rois_count'].item())
+        return p['cls_score'][:n], p['cls_prob'][:n], p['pred_boxes'][:n], p['rois'][:n], {}
+
+    def train_step(self, blobs, optimizer, update_weights=False):
+        raise NotImplementedError("training step is not on the HIP path yet")
+
+    def train_step_with_summary(self, blobs, optimizer, sum_size, update_weights=False):
+        raise NotImplementedError("training step is not on the HIP path yet")
+
+    def run_eval(self, blobs, batch_size, update_summaries=False):
+        raise NotImplementedError("validation step is not on the HIP path yet")

@@ -1,0 +1,268 @@
+"""Tensor-level wrappers over the C ABI (include/frcnn_hip.h).
+
+torch is used here only as the owner of device memory and of the HIP stream; every computation is a
+libfrcnn_hip.so kernel launched on ``torch.cuda.current_stream()``.  Nothing synchronises with the host,
+so a sequence of these calls can be captured into one hipGraph.  CPU tensors are rejected: there is no
+non-HIP execution path in this package.
+
+Layouts: activations NHWC ``(N, H, W, C)`` contiguous fp32, filters KRSC ``(K, R, S, C)`` contiguous fp32.
+"""
+import torch
+
+from . import _hip
+
+_DUMMY = {}
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev_f32(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _hip.HipError("%s must be a tensor on the MI355X (got %s); this package has no CPU path"
+                            % (name, getattr(t, "device", type(t))))
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise _hip.HipError("%s must be contiguous float32 (got %s, contiguous=%s)" % (name, t.dtype, t.is_contiguous()))
+    return t
+
+
+def _workspace(nbytes, device):
+    """Scratch buffer; a fresh allocation keeps graph capture simple (the caching allocator pools it)."""
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def conv_out_hw(h, w, r, s, stride, pad):
+    return (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
+
+
+def conv2d_nhwc(x, w_krsc, scale=None, shift=None, residual=None, stride=1, pad=0, relu=False, split_k=0, out=None):
+    """y = act(conv(x, w) * scale + shift + residual)  —  frcnn_conv2d_fwd."""
+    lib = _hip.load()
+    _dev_f32(x, "x"); _dev_f32(w_krsc, "w")
+    n, h, w, c = x.shape
+    k, r, s, c2 = w_krsc.shape
+    if c2 != c:
+        raise _hip.HipError("conv2d_nhwc: input has %d channels, filter expects %d" % (c, c2))
+    for nm, t in (("scale", scale), ("shift", shift)):
+        if t is not None:
+            _dev_f32(t, nm)
+            if t.numel() != k:
+                raise _hip.HipError("conv2d_nhwc: %s has %d elements, expected %d" % (nm, t.numel(), k))
+    ho, wo = conv_out_hw(h, w, r, s, stride, pad)
+    if out is None:
+        out = torch.empty((n, ho, wo, k), dtype=torch.float32, device=x.device)
+    else:
+        _dev_f32(out, "out")
+        if tuple(out.shape) != (n, ho, wo, k):
+            raise _hip.HipError("conv2d_nhwc: out has shape %s, expected %s" % (tuple(out.shape), (n, ho, wo, k)))
+    if residual is not None:
+        _dev_f32(residual, "residual")
+        if tuple(residual.shape) != (n, ho, wo, k):
+            raise _hip.HipError("conv2d_nhwc: residual shape %s != output shape %s" % (tuple(residual.shape), (n, ho, wo, k)))
+    ws_bytes = lib.frcnn_conv2d_fwd_ws_bytes(n, h, w, c, k, r, s, stride, pad, split_k)
+    ws = _workspace(ws_bytes, x.device) if ws_bytes else None
+    _hip.check(lib.frcnn_conv2d_fwd(_ptr(x), _ptr(w_krsc), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out), n, h, w,
+                                    c, k, r, s, stride, pad, int(bool(relu)), split_k, _ptr(ws), ws_bytes, _stream()),
+               "frcnn_conv2d_fwd")
+    return out
+
+
+def maxpool3x3s2_nhwc(x):
+    lib = _hip.load()
+    _dev_f32(x, "x")
+    n, h, w, c = x.shape
+    out = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=torch.float32, device=x.device)
+    _hip.check(lib.frcnn_maxpool3x3s2_fwd(_ptr(x), _ptr(out), n, h, w, c, _stream()), "frcnn_maxpool3x3s2_fwd")
+    return out
+
+
+def pad_channels(x, c_pad):
+    """(N,H,W,C) -> (N,H,W,c_pad) zero-padded channels."""
+    lib = _hip.load()
+    _dev_f32(x, "x")
+    n, h, w, c = x.shape
+    if c == c_pad:
+        return x
+    out = torch.empty((n, h, w, c_pad), dtype=torch.float32, device=x.device)
+    _hip.check(lib.frcnn_pad_channels(_ptr(x), _ptr(out), n * h * w, c, c_pad, _stream()), "frcnn_pad_channels")
+    return out
+
+
+def generate_anchors(base_f64, height, width, feat_stride):
+    """base_f64: (A,4) float64 DEVICE tensor -> (H*W*A, 4) float32 anchors."""
+    lib = _hip.load()
+    if not base_f64.is_cuda or base_f64.dtype != torch.float64 or not base_f64.is_contiguous():
+        raise _hip.HipError("generate_anchors: base must be a contiguous float64 device tensor")
+    a = base_f64.shape[0]
+    out = torch.empty((height * width * a, 4), dtype=torch.float32, device=base_f64.device)
+    _hip.check(lib.frcnn_generate_anchors(_ptr(base_f64), a, height, width, feat_stride, _ptr(out), _stream()),
+               "frcnn_generate_anchors")
+    return out
+
+
+def rpn_decode_clip(anchors, info, num_anchors, rpn=None, probs=None, deltas=None):
+    """Front half of proposal_layer. Either `rpn` (H*W, >=6A) fused head output or (probs, deltas).
+    info: host sequence [x_min, x_max, y_min, y_max, ...]. Returns (scores (N,), proposals (N,4))."""
+    lib = _hip.load()
+    _dev_f32(anchors, "anchors")
+    total = anchors.shape[0]
+    hw = total // num_anchors
+    ld = 0
+    if rpn is not None:
+        _dev_f32(rpn, "rpn")
+        ld = rpn.shape[-1]
+        if rpn.numel() != hw * ld:
+            raise _hip.HipError("rpn_decode_clip: rpn has %d elements, expected %d x %d" % (rpn.numel(), hw, ld))
+    if probs is not None:
+        _dev_f32(probs, "probs")
+        if probs.numel() != total:
+            raise _hip.HipError("rpn_decode_clip: probs has %d elements, expected %d" % (probs.numel(), total))
+    if deltas is not None:
+        _dev_f32(deltas, "deltas")
+        if deltas.numel() != total * 4:
+            raise _hip.HipError("rpn_decode_clip: deltas has %d elements, expected %d" % (deltas.numel(), total * 4))
+    scores = torch.empty((total,), dtype=torch.float32, device=anchors.device)
+    props = torch.empty((total, 4), dtype=torch.float32, device=anchors.device)
+    info_arr = _hip.float_array([float(v) for v in info[:4]])
+    _hip.check(lib.frcnn_rpn_decode_clip(_ptr(rpn), ld, _ptr(probs), _ptr(deltas), _ptr(anchors), info_arr, hw,
+                                         num_anchors, _ptr(scores), _ptr(props), _stream()), "frcnn_rpn_decode_clip")
+    return scores, props
+
+
+def bbox_transform_inv(boxes, deltas, scale=None):
+    """boxes (N, >=4) [x1,y1,x2,y2,...], deltas (N, 4K) -> (N, 4K) decoded boxes."""
+    lib = _hip.load()
+    _dev_f32(boxes, "boxes"); _dev_f32(deltas, "deltas")
+    n = boxes.shape[0]
+    if n == 0:
+        return deltas.detach() * 0  # reference: bbox_transform.py:79-80
+    k = deltas.shape[1] // 4
+    out = torch.empty((n, 4 * k), dtype=torch.float32, device=boxes.device)
+    _hip.check(lib.frcnn_bbox_transform_inv(_ptr(boxes), boxes.shape[1], _ptr(deltas), n, k,
+                                            float(scale) if scale is not None else 0.0, _ptr(out), _stream()),
+               "frcnn_bbox_transform_inv")
+    return out
+
+
+def clip_boxes(boxes, info):
+    lib = _hip.load()
+    _dev_f32(boxes, "boxes")
+    out = torch.empty_like(boxes)
+    if boxes.numel() == 0:
+        return out
+    _hip.check(lib.frcnn_clip_boxes(_ptr(boxes), boxes.numel() // 4, _hip.float_array([float(v) for v in info[:4]]),
+                                    _ptr(out), _stream()), "frcnn_clip_boxes")
+    return out
+
+
+def sort_topk_desc(scores, top_n):
+    """Returns (order int64 (top_n,), sorted_scores (top_n,), count int32 (1,)) — (score desc, index asc)."""
+    lib = _hip.load()
+    _dev_f32(scores, "scores")
+    n = scores.numel()
+    m = min(n, top_n)
+    order = torch.empty((m,), dtype=torch.int64, device=scores.device)
+    sout = torch.empty((m,), dtype=torch.float32, device=scores.device)
+    count = torch.empty((1,), dtype=torch.int32, device=scores.device)
+    _hip.check(lib.frcnn_sort_topk_desc(_ptr(scores), n, top_n, _ptr(order), _ptr(sout), _ptr(count), None, 0, _stream()),
+               "frcnn_sort_topk_desc")
+    return order, sout, count
+
+
+def gather_rows(rows, order, count=None):
+    lib = _hip.load()
+    _dev_f32(rows, "rows")
+    width = rows.shape[1] if rows.dim() > 1 else 1
+    m = order.numel()
+    out = torch.empty((m, width), dtype=torch.float32, device=rows.device)
+    _hip.check(lib.frcnn_gather_rows(_ptr(rows), _ptr(order), _ptr(count), m, width, _ptr(out), _stream()),
+               "frcnn_gather_rows")
+    return out
+
+
+def nms_sorted(boxes, thresh, max_keep=None, n_dev=None, want_mask=False):
+    """NMS over boxes already in descending-score order.
+    Returns (keep_idx int64 (max_keep,), keep_count int32 (1,), keep_mask uint8 (n,) or None)."""
+    lib = _hip.load()
+    _dev_f32(boxes, "boxes")
+    n = boxes.shape[0]
+    max_keep = n if max_keep is None or max_keep <= 0 else min(max_keep, n)
+    keep_idx = torch.zeros((max_keep,), dtype=torch.int64, device=boxes.device)
+    keep_count = torch.empty((1,), dtype=torch.int32, device=boxes.device)
+    keep_mask = torch.empty((n,), dtype=torch.uint8, device=boxes.device) if want_mask else None
+    ws_bytes = lib.frcnn_nms_ws_bytes(n)
+    ws = _workspace(ws_bytes, boxes.device)
+    _hip.check(lib.frcnn_nms(_ptr(boxes), _ptr(n_dev), n, float(thresh), max_keep, _ptr(keep_idx), _ptr(keep_mask),
+                             _ptr(keep_count), _ptr(ws), ws_bytes, _stream()), "frcnn_nms")
+    return keep_idx, keep_count, keep_mask
+
+
+def make_rois(sorted_boxes, sorted_scores, keep_idx, keep_count):
+    lib = _hip.load()
+    m = keep_idx.numel()
+    rois = torch.empty((m, 5), dtype=torch.float32, device=sorted_boxes.device)
+    roi_scores = torch.empty((m, 1), dtype=torch.float32, device=sorted_boxes.device)
+    _hip.check(lib.frcnn_make_rois(_ptr(sorted_boxes), _ptr(sorted_scores), _ptr(keep_idx), _ptr(keep_count), m,
+                                   _ptr(rois), _ptr(roi_scores), _stream()), "frcnn_make_rois")
+    return rois, roi_scores
+
+
+def roi_align_nhwc(feat, rois, pooled, spatial_scale, sampling_ratio=0, roi_count=None, level_of_roi=None, level=-1,
+                   out=None):
+    """feat (N,H,W,C), rois (R,5) -> (R, P, P, C)."""
+    lib = _hip.load()
+    _dev_f32(feat, "feat"); _dev_f32(rois, "rois")
+    n, h, w, c = feat.shape
+    r = rois.shape[0]
+    if out is None:
+        out = torch.empty((r, pooled, pooled, c), dtype=torch.float32, device=feat.device)
+    _hip.check(lib.frcnn_roi_align_fwd(_ptr(feat), h, w, c, _ptr(rois), _ptr(roi_count), r, pooled, float(spatial_scale),
+                                       int(sampling_ratio), _ptr(level_of_roi), level, _ptr(out), _stream()),
+               "frcnn_roi_align_fwd")
+    return out
+
+
+def head_fc_softmax_decode(x, w_cls, b_cls, w_box, b_box, rois, stds, means, scale):
+    """x (R,P,P,C) -> dict(fc7, cls_score, cls_prob, bbox_pred, pred_boxes)."""
+    lib = _hip.load()
+    for nm, t in (("x", x), ("w_cls", w_cls), ("b_cls", b_cls), ("w_box", w_box), ("b_box", b_box), ("rois", rois)):
+        _dev_f32(t, nm)
+    r, p, _, c = x.shape
+    k = w_cls.shape[0]
+    if w_box.shape[0] != 4 * k or w_cls.shape[1] != c or w_box.shape[1] != c:
+        raise _hip.HipError("head_fc_softmax_decode: inconsistent head weights")
+    dev = x.device
+    fc7 = torch.empty((r, c), dtype=torch.float32, device=dev)
+    cls_score = torch.empty((r, k), dtype=torch.float32, device=dev)
+    cls_prob = torch.empty((r, k), dtype=torch.float32, device=dev)
+    bbox_pred = torch.empty((r, 4 * k), dtype=torch.float32, device=dev)
+    pred_boxes = torch.empty((r, 4 * k), dtype=torch.float32, device=dev)
+    _hip.check(lib.frcnn_head_fc_softmax_decode(_ptr(x), r, p, c, _ptr(w_cls), _ptr(b_cls), _ptr(w_box), _ptr(b_box), k,
+                                                _ptr(rois), _hip.float_array(stds), _hip.float_array(means), float(scale),
+                                                _ptr(fc7), _ptr(cls_score), _ptr(cls_prob), _ptr(bbox_pred),
+                                                _ptr(pred_boxes), _stream()), "frcnn_head_fc_softmax_decode")
+    return {"fc7": fc7, "cls_score": cls_score, "cls_prob": cls_prob, "bbox_pred": bbox_pred, "pred_boxes": pred_boxes}
+
+
+def filter_per_class(pred_boxes, cls_prob, frame_w, frame_h, scale, thresh, nms_thresh, max_dets, max_out=None,
+                     roi_count=None):
+    """In-place clamp of pred_boxes + per-class threshold/NMS/max_dets.
+    Returns (dets (K, max_out, 5), det_count int32 (K,))."""
+    lib = _hip.load()
+    _dev_f32(pred_boxes, "pred_boxes"); _dev_f32(cls_prob, "cls_prob")
+    r, k = cls_prob.shape
+    max_out = r if max_out is None else max_out
+    dets = torch.zeros((k, max_out, 5), dtype=torch.float32, device=cls_prob.device)
+    det_count = torch.zeros((k,), dtype=torch.int32, device=cls_prob.device)
+    ws_bytes = lib.frcnn_filter_per_class_ws_bytes(r, k)
+    ws = _workspace(ws_bytes, cls_prob.device)
+    _hip.check(lib.frcnn_filter_per_class(_ptr(pred_boxes), _ptr(cls_prob), _ptr(roi_count), r, k, float(frame_w),
+                                          float(frame_h), float(scale), float(thresh), float(nms_thresh), int(max_dets),
+                                          int(max_out), _ptr(dets), _ptr(det_count), _ptr(ws), ws_bytes, _stream()),
+               "frcnn_filter_per_class")
+    return dets, det_count

@@ -1,0 +1,38 @@
+"""Test-time post-processing on the device — counterpart of lib/utils/filter_predictions.py:45-130.
+
+The reference loops over classes in Python and copies to the host once per class (``.cpu().numpy()`` at
+:64,:67).  Here one launch (``frcnn_filter_per_class``: one workgroup per foreground class) clamps the
+boxes to the frame, thresholds, sorts by (score desc, roi index asc), runs NMS at cfg.TEST.NMS_THRESH and
+optionally applies the ``max_dets`` cut of lib/model/test.py:213-221; a single device->host copy follows.
+"""
+import numpy as np
+
+from .. import ops
+from ..model.config import cfg
+
+
+def filter_device(rois_count, cls_prob, pred_boxes, info, thresh=0.1, max_dets=0, max_out=None):
+    """Asynchronous form: returns (dets (K, max_out, 5), det_count (K,)) device tensors.
+    ``pred_boxes`` is clamped IN PLACE like the reference (:85-91)."""
+    info = np.asarray(info, dtype=np.float32)
+    frame_w, frame_h, scale = info[1] - info[0], info[3] - info[2], info[6]
+    return ops.filter_per_class(pred_boxes, cls_prob, float(frame_w), float(frame_h), float(scale), thresh,
+                                cfg.TEST.NMS_THRESH, max_dets, max_out, roi_count=rois_count)
+
+
+def filter_and_draw_prep(rois, cls_score, pred_boxes, uncertainties, info, num_classes, thresh=0.1, db_type='none'):
+    """Reference signature and return value: (rois_np (R,4), all_boxes[K] of (n_j,5) float32 arrays,
+    all_uncertainty[K] dicts).  ``cls_score`` is the class-probability tensor (lib/model/test.py:75-93)."""
+    if db_type != 'image':
+        if db_type == 'lidar':
+            raise NotImplementedError("LiDAR (7-DoF) post-processing is not on the HIP path yet")
+        return None
+    dets, det_count = filter_device(None, cls_score.contiguous(), pred_boxes, info, thresh)
+    dets_np = dets.cpu().numpy()          # the one device->host copy (+ implicit sync)
+    counts = det_count.cpu().numpy()
+    all_boxes = [[] for _ in range(num_classes)]
+    all_uncertainty = [{} for _ in range(num_classes)]
+    for j in range(1, num_classes):
+        all_boxes[j] = dets_np[j, :counts[j]].copy() if counts[j] > 0 else np.empty(0)
+        all_uncertainty[j] = uncertainties
+    return rois[:, 1:5].detach().cpu().numpy(), all_boxes, all_uncertainty

@@ -1,0 +1,152 @@
+/*
+ * frcnn_hip.h — C ABI of libfrcnn_hip.so, the gfx950 (MI355X) HIP library behind the
+ * Faster R-CNN hot path of mathild7/faster_rcnn_pytorch_multimodal.
+ *
+ * The reference has no FFI of its own (it is 100 % Python on torch / torchvision); each entry
+ * point below names the reference call it replaces (path:line under the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch allocates), unless marked host;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), makes no allocation and
+ *     no host synchronisation, so a whole frame can be captured in one hipGraph;
+ *   - activations are NHWC fp32, filters are KRSC fp32 (K = output channels), both with C % 4 == 0;
+ *   - scratch memory comes from the caller: `*_ws_bytes()` says how much `(ws, ws_bytes)` must hold;
+ *   - return value 0 = ok, negative = error (frcnn_last_error() gives the message of the calling
+ *     thread's last failure). Counts produced on the device (NMS survivors ...) stay on the device.
+ */
+#ifndef FRCNN_HIP_H_
+#define FRCNN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRCNN_OK 0
+#define FRCNN_ERR_ARG (-1)     /* bad shape / null pointer / unsupported configuration */
+#define FRCNN_ERR_WS (-2)      /* workspace too small */
+#define FRCNN_ERR_LAUNCH (-3)  /* hipLaunch / runtime error */
+
+/* Library version (major*10000 + minor*100 + patch) and last error text of this thread. */
+int frcnn_version(void);
+const char* frcnn_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense backbone: conv + folded BN + residual + ReLU  (lib/nets/resnet.py:98-127 Bottleneck.forward,
+ * :24-32 conv3x3/conv1x1, :152-156 stem; lib/nets/fpn.py:33-39 lateral/smoothing convs; RPN convs of
+ * the missing lib/nets/network.py).  Implicit GEMM on v_mfma_f32_32x32x2_f32:
+ *     y[n,ho,wo,k] = act( (sum_{r,s,c} x[n,ho*stride-pad+r,wo*stride-pad+s,c] * w[k,r,s,c]) * scale[k]
+ *                          + shift[k] + residual[n,ho,wo,k] )
+ * scale/shift/residual may be NULL (1, 0, 0). relu != 0 applies max(.,0).
+ * split_k == 0 lets the library choose; >= 1 forces that many K splits (partials go through ws).
+ * ------------------------------------------------------------------------------------------- */
+size_t frcnn_conv2d_fwd_ws_bytes(int n, int h, int w, int c, int k, int r, int s, int stride, int pad,
+                                 int split_k);
+int frcnn_conv2d_fwd(const float* x, const float* wgt, const float* scale, const float* shift,
+                     const float* residual, float* y, int n, int h, int w, int c, int k, int r, int s,
+                     int stride, int pad, int relu, int split_k, void* ws, size_t ws_bytes, void* stream);
+
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1)  (lib/nets/resnet.py:156), NHWC. */
+int frcnn_maxpool3x3s2_fwd(const float* x, float* y, int n, int h, int w, int c, void* stream);
+
+/* NHWC image/BEV blob (lib/roi_data_layer/minibatch.py:670 layout, (1,H,W,C)) -> NHWC with the channel
+ * count padded with zeros to c_pad (multiple of 4) so the stem conv reads 16-byte pixels. */
+int frcnn_pad_channels(const float* x, float* y, int64_t pixels, int c, int c_pad, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * RPN / proposal stage
+ * ------------------------------------------------------------------------------------------- */
+/* generate_anchors_pre (lib/layer_utils/snippets.py:13-40): anchors[(y*W+x)*A + a] = base[a] + shift.
+ * `base` is the (A,4) table of generate_anchors (lib/layer_utils/generate_anchors.py:41-54), computed on
+ * the host in float64 (DEVICE pointer to A*4 doubles); the shift is added in float64 and the sum is
+ * rounded once to fp32, exactly like the reference's astype(float32). */
+int frcnn_generate_anchors(const double* base, int num_base, int height, int width, int feat_stride,
+                           float* anchors, void* stream);
+
+/* Fused front half of proposal_layer (lib/layer_utils/proposal_layer.py:32-36) on the raw RPN head
+ * output `rpn` (H*W, ld) NHWC with channels [0,A) = bg logits, [A,2A) = fg logits, [2A,6A) = deltas:
+ *   fg prob of the 2-way softmax, bbox_transform_inv (lib/model/bbox_transform.py:75-105) and
+ *   clip_boxes (:235-257, info = [x_min,x_max,y_min,y_max,...]).
+ * With probs_in != NULL the logits are ignored and (H*W*A) ready-made fg probabilities are copied
+ * (the exact proposal_layer signature, which receives rpn_cls_prob). info is a HOST pointer to 4+ floats. */
+int frcnn_rpn_decode_clip(const float* rpn, int ld, const float* probs_in, const float* deltas_in,
+                          const float* anchors, const float* info_host, int hw, int num_anchors,
+                          float* scores, float* proposals, void* stream);
+
+/* Stand-alone box codec (the proposal and tail kernels fuse the same arithmetic):
+ * bbox_transform_inv (lib/model/bbox_transform.py:75-105): boxes rows of box_ld floats whose first 4 are
+ * [x1,y1,x2,y2]; deltas/out (n, 4*num_classes); scale > 0 divides the boxes first (:77-78), scale <= 0 = None.
+ * clip_boxes (:235-257): num_boxes 4-float boxes; info HOST pointer [x_min,x_max,y_min,y_max]. */
+int frcnn_bbox_transform_inv(const float* boxes, int box_ld, const float* deltas, int n, int num_classes,
+                             float scale, float* out, void* stream);
+int frcnn_clip_boxes(const float* boxes, int num_boxes, const float* info_host, float* out, void* stream);
+
+/* scores.sort(descending=True)[:top_n] (proposal_layer.py:39-42) with the canonical total order
+ * (score desc, index asc).  order_out[top_n] int64 source indices, scores_out[top_n];
+ * count_out[0] = min(n, top_n).  top_n <= 16384. */
+size_t frcnn_sort_topk_desc_ws_bytes(int n, int top_n);
+int frcnn_sort_topk_desc(const float* scores, int n, int top_n, int64_t* order_out, float* scores_out,
+                         int* count_out, void* ws, size_t ws_bytes, void* stream);
+
+/* rows_out[i,:] = rows[order[i],:]  for i < count (device count), `width` floats per row. */
+int frcnn_gather_rows(const float* rows, const int64_t* order, const int* count, int max_count, int width,
+                      float* rows_out, void* stream);
+
+/* torchvision.ops.nms (call sites proposal_layer.py:46, filter_predictions.py:67-69) on boxes already
+ * sorted by descending score: box j is dropped when IoU(i,j) > thresh for an earlier kept i
+ * (areas without +1).  n_dev (device int, may be NULL -> n_max) boxes are live.
+ * keep_idx[max_keep] int64 positions of survivors in score order, keep_mask[n_max] bytes,
+ * keep_count[0] = min(#survivors, max_keep). */
+size_t frcnn_nms_ws_bytes(int n_max);
+int frcnn_nms(const float* boxes, const int* n_dev, int n_max, float thresh, int max_keep,
+              int64_t* keep_idx, uint8_t* keep_mask, int* keep_count, void* ws, size_t ws_bytes,
+              void* stream);
+
+/* Tail of proposal_layer (proposal_layer.py:50-55): rois[i] = [0, proposals[order... keep[i]]],
+ * roi_scores[i]; rows >= keep_count are zero-filled.  sorted_boxes are the score-ordered boxes. */
+int frcnn_make_rois(const float* sorted_boxes, const float* sorted_scores, const int64_t* keep_idx,
+                    const int* keep_count, int max_keep, float* rois, float* roi_scores, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * RoIAlign (torchvision.ops.roi_align 0.4.0 semantics = aligned=False; call sites
+ * lib/utils/torchpoolers.py:165-170,194-197 and the _crop_pool_layer of the missing network.py).
+ * feat NHWC (1,H,W,C); rois (R,5) [batch,x1,y1,x2,y2]; out (R,P,P,C) NHWC.
+ * sampling_ratio <= 0 -> adaptive ceil(roi/P).  roi_count (device int, may be NULL) masks rows
+ * >= count to zero.  level_of_roi/level (may be NULL/-1): only rois with level_of_roi[r]==level
+ * are written (MultiScaleRoIAlign, torchpoolers.py:187-199).
+ * ------------------------------------------------------------------------------------------- */
+int frcnn_roi_align_fwd(const float* feat, int h, int w, int c, const float* rois, const int* roi_count,
+                        int num_rois, int pooled, float spatial_scale, int sampling_ratio,
+                        const int* level_of_roi, int level, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Detection tail (_head_to_tail mean + _region_classification + test-time decode of network.py;
+ * evidence lib/model/test.py:75-79, lib/model/config.py:219-223):
+ *   fc7 = x.mean(3).mean(2); cls_score = fc7 W_c^T + b_c; cls_prob = softmax; deltas = fc7 W_b^T + b_b;
+ *   pred_boxes = bbox_transform_inv(rois[:,1:5], deltas*stds+means, scale).
+ * x (R,P,P,C) NHWC; w_cls (K,C); w_box (K*4,C); stds/means HOST pointers to 4 floats.
+ * Outputs: fc7 (R,C), cls_score (R,K), cls_prob (R,K), bbox_pred (R,4K) raw, pred_boxes (R,4K).
+ * ------------------------------------------------------------------------------------------- */
+int frcnn_head_fc_softmax_decode(const float* x, int num_rois, int pooled, int c, const float* w_cls,
+                                 const float* b_cls, const float* w_box, const float* b_box,
+                                 int num_classes, const float* rois, const float* stds_host,
+                                 const float* means_host, float scale, float* fc7, float* cls_score,
+                                 float* cls_prob, float* bbox_pred, float* pred_boxes, void* stream);
+
+/* filter_and_draw_prep + nms_hstack_torch + the max_dets cut (lib/utils/filter_predictions.py:75-130,
+ * 45-72; lib/model/test.py:210-221) for the image detector, all on the device:
+ * clamp to [0, frame/scale-1] in place, per class j>=1 keep score > thresh, NMS(nms_thresh) in
+ * descending score order, keep dets with score >= the max_dets-th best.
+ * dets (K, max_out, 5) [x1,y1,x2,y2,score], det_count (K) ints. roi_count device int or NULL. */
+size_t frcnn_filter_per_class_ws_bytes(int num_rois, int num_classes);
+int frcnn_filter_per_class(float* pred_boxes, const float* cls_prob, const int* roi_count, int num_rois,
+                           int num_classes, float frame_w, float frame_h, float scale, float thresh,
+                           float nms_thresh, int max_dets, int max_out, float* dets, int* det_count,
+                           void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRCNN_HIP_H_ */

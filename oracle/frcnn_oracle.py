@@ -1,0 +1,514 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE ONLY.
+
+A plain numpy / PyTorch-CPU restatement of the reference algorithm for the Faster R-CNN hot path of
+mathild7/faster_rcnn_pytorch_multimodal.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this module; the product package
+(``faster_rcnn_pytorch_multimodal_amd``) never does and has no CPU execution path.
+
+Pinning status:
+  * pinned by golden vectors generated from the importable reference modules
+    (tests/golden/make_golden.py): generate_anchors / generate_anchors_pre, bbox_transform(_inv),
+    clip_boxes, ResNet-101 stage outputs, bbox_overlaps;
+  * PARITY UNPINNED: nms and roi_align restate the documented semantics of torchvision==0.4.0
+    (req.txt:283), which is neither vendored in the reference nor installed here, and the reference has
+    no tests for them; the Network pipeline restates the RECONSTRUCTED contract of the missing
+    lib/nets/network.py.
+
+Every function cites the reference file:line it follows (paths relative to the reference root).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------------------------
+# constants of lib/model/config.py used on the path
+# ----------------------------------------------------------------------------------------------
+ANCHOR_SCALES = (2, 4, 8, 16, 32)             # config.py:373
+ANCHOR_RATIOS = (0.5, 0.75, 1, 1.25, 2)       # config.py:378
+RPN_CHANNELS = 512                            # config.py:381
+POOLING_SIZE = 7                              # config.py:366
+TEST_RPN_PRE_NMS_TOP_N = 6000                 # config.py:253
+TEST_RPN_POST_NMS_TOP_N = 300                 # config.py:256
+TEST_RPN_NMS_THRESH = 0.7                     # config.py:250
+TEST_NMS_THRESH = 0.6                         # config.py:234
+BBOX_NORMALIZE_MEANS = (0.0, 0.0, 0.0, 0.0)   # config.py:222
+BBOX_NORMALIZE_STDS = (0.1, 0.1, 0.2, 0.2)    # config.py:223
+ROI_ALIGN_SAMPLING_RATIO = 0                  # unpinned (network.py missing); ancestor convention: adaptive
+
+
+# ----------------------------------------------------------------------------------------------
+# anchors — lib/layer_utils/generate_anchors.py:41-105, lib/layer_utils/snippets.py:13-40
+# ----------------------------------------------------------------------------------------------
+def _whctrs(a):
+    w = a[2] - a[0] + 1
+    h = a[3] - a[1] + 1
+    return w, h, a[0] + 0.5 * (w - 1), a[1] + 0.5 * (h - 1)
+
+
+def _mkanchors(ws, hs, xc, yc):
+    ws = np.asarray(ws, dtype=np.float64)[:, None]
+    hs = np.asarray(hs, dtype=np.float64)[:, None]
+    return np.hstack((xc - 0.5 * (ws - 1), yc - 0.5 * (hs - 1), xc + 0.5 * (ws - 1), yc + 0.5 * (hs - 1)))
+
+
+def generate_anchors(base_size=16, ratios=(0.5, 1, 2), scales=2 ** np.arange(3, 6)):
+    """generate_anchors.py:41-54: ratio enumeration (np.round, :82-93) then scale enumeration (:96-105)."""
+    ratios = np.asarray(ratios, dtype=np.float64)
+    scales = np.asarray(scales, dtype=np.float64)
+    base = np.array([1, 1, base_size, base_size], dtype=np.float64) - 1
+    w, h, xc, yc = _whctrs(base)
+    size_ratios = (w * h) / ratios
+    ws = np.round(np.sqrt(size_ratios))
+    hs = np.round(ws * ratios)
+    ratio_anchors = _mkanchors(ws, hs, xc, yc)
+    out = []
+    for i in range(ratio_anchors.shape[0]):
+        w, h, xc, yc = _whctrs(ratio_anchors[i])
+        out.append(_mkanchors(w * scales, h * scales, xc, yc))
+    return np.vstack(out)
+
+
+def generate_anchors_pre(height, width, feat_stride, anchor_scales=(8, 16, 32), anchor_ratios=(0.5, 1, 2),
+                         frame_scale=1.0):
+    """snippets.py:13-40: (H, W, A) layout, A fastest; float64 sum cast once to float32."""
+    base = generate_anchors(ratios=np.array(anchor_ratios), scales=np.array(anchor_scales) * frame_scale)
+    a = base.shape[0]
+    sx = np.arange(0, width) * feat_stride
+    sy = np.arange(0, height) * feat_stride
+    sx, sy = np.meshgrid(sx, sy)
+    shifts = np.vstack((sx.ravel(), sy.ravel(), sx.ravel(), sy.ravel())).transpose()
+    k = shifts.shape[0]
+    anchors = base.reshape((1, a, 4)) + shifts.reshape((1, k, 4)).transpose((1, 0, 2))
+    return anchors.reshape((k * a, 4)).astype(np.float32, copy=False), np.int32(k * a)
+
+
+# ----------------------------------------------------------------------------------------------
+# box codec — lib/model/bbox_transform.py:52-70, 75-105, 235-257
+# ----------------------------------------------------------------------------------------------
+def bbox_transform(ex_rois, gt_rois):
+    ew = ex_rois[:, 2] - ex_rois[:, 0] + 1.0
+    eh = ex_rois[:, 3] - ex_rois[:, 1] + 1.0
+    diag = torch.sqrt(torch.pow(ew, 2) + torch.pow(eh, 2))
+    ecx = ex_rois[:, 0] + 0.5 * ew
+    ecy = ex_rois[:, 1] + 0.5 * eh
+    gw = gt_rois[:, 2] - gt_rois[:, 0] + 1.0
+    gh = gt_rois[:, 3] - gt_rois[:, 1] + 1.0
+    gcx = gt_rois[:, 0] + 0.5 * gw
+    gcy = gt_rois[:, 1] + 0.5 * gh
+    return torch.stack(((gcx - ecx) / diag, (gcy - ecy) / diag, torch.log(gw / ew), torch.log(gh / eh)), 1)
+
+
+def bbox_transform_inv(boxes, deltas, scales=None):
+    if scales is not None:
+        boxes = boxes / scales
+    if len(boxes) == 0:
+        return deltas.detach() * 0
+    w = boxes[:, 2] - boxes[:, 0] + 1.0
+    h = boxes[:, 3] - boxes[:, 1] + 1.0
+    diag = torch.sqrt(torch.pow(w, 2) + torch.pow(h, 2))
+    cx = boxes[:, 0] + 0.5 * w
+    cy = boxes[:, 1] + 0.5 * h
+    dx, dy, dw, dh = deltas[:, 0::4], deltas[:, 1::4], deltas[:, 2::4], deltas[:, 3::4]
+    pcx = dx * diag.unsqueeze(1) + cx.unsqueeze(1)
+    pcy = dy * diag.unsqueeze(1) + cy.unsqueeze(1)
+    pw = torch.exp(dw) * w.unsqueeze(1)
+    ph = torch.exp(dh) * h.unsqueeze(1)
+    parts = [pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph]
+    return torch.cat([p.unsqueeze(2) for p in parts], 2).view(len(boxes), -1)
+
+
+def clip_boxes(boxes, info):
+    """bbox_transform.py:252-255: x in [info[0], info[1]-1], y in [info[2], info[3]-1]."""
+    b = boxes.view(boxes.size(0), -1, 4)
+    info = np.asarray(info, dtype=np.float32)
+    xl, xh, yl, yh = float(info[0]), float(info[1] - np.float32(1)), float(info[2]), float(info[3] - np.float32(1))
+    return torch.stack([b[:, :, 0].clamp(xl, xh), b[:, :, 1].clamp(yl, yh), b[:, :, 2].clamp(xl, xh),
+                        b[:, :, 3].clamp(yl, yh)], 2).view(boxes.size(0), -1)
+
+
+def bbox_overlaps(boxes, query_boxes):
+    """lib/utils/bbox.py:5-33: pairwise IoU with the +1 area convention."""
+    boxes = torch.as_tensor(boxes, dtype=torch.float32)
+    q = torch.as_tensor(query_boxes, dtype=torch.float32)
+    ba = (boxes[:, 2] - boxes[:, 0] + 1) * (boxes[:, 3] - boxes[:, 1] + 1)
+    qa = (q[:, 2] - q[:, 0] + 1) * (q[:, 3] - q[:, 1] + 1)
+    iw = (torch.min(boxes[:, 2:3], q[:, 2:3].t()) - torch.max(boxes[:, 0:1], q[:, 0:1].t()) + 1).clamp(min=0)
+    ih = (torch.min(boxes[:, 3:4], q[:, 3:4].t()) - torch.max(boxes[:, 1:2], q[:, 1:2].t()) + 1).clamp(min=0)
+    ua = ba.view(-1, 1) + qa.view(1, -1) - iw * ih
+    return iw * ih / ua
+
+
+# ----------------------------------------------------------------------------------------------
+# torchvision.ops.nms (0.4.0, un-vendored; PARITY UNPINNED) — call sites proposal_layer.py:46,
+# filter_predictions.py:67-69.  Greedy, areas without +1, drop when IoU > thresh, survivors returned in
+# descending-score order; ties in score broken by ascending index (canonical order of this build).
+# ----------------------------------------------------------------------------------------------
+def stable_desc_order(scores):
+    s = torch.as_tensor(scores, dtype=torch.float32).reshape(-1)
+    return torch.sort(s, descending=True, stable=True)[1]
+
+
+def nms(boxes, scores, thresh):
+    boxes = torch.as_tensor(boxes, dtype=torch.float32)
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.zeros((0,), dtype=torch.int64)
+    order = stable_desc_order(scores).numpy()
+    b = boxes.numpy()[order]
+    x1, y1, x2, y2 = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+    areas = (x2 - x1) * (y2 - y1)
+    thr = np.float32(thresh)
+    dead = np.zeros(n, dtype=bool)
+    keep = []
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for i in range(n):
+            if dead[i]:
+                continue
+            keep.append(order[i])
+            if i + 1 == n:
+                break
+            xx1 = np.maximum(x1[i], x1[i + 1:])
+            yy1 = np.maximum(y1[i], y1[i + 1:])
+            xx2 = np.minimum(x2[i], x2[i + 1:])
+            yy2 = np.minimum(y2[i], y2[i + 1:])
+            w = np.maximum(np.float32(0), xx2 - xx1)
+            h = np.maximum(np.float32(0), yy2 - yy1)
+            inter = w * h
+            ovr = inter / (areas[i] + areas[i + 1:] - inter)
+            dead[i + 1:] |= ovr > thr
+    return torch.as_tensor(np.asarray(keep, dtype=np.int64))
+
+
+# ----------------------------------------------------------------------------------------------
+# proposal_layer — lib/layer_utils/proposal_layer.py:18-57
+# ----------------------------------------------------------------------------------------------
+def proposal_layer(rpn_cls_prob, rpn_bbox_pred, info, anchors, num_anchors, pre_nms_top_n=TEST_RPN_PRE_NMS_TOP_N,
+                   post_nms_top_n=TEST_RPN_POST_NMS_TOP_N, nms_thresh=TEST_RPN_NMS_THRESH, return_debug=False):
+    """rpn_cls_prob (1,H,W,2A) with fg = [..., A:] (:32); rpn_bbox_pred (1,H,W,4A) viewed (-1,4) (:33)."""
+    scores = rpn_cls_prob[:, :, :, num_anchors:].contiguous().view(-1)
+    deltas = rpn_bbox_pred.reshape(-1, 4)
+    proposals = clip_boxes(bbox_transform_inv(anchors, deltas), info)
+    order = stable_desc_order(scores)       # :39 (sort is unstable in torch 1.2; canonical order here)
+    if pre_nms_top_n > 0:
+        order = order[:pre_nms_top_n]
+    sorted_scores = scores[order]
+    sorted_props = proposals[order]
+    keep = nms(sorted_props, sorted_scores, nms_thresh)
+    if post_nms_top_n > 0:
+        keep = keep[:post_nms_top_n]
+    rois = torch.cat((sorted_props.new_zeros(len(keep), 1), sorted_props[keep]), 1)
+    out_scores = sorted_scores[keep].view(-1, 1)
+    if return_debug:
+        return rois, out_scores, {"scores": scores, "proposals": proposals, "order": order, "keep": keep}
+    return rois, out_scores
+
+
+# ----------------------------------------------------------------------------------------------
+# torchvision.ops.roi_align 0.4.0 (aligned=False; PARITY UNPINNED) — call sites
+# lib/utils/torchpoolers.py:165-170,194-197.  feat (1,C,H,W); rois (R,5); out (R,C,P,P).
+# The (iy, ix) accumulation order and the per-sample expression order follow the library's CPU kernel.
+# ----------------------------------------------------------------------------------------------
+def roi_align(feat, rois, pooled, spatial_scale, sampling_ratio=ROI_ALIGN_SAMPLING_RATIO):
+    f = feat.detach().numpy().astype(np.float32, copy=False)
+    r_np = rois.detach().numpy().astype(np.float32, copy=False)
+    _, c, hgt, wid = f.shape
+    out = np.zeros((r_np.shape[0], c, pooled, pooled), dtype=np.float32)
+    scale = np.float32(spatial_scale)
+    pf = np.float32(pooled)
+    ph_idx = np.arange(pooled, dtype=np.float32)
+    for r in range(r_np.shape[0]):
+        b = int(r_np[r, 0])
+        sw, sh = r_np[r, 1] * scale, r_np[r, 2] * scale
+        ew, eh = r_np[r, 3] * scale, r_np[r, 4] * scale
+        rw = max(ew - sw, np.float32(1.0))
+        rh = max(eh - sh, np.float32(1.0))
+        bh, bw = np.float32(rh / pf), np.float32(rw / pf)
+        gh = sampling_ratio if sampling_ratio > 0 else int(math.ceil(np.float32(rh / pf)))
+        gw = sampling_ratio if sampling_ratio > 0 else int(math.ceil(np.float32(rw / pf)))
+        count = np.float32(gh * gw)
+        acc = np.zeros((c, pooled, pooled), dtype=np.float32)
+        fm = f[b]
+        for iy in range(gh):
+            y = (sh + ph_idx * bh) + (np.float32(iy) + np.float32(0.5)) * bh / np.float32(gh)  # (P,)
+            for ix in range(gw):
+                x = (sw + ph_idx * bw) + (np.float32(ix) + np.float32(0.5)) * bw / np.float32(gw)  # (P,)
+                yy, xx = np.meshgrid(y, x, indexing="ij")
+                empty = (yy < -1.0) | (yy > hgt) | (xx < -1.0) | (xx > wid)
+                yy = np.where(yy <= 0, np.float32(0), yy).astype(np.float32)
+                xx = np.where(xx <= 0, np.float32(0), xx).astype(np.float32)
+                yl, xl = yy.astype(np.int32), xx.astype(np.int32)
+                ytop, xtop = yl >= hgt - 1, xl >= wid - 1
+                yl = np.where(ytop, hgt - 1, yl)
+                xl = np.where(xtop, wid - 1, xl)
+                yh_ = np.where(ytop, hgt - 1, yl + 1)
+                xh_ = np.where(xtop, wid - 1, xl + 1)
+                yy = np.where(ytop, yl.astype(np.float32), yy)
+                xx = np.where(xtop, xl.astype(np.float32), xx)
+                ly, lx = yy - yl.astype(np.float32), xx - xl.astype(np.float32)
+                hy, hx = np.float32(1.0) - ly, np.float32(1.0) - lx
+                w1, w2, w3, w4 = hy * hx, hy * lx, ly * hx, ly * lx
+                val = w1 * fm[:, yl, xl] + w2 * fm[:, yl, xh_] + w3 * fm[:, yh_, xl] + w4 * fm[:, yh_, xh_]
+                acc += np.where(empty[None], np.float32(0), val)
+        out[r] = acc / count
+    return torch.from_numpy(out)
+
+
+# ----------------------------------------------------------------------------------------------
+# ResNet-101, caffe stride placement — lib/nets/resnet.py:74-128 (Bottleneck), 131-224 (ResNet),
+# 227-240 (ResNetWrapper stride edits), 275-284 (resnet101).  State-dict keys equal the reference's.
+# ----------------------------------------------------------------------------------------------
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, batchnorm_en=True):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+        self.batchnorm_en = batchnorm_en
+
+    def forward(self, x):
+        out = self.conv1(x)
+        if self.batchnorm_en:
+            out = self.bn1(out)
+        out = F.relu(out)
+        out = self.conv2(out)
+        if self.batchnorm_en:
+            out = self.bn2(out)
+        out = F.relu(out)
+        out = self.conv3(out)
+        if self.batchnorm_en:
+            out = self.bn3(out)
+        identity = x if self.downsample is None else self.downsample(x)
+        return F.relu(out + identity)
+
+
+class ResNet101(nn.Module):
+    """Module tree named like the reference's ``resnet`` attribute (conv1, bn1, layer1..layer4)."""
+
+    def __init__(self, in_channels=3, use_fpn=False, batchnorm_en=True, blocks=(3, 4, 23, 3)):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.layer1 = self._make_layer(64, blocks[0], 1, True)
+        self.layer2 = self._make_layer(128, blocks[1], 2, True)
+        self.layer3 = self._make_layer(256, blocks[2], 2, True)
+        self.layer4 = self._make_layer(512, blocks[3], 2, batchnorm_en)
+        for i in (2, 3):  # resnet.py:232-234: stride on the first 1x1
+            blk = getattr(self, "layer%d" % i)[0]
+            blk.conv1.stride = (2, 2)
+            blk.conv2.stride = (1, 1)
+        if not use_fpn:   # resnet.py:236-238
+            self.layer4[0].conv2.stride = (1, 1)
+            self.layer4[0].downsample[0].stride = (1, 1)
+
+    def _make_layer(self, planes, blocks, stride, bn):
+        down = None
+        if stride != 1 or self.inplanes != planes * 4:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False),
+                                 nn.BatchNorm2d(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, down, bn)]
+        self.inplanes = planes * 4
+        layers += [Bottleneck(self.inplanes, planes, batchnorm_en=bn) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def stem(self, x):
+        return F.max_pool2d(F.relu(self.bn1(self.conv1(x))), kernel_size=3, stride=2, padding=1)
+
+
+def seeded_state_dict(module, seed, bn_mode="identity", all_backbone=False):
+    """Deterministic weights keyed by module NAME (independent of construction order), following the
+    reference's init rules: kaiming-normal fan_out for backbone convs (resnet.py:168-173), N(0,0.01) for
+    rpn_net / rpn_* / cls_score_net / FPN convs and N(0,0.001) for bbox_pred_net (imagenet.py:65-91,
+    fpn.py:47-54), zero biases; BN affine (1,0) with running stats (0,1) for bn_mode='identity', random
+    affine + stats for bn_mode='random' (exercises the BN fold), and 'tame' = 'random' with bn3 damped.  all_backbone=True treats every conv as
+    a backbone conv (stand-alone ResNet101)."""
+    import zlib
+    out = {}
+    for name, m in module.named_modules():
+        g = torch.Generator().manual_seed((int(seed) * 1000003 + zlib.crc32(name.encode())) % (2 ** 63))
+        pre = name + "." if name else ""
+        if isinstance(m, nn.Conv2d):
+            if all_backbone or name.startswith("resnet."):
+                std = math.sqrt(2.0 / (m.out_channels * m.kernel_size[0] * m.kernel_size[1]))
+            else:
+                std = 0.01
+            out[pre + "weight"] = torch.randn(m.weight.shape, generator=g) * std
+            if m.bias is not None:
+                out[pre + "bias"] = torch.zeros_like(m.bias)
+        elif isinstance(m, nn.Linear):
+            std = 0.001 if name == "bbox_pred_net" else 0.01
+            out[pre + "weight"] = torch.randn(m.weight.shape, generator=g) * std
+            out[pre + "bias"] = torch.zeros_like(m.bias)
+        elif isinstance(m, nn.BatchNorm2d):
+            c = m.num_features
+            if bn_mode == "identity":
+                out[pre + "weight"], out[pre + "bias"] = torch.ones(c), torch.zeros(c)
+                out[pre + "running_mean"], out[pre + "running_var"] = torch.zeros(c), torch.ones(c)
+            else:
+                # 'tame': like 'random' but the residual-branch BN (bn3) is damped so that activations
+                # stay O(input) through the 33 blocks instead of growing to 1e7 (workload)
+                damp = 0.25 if (bn_mode == "tame" and name.endswith("bn3")) else 1.0
+                out[pre + "weight"] = (torch.rand(c, generator=g) + 0.5) * damp
+                out[pre + "bias"] = torch.randn(c, generator=g) * 0.1
+                out[pre + "running_mean"] = torch.randn(c, generator=g) * 0.1
+                out[pre + "running_var"] = torch.rand(c, generator=g) + 0.5
+            out[pre + "num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Network (image detector, non-FPN) — RECONSTRUCTED contract of the missing lib/nets/network.py
+#  + lib/nets/imagenet.py:29-134.
+# ----------------------------------------------------------------------------------------------
+class ImageNetOracle(nn.Module):
+    def __init__(self, num_classes=2, anchor_scales=ANCHOR_SCALES, anchor_ratios=ANCHOR_RATIOS, in_channels=3):
+        super().__init__()
+        self._num_classes = num_classes
+        self._anchor_scales = tuple(anchor_scales)
+        self._anchor_ratios = tuple(anchor_ratios)
+        self._num_anchors = len(anchor_scales) * len(anchor_ratios)
+        self._feat_stride = 16                       # imagenet.py:44
+        self.resnet = ResNet101(in_channels=in_channels)
+        a = self._num_anchors
+        self.rpn_net = nn.Conv2d(1024, RPN_CHANNELS, 3, padding=1)
+        self.rpn_cls_score_net = nn.Conv2d(RPN_CHANNELS, 2 * a, 1)
+        self.rpn_bbox_pred_net = nn.Conv2d(RPN_CHANNELS, 4 * a, 1)
+        self.cls_score_net = nn.Linear(2048, num_classes)
+        self.bbox_pred_net = nn.Linear(2048, num_classes * 4)
+        self.eval()
+
+    # imagenet.py:131-134: head = conv1, bn1, relu, maxpool, layer1..3
+    def _image_to_head(self, image):
+        r = self.resnet
+        return r.layer3(r.layer2(r.layer1(r.stem(image))))
+
+    def _region_proposal(self, net_conv, info, structured=None):
+        a = self._num_anchors
+        h, w = net_conv.shape[2], net_conv.shape[3]
+        anchors, _ = generate_anchors_pre(h, w, self._feat_stride, self._anchor_scales, self._anchor_ratios,
+                                          float(info[6]))
+        anchors = torch.from_numpy(anchors)
+        rpn = F.relu(self.rpn_net(net_conv))
+        cls_score = self.rpn_cls_score_net(rpn)                      # (1, 2A, H, W)
+        bbox_pred = self.rpn_bbox_pred_net(rpn).permute(0, 2, 3, 1).contiguous()  # (1, H, W, 4A)
+        if structured is not None:                                   # injected logits / deltas
+            cls_score, bbox_pred = structured
+        # (1,2A,H,W) -> (1,2,A*H,W) softmax over dim 1 -> back -> (1,H,W,2A): channel a pairs with a+A
+        prob = F.softmax(cls_score.view(1, 2, a * h, w), dim=1).view(1, 2 * a, h, w).permute(0, 2, 3, 1).contiguous()
+        rois, scores, dbg = proposal_layer(prob, bbox_pred, info, anchors, a, return_debug=True)
+        self._dbg = {"anchors": anchors, "rpn_cls_prob": prob, "rpn_bbox_pred": bbox_pred, "rpn_cls_score": cls_score,
+                     **dbg}
+        return rois, scores
+
+    def _crop_pool_layer(self, net_conv, rois):
+        return roi_align(net_conv, rois, POOLING_SIZE, 1.0 / self._feat_stride, ROI_ALIGN_SAMPLING_RATIO)
+
+    def _head_to_tail(self, pool5):
+        return self.resnet.layer4(pool5).mean(3).mean(2)
+
+    def _region_classification(self, fc7):
+        cls_score = self.cls_score_net(fc7)
+        return cls_score, F.softmax(cls_score, dim=1), self.bbox_pred_net(fc7)
+
+    @torch.no_grad()
+    def test_frame(self, data, info, structured=None):
+        """data (1,H,W,C) NHWC float32 numpy blob, info 7-vector (minibatch.py:670).
+        Returns (cls_score, cls_prob, pred_boxes, rois, uncertainties={})."""
+        image = torch.from_numpy(np.ascontiguousarray(data)).permute(0, 3, 1, 2).contiguous()
+        net_conv = self._image_to_head(image)
+        rois, _ = self._region_proposal(net_conv, info, structured)
+        pool5 = self._crop_pool_layer(net_conv, rois)
+        fc7 = self._head_to_tail(pool5)
+        cls_score, cls_prob, bbox_pred = self._region_classification(fc7)
+        stds = torch.tensor(BBOX_NORMALIZE_STDS).repeat(self._num_classes).unsqueeze(0)
+        means = torch.tensor(BBOX_NORMALIZE_MEANS).repeat(self._num_classes).unsqueeze(0)
+        deltas = bbox_pred.mul(stds).add(means)
+        pred_boxes = bbox_transform_inv(rois[:, 1:5], deltas, float(info[6]))
+        self._dbg.update({"net_conv": net_conv, "pool5": pool5, "fc7": fc7, "bbox_pred": bbox_pred})
+        return cls_score, cls_prob, pred_boxes, rois, {}
+
+
+# ----------------------------------------------------------------------------------------------
+# filter_and_draw_prep / nms_hstack_torch — lib/utils/filter_predictions.py:45-130, and the max_dets
+# cut of lib/model/test.py:210-221.  Image detector only here.
+# ----------------------------------------------------------------------------------------------
+def filter_and_draw_prep(rois, cls_prob, pred_boxes, info, num_classes, thresh=0.1, nms_thresh=TEST_NMS_THRESH):
+    info = np.asarray(info, dtype=np.float32)
+    fw, fh, scale = info[1] - info[0], info[3] - info[2], info[6]
+    pred_boxes = pred_boxes.clone()
+    pred_boxes[:, 0::4] = torch.clamp_min(pred_boxes[:, 0::4], 0)
+    pred_boxes[:, 1::4] = torch.clamp_min(pred_boxes[:, 1::4], 0)
+    pred_boxes[:, 2::4] = torch.clamp_max(pred_boxes[:, 2::4], float(fw / scale - np.float32(1)))
+    pred_boxes[:, 3::4] = torch.clamp_max(pred_boxes[:, 3::4], float(fh / scale - np.float32(1)))
+    all_boxes = [np.empty((0, 5), dtype=np.float32) for _ in range(num_classes)]
+    for j in range(1, num_classes):
+        inds = torch.where(cls_prob[:, j] > thresh)[0]
+        if inds.numel() == 0:
+            continue
+        cs = cls_prob[inds, j]
+        cb = pred_boxes[inds, j * 4:(j + 1) * 4]
+        dets = np.hstack((cb.numpy(), cs.unsqueeze(1).numpy())).astype(np.float32, copy=False)
+        keep = nms(cb, cs, nms_thresh).numpy()
+        all_boxes[j] = dets[keep, :]
+    return rois[:, 1:5].numpy(), all_boxes, pred_boxes
+
+
+def max_dets_cut(cls_boxes, max_dets):
+    """test.py:213-221: keep score >= the max_dets-th best (ties stay)."""
+    if max_dets > 0 and len(cls_boxes) > max_dets:
+        cut = np.sort(cls_boxes[:, -1])[-max_dets]
+        cls_boxes = cls_boxes[np.where(cls_boxes[:, -1] >= cut)[0], :]
+    return cls_boxes
+
+
+def frame_detect(net, data, info, num_classes, thresh=0.5, max_dets=100, structured=None):
+    """lib/model/test.py:68-93 + :210-221 for one frame -> list over classes of (n,5) arrays."""
+    _, probs, boxes, rois, _ = net.test_frame(data, info, structured)
+    _, all_boxes, _ = filter_and_draw_prep(rois, probs, boxes, info, num_classes, thresh)
+    return [max_dets_cut(b, max_dets) for b in all_boxes]
+
+
+# ----------------------------------------------------------------------------------------------
+# VOC-style AP (lib/datasets/voc_eval.py:53-69, continuous-area rule) for the "mAP delta" report.
+# ----------------------------------------------------------------------------------------------
+def voc_ap(rec, prec):
+    mrec = np.concatenate(([0.0], rec, [1.0]))
+    mpre = np.concatenate(([0.0], prec, [0.0]))
+    for i in range(mpre.size - 1, 0, -1):
+        mpre[i - 1] = np.maximum(mpre[i - 1], mpre[i])
+    i = np.where(mrec[1:] != mrec[:-1])[0]
+    return float(np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1]))
+
+
+def average_precision(dets, gt_boxes, iou_thresh=0.7):
+    """dets (n,5) [x1,y1,x2,y2,score]; gt (g,4).  Greedy matching by descending score, +1 IoU convention."""
+    if len(gt_boxes) == 0:
+        return 0.0
+    if len(dets) == 0:
+        return 0.0
+    order = np.argsort(-dets[:, 4], kind="stable")
+    dets = dets[order]
+    ious = bbox_overlaps(dets[:, :4], gt_boxes).numpy()
+    used = np.zeros(len(gt_boxes), dtype=bool)
+    tp = np.zeros(len(dets))
+    fp = np.zeros(len(dets))
+    for d in range(len(dets)):
+        j = int(np.argmax(ious[d]))
+        if ious[d, j] >= iou_thresh and not used[j]:
+            tp[d] = 1
+            used[j] = True
+        else:
+            fp[d] = 1
+    tp, fp = np.cumsum(tp), np.cumsum(fp)
+    rec = tp / float(len(gt_boxes))
+    prec = tp / np.maximum(tp + fp, np.finfo(np.float64).eps)
+    return voc_ap(rec, prec)
