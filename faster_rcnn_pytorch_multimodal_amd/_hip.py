@@ -20,6 +20,7 @@ PROTOTYPES = {
     "frcnn_last_error": (c_char_p, []),
     "frcnn_conv2d_fwd_ws_bytes": (c_size_t, [c_int] * 10),
     "frcnn_conv2d_fwd": (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 11 + [_P, c_size_t, _P]),
+    "frcnn_conv2d_set_tile": (c_int, [c_int, c_int]),
     "frcnn_maxpool3x3s2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "frcnn_pad_channels": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
     "frcnn_generate_anchors": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),

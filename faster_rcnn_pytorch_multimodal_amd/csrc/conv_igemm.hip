@@ -253,6 +253,9 @@ struct Plan {
   int tm, tn, splits, steps_per_split;
 };
 
+// test / tuning hook: force the block tile (0 = automatic choice)
+int g_force_tm = 0, g_force_tn = 0;
+
 // Pick the block tile and the K split that minimise the estimated time on 256 CUs.  Units: MFMA
 // issue cycles of one SIMD (64 per v_mfma_f32_32x32x2_f32).
 Plan choose_plan(int M, int K, int ksteps, int forced_splits) {
@@ -261,6 +264,7 @@ Plan choose_plan(int M, int K, int ksteps, int forced_splits) {
   Plan best{2, 2, 1, ksteps};
   double best_t = 1e300;
   for (auto& c : cand) {
+    if (g_force_tm > 0 && (c[0] != g_force_tm || c[1] != g_force_tn)) continue;
     const int bm = 64 * c[0], bn = 64 * c[1];
     const long tiles = (long)((M + bm - 1) / bm) * ((K + bn - 1) / bn);
     for (int sp : split_cand) {
@@ -312,6 +316,14 @@ bool conv_args_ok(int n, int h, int w, int c, int k, int r, int s, int stride, i
 }
 
 }  // namespace
+
+extern "C" int frcnn_conv2d_set_tile(int tm, int tn) {
+  FRCNN_REQUIRE((tm == 0 && tn == 0) || ((tm == 1 || tm == 2) && (tn == 1 || tn == 2)),
+                "conv2d_set_tile: tiles are 64*tm x 64*tn with tm,tn in {1,2} (0,0 = automatic)");
+  g_force_tm = tm;
+  g_force_tn = tn;
+  return FRCNN_OK;
+}
 
 extern "C" size_t frcnn_conv2d_fwd_ws_bytes(int n, int h, int w, int c, int k, int r, int s, int stride, int pad,
                                             int split_k) {

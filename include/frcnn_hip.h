@@ -48,6 +48,10 @@ int frcnn_conv2d_fwd(const float* x, const float* wgt, const float* scale, const
                      const float* residual, float* y, int n, int h, int w, int c, int k, int r, int s,
                      int stride, int pad, int relu, int split_k, void* ws, size_t ws_bytes, void* stream);
 
+/* Tuning / test hook: force the workgroup tile to (64*tm) x (64*tn) output pixels x channels for all
+ * following frcnn_conv2d_fwd calls of this process; (0,0) restores the automatic choice. */
+int frcnn_conv2d_set_tile(int tm, int tn);
+
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1)  (lib/nets/resnet.py:156), NHWC. */
 int frcnn_maxpool3x3s2_fwd(const float* x, float* y, int n, int h, int w, int c, void* stream);
 

@@ -1,0 +1,497 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI (ops.py -> ctypes -> libfrcnn_hip.so),
+against the CPU oracle / a plain PyTorch-CPU fp32 reference on the same seeded inputs.
+
+Bars: bit-exact for indices, orders and keep masks; <= 1e-4 abs on box / score tensors; feature tensors
+(unbounded magnitude) within 2e-5 of the tensor's max magnitude (fp32 accumulation-order noise).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import frcnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SCALES, RATIOS = (2, 4, 8, 16, 32), (0.5, 0.75, 1, 1.25, 2)
+DEV = "cuda:0"
+
+
+def _ops():
+    from faster_rcnn_pytorch_multimodal_amd import ops
+    return ops
+
+
+def _close_feat(got, ref, what="", frac=2e-5):
+    got, ref = np.asarray(got, np.float32), np.asarray(ref, np.float32)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    tol = frac * max(float(np.abs(ref).max()), 1e-6)
+    err = float(np.abs(got - ref).max())
+    assert err <= tol, "%s: max abs err %.3e > %.3e (max |ref| %.3e)" % (what, err, tol, np.abs(ref).max())
+
+
+def _rand_boxes(n, gen, extent=(1000, 600), max_wh=300):
+    xy = torch.rand(n, 2, generator=gen) * torch.tensor([extent[0] - 50.0, extent[1] - 50.0])
+    wh = torch.rand(n, 2, generator=gen) * max_wh + 1
+    return torch.cat((xy, xy + wh), 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# conv / pool
+# ------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # n, h, w, c, k, r, stride, pad, relu, res, bn
+    (1, 19, 23, 64, 64, 1, 1, 0, True, False, True),      # 1x1
+    (1, 19, 23, 64, 256, 1, 1, 0, True, True, True),      # 1x1 + residual
+    (1, 20, 26, 256, 128, 1, 2, 0, True, False, True),    # strided 1x1 (caffe placement)
+    (1, 17, 21, 128, 128, 3, 1, 1, True, False, True),    # 3x3
+    (1, 38, 63, 4, 64, 7, 2, 3, True, False, True),       # stem, C padded 3 -> 4
+    (1, 24, 30, 16, 64, 7, 2, 3, True, False, True),      # LiDAR stem, C padded 15 -> 16
+    (1, 12, 15, 512, 150, 1, 1, 0, False, False, False),  # fused RPN head (K = 6A = 150, bias only)
+    (7, 7, 7, 96, 160, 3, 1, 1, True, True, True),        # RoI batch (layer4-style), odd M
+    (1, 9, 11, 1024, 512, 3, 1, 1, True, False, False),   # RPN 3x3 with bias, long K
+    (2, 14, 14, 32, 48, 3, 2, 1, False, False, True),     # strided 3x3 (FPN layer4[0])
+]
+
+
+def _conv_ref(x_nhwc, w_kcrs, scale, shift, res_nhwc, stride, pad, relu):
+    y = F.conv2d(x_nhwc.permute(0, 3, 1, 2).double(), w_kcrs.double(), stride=stride, padding=pad)
+    if scale is not None:
+        y = y * scale.double().view(1, -1, 1, 1)
+    if shift is not None:
+        y = y + shift.double().view(1, -1, 1, 1)
+    y = y.permute(0, 2, 3, 1)
+    if res_nhwc is not None:
+        y = y + res_nhwc.double()
+    return (F.relu(y) if relu else y).float()
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("tile", [(0, 0), (2, 2), (2, 1), (1, 2), (1, 1)])
+def test_conv2d_fwd(hip, case, tile):
+    ops = _ops()
+    n, h, w, c, k, r, stride, pad, relu, use_res, use_bn = case
+    g = torch.Generator().manual_seed(hash(case) % 2 ** 31)
+    x = torch.randn(n, h, w, c, generator=g)
+    if c in (4, 16):
+        x[..., c - 1] = 0  # padded channel
+    wt = torch.randn(k, c, r, r, generator=g) / np.sqrt(c * r * r)
+    scale = torch.rand(k, generator=g) + 0.5 if use_bn else None
+    shift = torch.randn(k, generator=g)
+    ho, wo = ops.conv_out_hw(h, w, r, r, stride, pad)
+    res = torch.randn(n, ho, wo, k, generator=g) if use_res else None
+    ref = _conv_ref(x, wt, scale, shift, res, stride, pad, relu)
+    w_krsc = wt.permute(0, 2, 3, 1).contiguous()
+    dev = lambda t: None if t is None else t.to(DEV)
+    assert hip.frcnn_conv2d_set_tile(*tile) == 0
+    try:
+        for split in (0, 1, 3):
+            got = ops.conv2d_nhwc(dev(x), dev(w_krsc), dev(scale), dev(shift), dev(res), stride=stride, pad=pad,
+                                  relu=relu, split_k=split)
+            torch.cuda.synchronize()
+            _close_feat(got.cpu().numpy(), ref.numpy(), "conv %s tile %s split %d" % (case, tile, split), frac=1e-5)
+    finally:
+        hip.frcnn_conv2d_set_tile(0, 0)
+
+
+def test_conv2d_is_deterministic_and_tile_independent(hip):
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 38, 63, 256, generator=g).to(DEV)
+    w = (torch.randn(256, 3, 3, 256, generator=g) / 48).to(DEV)
+    outs = []
+    for tile in ((2, 2), (1, 1), (2, 1)):
+        hip.frcnn_conv2d_set_tile(*tile)
+        outs.append(ops.conv2d_nhwc(x, w, stride=1, pad=1, split_k=1).cpu())
+    hip.frcnn_conv2d_set_tile(0, 0)
+    # split_k = 1: the MFMA is an exact k-ordered fma chain, so every tile shape gives the same bits
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_conv2d_rejects_bad_arguments(hip):
+    ops = _ops()
+    from faster_rcnn_pytorch_multimodal_amd._hip import HipError
+    x = torch.zeros(1, 8, 8, 6, device=DEV)          # C % 4 != 0
+    with pytest.raises(HipError, match="c%4==0"):
+        ops.conv2d_nhwc(x, torch.zeros(8, 3, 3, 6, device=DEV), pad=1)
+    with pytest.raises(HipError, match="channels"):
+        ops.conv2d_nhwc(torch.zeros(1, 8, 8, 8, device=DEV), torch.zeros(8, 3, 3, 4, device=DEV), pad=1)
+
+
+def test_maxpool_and_pad(hip):
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    for (h, w) in ((300, 500), (31, 47), (2, 2)):
+        x = torch.randn(1, h, w, 64, generator=g)
+        ref = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+        got = ops.maxpool3x3s2_nhwc(x.to(DEV)).cpu()
+        assert torch.equal(got, ref.contiguous())
+    x = torch.randn(1, 5, 7, 3, generator=g)
+    got = ops.pad_channels(x.to(DEV), 4).cpu()
+    assert torch.equal(got[..., :3], x) and (got[..., 3] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# anchors / codec / sort / nms / proposal layer
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg_", [(38, 63, 16, 1.0), (19, 32, 16, 0.5), (5, 7, 16, 0.3), (150, 250, 4, 1.0), (25, 22, 16, 0.5)])
+def test_anchors_bit_exact(hip, cfg_, golden_dir):
+    from faster_rcnn_pytorch_multimodal_amd.layer_utils.snippets import generate_anchors_pre
+    h, w, stride, fs = cfg_
+    got, n = generate_anchors_pre(h, w, stride, SCALES, RATIOS, fs, device=DEV)
+    ref, n_ref = O.generate_anchors_pre(h, w, stride, SCALES, RATIOS, fs)
+    assert n == n_ref and got.dtype == torch.float32
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    if cfg_ == (38, 63, 16, 1.0):  # and against the reference's own output
+        np.testing.assert_array_equal(got.cpu().numpy(), np.load(os.path.join(golden_dir, "anchors.npz"))["pre_38x63_s16"])
+
+
+def test_box_codec_against_reference_golden(hip, golden_dir):
+    ops = _ops()
+    g = np.load(os.path.join(golden_dir, "box_codec.npz"))
+    boxes, d1, d2 = (torch.from_numpy(g[k]).to(DEV) for k in ("boxes", "deltas1", "deltas2"))
+    inv1 = ops.bbox_transform_inv(boxes, d1)
+    inv2 = ops.bbox_transform_inv(boxes, d2)
+    inv2s = ops.bbox_transform_inv(boxes, d2, 0.5)
+    np.testing.assert_allclose(inv1.cpu().numpy(), g["inv1"], rtol=3e-7, atol=1e-4)
+    np.testing.assert_allclose(inv2.cpu().numpy(), g["inv2"], rtol=3e-7, atol=1e-4)
+    np.testing.assert_allclose(inv2s.cpu().numpy(), g["inv2_scale0.5"], rtol=3e-7, atol=1e-4)
+    np.testing.assert_allclose(ops.clip_boxes(inv1, g["info"]).cpu().numpy(), g["clip1"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(ops.clip_boxes(inv2, g["info2"]).cpu().numpy(), g["clip2_info2"], rtol=0, atol=1e-4)
+    # everything except exp() is exact: rows with zero dw/dh deltas must match bit for bit
+    z = ops.bbox_transform_inv(boxes, torch.zeros_like(d1))
+    np.testing.assert_array_equal(z.cpu().numpy(), O.bbox_transform_inv(boxes.cpu(), torch.zeros(len(boxes), 4)).numpy())
+
+
+def test_rpn_decode_clip(hip):
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    h, w, a = 12, 17, 25
+    anchors = torch.from_numpy(O.generate_anchors_pre(h, w, 16, SCALES, RATIOS)[0])
+    rpn = torch.randn(h * w, 6 * a, generator=g)
+    rpn[:, 2 * a:] *= 0.4
+    info = np.array([0, 272, 0, 192, 0, 0, 1.0], np.float32)
+    scores, props = ops.rpn_decode_clip(anchors.to(DEV), info, a, rpn=rpn.to(DEV))
+    # oracle: logits (1,2A,H,W) -> softmax pairs (a, a+A) -> (1,H,W,2A); deltas (1,H,W,4A)
+    cls = rpn[:, :2 * a].reshape(1, h, w, 2 * a).permute(0, 3, 1, 2)
+    prob = F.softmax(cls.reshape(1, 2, a * h, w), dim=1).view(1, 2 * a, h, w).permute(0, 2, 3, 1)
+    ref_scores = prob[..., a:].reshape(-1)
+    ref_props = O.clip_boxes(O.bbox_transform_inv(anchors, rpn[:, 2 * a:].reshape(-1, 4)), info)
+    np.testing.assert_allclose(scores.cpu().numpy(), ref_scores.numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(props.cpu().numpy(), ref_props.numpy(), rtol=0, atol=1e-4)
+    assert props.min().item() >= 0 and props[:, 0::2].max().item() <= 271 and props[:, 1::2].max().item() <= 191
+    # (probs, deltas) form: probabilities are passed through untouched
+    s2, p2 = ops.rpn_decode_clip(anchors.to(DEV), info, a, probs=ref_scores.contiguous().to(DEV),
+                                 deltas=rpn[:, 2 * a:].reshape(-1, 4).contiguous().to(DEV))
+    assert torch.equal(s2.cpu(), ref_scores) and torch.equal(p2.cpu(), props.cpu())
+
+
+def _sort_case(name, n, gen):
+    if name == "random":
+        return torch.rand(n, generator=gen)
+    if name == "ties":
+        return (torch.rand(n, generator=gen) * 50).floor() / 50
+    if name == "saturated":
+        return (torch.rand(n, generator=gen) > 0.7).float()
+    if name == "constant":
+        return torch.full((n,), 0.25)
+    if name == "signed":
+        s = torch.randn(n, generator=gen)
+        s[::7] = 0.0
+        s[3::11] = -0.0
+        return s
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["random", "ties", "saturated", "constant", "signed"])
+@pytest.mark.parametrize("n,top", [(59850, 6000), (59850, 12000), (1100, 6000), (5000, 5000), (37, 16), (1, 300), (16385, 16384)])
+def test_sort_topk_order_bit_exact(hip, name, n, top):
+    ops = _ops()
+    s = _sort_case(name, n, torch.Generator().manual_seed(n + top))
+    order, sorted_scores, count = ops.sort_topk_desc(s.to(DEV), top)
+    ref_order = O.stable_desc_order(s)[:top]
+    assert count.item() == min(n, top)
+    assert torch.equal(order.cpu(), ref_order), "%s n=%d top=%d" % (name, n, top)
+    assert torch.equal(sorted_scores.cpu(), s[ref_order])
+
+
+def _nms_inputs(kind, n, gen):
+    if kind == "clustered":
+        centres = _rand_boxes(40, gen)
+        pick = torch.randint(0, 40, (n,), generator=gen)
+        boxes = centres[pick] + torch.randn(n, 4, generator=gen) * 6
+        boxes[:, 2:] = torch.maximum(boxes[:, 2:], boxes[:, :2] + 1)
+    elif kind == "random":
+        boxes = _rand_boxes(n, gen)
+    elif kind == "degenerate":
+        boxes = _rand_boxes(n, gen)
+        boxes[::3, 2:] = boxes[::3, :2]          # zero area -> NaN IoU with itself
+        boxes[1::5] = torch.tensor([0., 0, 999, 599])
+    else:
+        raise KeyError(kind)
+    return boxes.contiguous()
+
+
+@pytest.mark.parametrize("kind", ["clustered", "random", "degenerate"])
+@pytest.mark.parametrize("n", [6000, 1000, 300, 65, 64, 1])
+def test_nms_keep_bit_exact(hip, kind, n):
+    ops = _ops()
+    gen = torch.Generator().manual_seed(n * 7 + len(kind))
+    boxes = _nms_inputs(kind, n, gen)
+    scores = torch.sort(torch.rand(n, generator=gen), descending=True)[0]   # already in score order
+    ref = O.nms(boxes, scores, 0.7)
+    keep_idx, count, mask = ops.nms_sorted(boxes.to(DEV), 0.7, want_mask=True)
+    c = count.item()
+    assert c == len(ref)
+    assert torch.equal(keep_idx[:c].cpu(), ref)
+    ref_mask = torch.zeros(n, dtype=torch.uint8)
+    ref_mask[ref] = 1
+    assert torch.equal(mask.cpu(), ref_mask)
+    # truncated form (post_nms_topN) and device-side live count
+    k2, c2, _ = ops.nms_sorted(boxes.to(DEV), 0.7, max_keep=min(300, n))
+    assert torch.equal(k2[:c2.item()].cpu(), ref[:300])
+    if n > 10:
+        live = torch.tensor([n - 7], dtype=torch.int32, device=DEV)
+        k3, c3, _ = ops.nms_sorted(boxes.to(DEV), 0.7, n_dev=live)
+        ref3 = O.nms(boxes[:n - 7], scores[:n - 7], 0.7)
+        assert torch.equal(k3[:c3.item()].cpu(), ref3)
+
+
+def test_nms_threshold_edge(hip):
+    ops = _ops()
+    boxes = torch.tensor([[0., 0, 10, 10], [0, 0, 10, 5], [0, 0, 10, 7], [20, 20, 30, 30], [0, 0, 10, 7.0001]])
+    for thr, want in ((0.5, [0, 1, 3]), (0.49, [0, 3]), (0.7, [0, 1, 2, 3])):
+        k, c, _ = ops.nms_sorted(boxes.to(DEV), thr)
+        assert k[:c.item()].cpu().tolist() == O.nms(boxes, torch.arange(5, 0, -1).float(), thr).tolist()
+        if thr != 0.7:
+            assert k[:c.item()].cpu().tolist() == want
+
+
+@pytest.mark.parametrize("shape", [(38, 63, 6000, 300), (12, 17, 6000, 300), (25, 22, 12000, 2000)])
+def test_proposal_layer_matches_oracle(hip, shape):
+    from faster_rcnn_pytorch_multimodal_amd.layer_utils.proposal_layer import proposal_layer
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    h, w, pre, post = shape
+    a = 25
+    C.reset_cfg()
+    C.cfg.TEST.RPN_PRE_NMS_TOP_N, C.cfg.TEST.RPN_POST_NMS_TOP_N = pre, post
+    g = torch.Generator().manual_seed(h * w)
+    anchors = torch.from_numpy(O.generate_anchors_pre(h, w, 16, SCALES, RATIOS)[0])
+    prob = torch.rand(1, h, w, 2 * a, generator=g)
+    prob[0, :, :, a:][torch.rand(h, w, a, generator=g) > 0.9] = 1.0        # saturated ties
+    deltas = torch.randn(1, h, w, 4 * a, generator=g) * 0.3
+    info = np.array([0, w * 16, 0, h * 16, 0, 0, 1.0], np.float32)
+    rois_ref, scores_ref, dbg = O.proposal_layer(prob, deltas, info, anchors, a, pre, post, 0.7, return_debug=True)
+    blob, scores, _ = proposal_layer(prob.to(DEV), deltas.to(DEV), info, "TEST", anchors.to(DEV), None, a)
+    C.reset_cfg()
+    assert blob.shape == rois_ref.shape
+    assert torch.equal(scores.cpu(), scores_ref)                       # same boxes chosen, in the same order
+    np.testing.assert_allclose(blob.cpu().numpy(), rois_ref.numpy(), rtol=0, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# RoIAlign / detection tail / per-class filter
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sampling", [0, 2])
+def test_roi_align_matches_oracle(hip, sampling):
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    c, h, w = 64, 38, 63
+    feat = torch.randn(1, c, h, w, generator=g)
+    rois = torch.cat((torch.zeros(60, 1), _rand_boxes(60, g)), 1)
+    rois[0, 1:] = torch.tensor([0., 0, 999, 599])            # whole frame
+    rois[1, 1:] = torch.tensor([500., 300, 500, 300])        # empty -> widened to 1 px
+    rois[2, 1:] = torch.tensor([990., 590, 1200, 800])       # hangs over the border
+    rois[3, 1:] = torch.tensor([-40., -30, 20, 10])          # starts outside
+    ref = O.roi_align(feat, rois, 7, 1 / 16.0, sampling)      # (R, C, 7, 7)
+    got = ops.roi_align_nhwc(feat.permute(0, 2, 3, 1).contiguous().to(DEV), rois.to(DEV), 7, 1 / 16.0, sampling)
+    _close_feat(got.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), "roi_align", frac=2e-6)
+    # device-side count masks the tail to zero
+    cnt = torch.tensor([10], dtype=torch.int32, device=DEV)
+    got2 = ops.roi_align_nhwc(feat.permute(0, 2, 3, 1).contiguous().to(DEV), rois.to(DEV), 7, 1 / 16.0, sampling,
+                              roi_count=cnt)
+    assert torch.equal(got2[:10], got[:10]) and (got2[10:] == 0).all()
+
+
+def test_head_fc_softmax_decode(hip):
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    r, c, k = 37, 2048, 2
+    x = torch.randn(r, c, 7, 7, generator=g)
+    wc, bc = torch.randn(k, c, generator=g) * 0.01, torch.randn(k, generator=g) * 0.1
+    wb, bb = torch.randn(4 * k, c, generator=g) * 0.01, torch.randn(4 * k, generator=g) * 0.1
+    rois = torch.cat((torch.zeros(r, 1), _rand_boxes(r, g)), 1)
+    fc7 = x.mean(3).mean(2)
+    cls_score = F.linear(fc7, wc, bc)
+    cls_prob = F.softmax(cls_score, 1)
+    bbox_pred = F.linear(fc7, wb, bb)
+    stds = torch.tensor(O.BBOX_NORMALIZE_STDS).repeat(k)
+    pred = O.bbox_transform_inv(rois[:, 1:5], bbox_pred * stds, 0.5)
+    out = ops.head_fc_softmax_decode(x.permute(0, 2, 3, 1).contiguous().to(DEV), wc.to(DEV), bc.to(DEV), wb.to(DEV),
+                                     bb.to(DEV), rois.to(DEV), O.BBOX_NORMALIZE_STDS, O.BBOX_NORMALIZE_MEANS, 0.5)
+    np.testing.assert_allclose(out["fc7"].cpu().numpy(), fc7.numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out["cls_score"].cpu().numpy(), cls_score.numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(out["cls_prob"].cpu().numpy(), cls_prob.numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(out["bbox_pred"].cpu().numpy(), bbox_pred.numpy(), rtol=0, atol=1e-5)
+    # boxes up to 2000 px: 1e-4 abs needs the deltas to agree to ~1e-7; compare with the decode of OUR deltas too
+    pred_own = O.bbox_transform_inv(rois[:, 1:5], out["bbox_pred"].cpu() * stds, 0.5)
+    np.testing.assert_allclose(out["pred_boxes"].cpu().numpy(), pred_own.numpy(), rtol=3e-7, atol=1e-4)
+    np.testing.assert_allclose(out["pred_boxes"].cpu().numpy(), pred.numpy(), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("thresh,max_dets", [(0.1, 100), (0.5, 100), (0.05, 20), (0.999, 100)])
+def test_filter_per_class_matches_oracle(hip, thresh, max_dets):
+    from faster_rcnn_pytorch_multimodal_amd.utils.filter_predictions import filter_device
+    g = torch.Generator().manual_seed(int(thresh * 1000) + max_dets)
+    r, k = 300, 3
+    info = np.array([0, 1000, 0, 600, 0, 0, 1.0], np.float32)
+    prob = F.softmax(torch.randn(r, k, generator=g) * 2, 1)
+    prob[5:9, 1] = prob[5, 1]                                  # score ties
+    centres = _rand_boxes(12, g)
+    boxes = torch.cat([centres[torch.randint(0, 12, (r,), generator=g)] + torch.randn(r, 4, generator=g) * 8
+                       for _ in range(k)], 1)
+    boxes[:, 0::4] -= 30                                        # some boxes leave the frame -> clamp matters
+    rois = torch.cat((torch.zeros(r, 1), boxes[:, :4]), 1)
+    _, ref_boxes, ref_clamped = O.filter_and_draw_prep(rois, prob, boxes, info, k, thresh)
+    ref = [O.max_dets_cut(b, max_dets) for b in ref_boxes]
+    boxes_dev = boxes.contiguous().to(DEV)
+    dets, counts = filter_device(None, prob.contiguous().to(DEV), boxes_dev, info, thresh, max_dets, r)
+    assert torch.equal(boxes_dev.cpu(), ref_clamped)            # in-place clamp like the reference
+    dets, counts = dets.cpu().numpy(), counts.cpu().numpy()
+    for j in range(1, k):
+        assert counts[j] == len(ref[j]), (j, counts[j], len(ref[j]))
+        # the oracle's max_dets cut keeps index order; ours is score order: compare as sorted sets of rows
+        got = dets[j, :counts[j]]
+        want = ref[j]
+        if len(want):
+            want = want[np.lexsort((np.arange(len(want)), -want[:, 4]))]
+            np.testing.assert_array_equal(got, want)
+    assert counts[0] == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# backbone against the reference's golden stage outputs, and the whole detector against the oracle
+# ------------------------------------------------------------------------------------------------
+def test_resnet101_stages_against_reference_golden(hip, golden_dir):
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.nets import resnet as R
+    C.reset_cfg()
+    g = np.load(os.path.join(golden_dir, "resnet101_stages.npz"))
+    net = R.resnet101()
+    net.eval()
+    for mode, seed in (("random", 11), ("tame", 12)):
+        net.load_state_dict(O.seeded_state_dict(net, seed, bn_mode=mode, all_backbone=True), strict=True)
+        net.to(DEV)
+        x = torch.from_numpy(g[mode + "_x"]).permute(0, 2, 3, 1).contiguous().to(DEV)
+        from faster_rcnn_pytorch_multimodal_amd import ops
+        with torch.no_grad():
+            stem = net.stem()(ops.pad_channels(x, 4))
+            l1 = net.layer1(stem)
+            l2 = net.layer2(l1)
+            l3 = net.layer3(l2)
+            pooled = torch.from_numpy(g[mode + "_pooled"]).permute(0, 2, 3, 1).contiguous().to(DEV)
+            l4 = net.layer4(pooled)
+        for name, got in (("stem", stem), ("layer1", l1), ("layer2", l2), ("layer3", l3)):
+            _close_feat(got.cpu().permute(0, 3, 1, 2).numpy(), g[mode + "_" + name], mode + " " + name, frac=3e-5)
+        l4 = l4.cpu().permute(0, 3, 1, 2)
+        _close_feat(l4.numpy()[:, ::16], g[mode + "_layer4_probe"], mode + " layer4", frac=3e-5)
+        _close_feat(l4.mean(3).mean(2).numpy(), g[mode + "_layer4_mean"], mode + " layer4 mean", frac=3e-5)
+
+
+def _build_pair(seed=5, bn_mode="tame"):
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.nets.imagenet import imagenet
+    C.reset_cfg()
+    C.cfg.NET_TYPE = "image"
+    oracle = O.ImageNetOracle(num_classes=2)
+    sd = O.seeded_state_dict(oracle, seed, bn_mode=bn_mode)
+    oracle.load_state_dict(sd, strict=True)
+    net = imagenet(num_layers=101)
+    net.create_architecture(2, tag="default", anchor_scales=C.cfg.ANCHOR_SCALES, anchor_ratios=C.cfg.ANCHOR_RATIOS)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    net._device = DEV
+    net.to(DEV)
+    return net, oracle
+
+
+def test_detector_stagewise_against_oracle(hip):
+    """Whole image detector on a 192x320 frame.  Stage outputs are compared where the two paths still
+    see the same inputs; the proposal / detection stages are re-run on the ORACLE's intermediate tensors
+    so that index parity is not blurred by conv rounding noise."""
+    from faster_rcnn_pytorch_multimodal_amd import ops
+    from faster_rcnn_pytorch_multimodal_amd.layer_utils.proposal_layer import proposal_layer_device
+    net, oracle = _build_pair()
+    rng = np.random.default_rng(0)
+    data = (rng.standard_normal((1, 192, 320, 3)) * 50).astype(np.float32)
+    info = np.array([0, 320, 0, 192, 0, 0, 1.0], np.float32)
+    cs_r, cp_r, pb_r, rois_r, _ = oracle.test_frame(data, info)
+    d = oracle._dbg
+    cs, cp, pb, rois, _ = net.test_frame(data, info)
+    p = net._predictions
+    # backbone
+    _close_feat(net._act_summaries["conv"].cpu().permute(0, 3, 1, 2).numpy(), d["net_conv"].numpy(), "net_conv", 5e-5)
+    # RPN head: logits|deltas (1,H,W,6A) vs oracle's (1,2A,H,W) scores and (1,H,W,4A) deltas
+    a = 25
+    rpn_out = p["rpn_out"].cpu()
+    _close_feat(rpn_out[..., :2 * a].permute(0, 3, 1, 2).numpy(), d["rpn_cls_score"].numpy(), "rpn_cls_score", 1e-4)
+    _close_feat(rpn_out[..., 2 * a:].numpy(), d["rpn_bbox_pred"].numpy(), "rpn_bbox_pred", 1e-4)
+    # proposal stage on the oracle's probabilities/deltas: bit-exact choice, boxes within 1e-4
+    fg = d["rpn_cls_prob"][..., a:].contiguous().view(-1).to(DEV)
+    res = proposal_layer_device(d["anchors"].to(DEV), info, a, 6000, 300, 0.7, rpn_cls_prob_fg=fg,
+                                rpn_bbox_pred=d["rpn_bbox_pred"].reshape(-1, 4).contiguous().to(DEV))
+    n = res.count.item()
+    assert n == rois_r.shape[0]
+    assert torch.equal(res.order[res.keep_idx[:n]].cpu(), d["order"][d["keep"]])
+    np.testing.assert_allclose(res.rois[:n].cpu().numpy(), rois_r.numpy(), rtol=0, atol=1e-4)
+    # RoIAlign + layer4 + tail on the oracle's net_conv / rois
+    feat = d["net_conv"].permute(0, 2, 3, 1).contiguous().to(DEV)
+    pool = ops.roi_align_nhwc(feat, rois_r.contiguous().to(DEV), 7, 1 / 16.0, 0)
+    _close_feat(pool.cpu().permute(0, 3, 1, 2).numpy(), d["pool5"].numpy(), "pool5", 2e-6)
+    with torch.no_grad():
+        y = net.resnet.layer4(d["pool5"].permute(0, 2, 3, 1).contiguous().to(DEV))
+        net._frame_scale = 1.0
+        tail = net._tail_kernel(y, rois_r.contiguous().to(DEV))
+    _close_feat(tail["fc7"].cpu().numpy(), d["fc7"].numpy(), "fc7", 5e-5)
+    np.testing.assert_allclose(tail["cls_prob"].cpu().numpy(), cp_r.numpy(), rtol=0, atol=1e-4)
+    # end to end (conv rounding noise included): same number of proposals is NOT guaranteed, report only
+    print("e2e: proposals hip=%d oracle=%d; max |cls_prob diff| on common rows = %.3e" % (
+        rois.shape[0], rois_r.shape[0],
+        float((cp[:min(len(cp), len(cp_r))].cpu() - cp_r[:min(len(cp), len(cp_r))]).abs().max())))
+
+
+def test_full_size_frame_properties(hip):
+    """1000x600 (BASELINE config 2): size-independent properties of the device pipeline."""
+    from faster_rcnn_pytorch_multimodal_amd import ops
+    from faster_rcnn_pytorch_multimodal_amd.model.test import detect_frame_device
+    net, _ = _build_pair(seed=7)
+    rng = np.random.default_rng(1)
+    data = (rng.standard_normal((1, 600, 1000, 3)) * 50).astype(np.float32)
+    info = np.array([0, 1000, 0, 600, 0, 0, 1.0], np.float32)
+    dets, counts = detect_frame_device(net, data, info, thresh=0.0, max_dets=100)
+    p = net._predictions
+    n = p["rois_count"].item()
+    assert 0 < n <= 300 and net._act_summaries["conv"].shape == (1, 38, 63, 1024)
+    rois = p["rois"][:n].cpu()
+    assert (rois[:, 0] == 0).all() and rois[:, 1:].min() >= 0
+    assert rois[:, 3].max() <= 999 and rois[:, 4].max() <= 599
+    s = p["roi_scores"][:n, 0].cpu()
+    assert (s[:-1] >= s[1:]).all()                                        # sortedness
+    # the selected order is the canonical one
+    assert torch.equal(p["rpn_order"].cpu(), O.stable_desc_order(p["rpn_scores"].cpu())[:6000])
+    # idempotence: NMS over its own survivors keeps all of them
+    k2, c2, _ = ops.nms_sorted(rois[:, 1:5].contiguous().to(DEV), 0.7)
+    assert c2.item() == n and torch.equal(k2[:n].cpu(), torch.arange(n))
+    # and the keep list equals the oracle's NMS on the same (device-produced) sorted boxes
+    sorted_boxes = ops.gather_rows(p["rpn_proposals"], p["rpn_order"]).cpu()
+    ref_keep = O.nms(sorted_boxes, torch.arange(len(sorted_boxes), 0, -1).float(), 0.7)[:300]
+    assert torch.equal(p["rpn_keep"][:n].cpu(), ref_keep)
+    prob = p["cls_prob"][:n].cpu()
+    np.testing.assert_allclose(prob.sum(1).numpy(), 1.0, atol=1e-5)
+    c = counts.cpu().numpy()
+    assert c[0] == 0 and 0 <= c[1] <= n
+    # determinism: a second run gives identical bits
+    dets2, counts2 = detect_frame_device(net, data, info, thresh=0.0, max_dets=100)
+    assert torch.equal(dets, dets2) and torch.equal(counts, counts2)

@@ -1,0 +1,105 @@
+"""CPU: host logic of the product package — config, anchor base table, C-ABI surface, loud failure."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from faster_rcnn_pytorch_multimodal_amd import _hip, ops
+from faster_rcnn_pytorch_multimodal_amd.layer_utils.generate_anchors import generate_anchors
+from faster_rcnn_pytorch_multimodal_amd.model import config as C
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_base_anchor_table_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "anchors.npz"))
+    np.testing.assert_array_equal(generate_anchors(), g["default9"])
+    np.testing.assert_array_equal(generate_anchors(ratios=np.array([0.5, 0.75, 1, 1.25, 2]),
+                                                   scales=np.array([2, 4, 8, 16, 32])), g["waymo25"])
+    # the dense grid = base + shift in float64, rounded once: check the first cell rows against the golden grid
+    full = g["pre_38x63_s16"]
+    np.testing.assert_array_equal(g["waymo25"].astype(np.float32), full[:25])
+    # non-dyadic frame scale (scales * 0.3): float32(base64 + shift) must equal the reference grid
+    base = generate_anchors(ratios=np.array([0.5, 0.75, 1, 1.25, 2]), scales=np.array([2, 4, 8, 16, 32]) * 0.3)
+    grid = g["pre_5x7_s16_fs0.3"].reshape(5, 7, 25, 4)
+    for (y, x) in ((0, 0), (2, 3), (4, 6)):
+        shift = np.array([x * 16, y * 16, x * 16, y * 16], dtype=np.float64)
+        np.testing.assert_array_equal((base + shift).astype(np.float32), grid[y, x])
+
+
+def test_cfg_defaults_and_overrides():
+    C.reset_cfg()
+    cfg = C.cfg
+    assert cfg.TEST.RPN_PRE_NMS_TOP_N == 6000 and cfg.TEST.RPN_POST_NMS_TOP_N == 300
+    assert cfg.TEST.RPN_NMS_THRESH == 0.7 and cfg.TEST.NMS_THRESH == 0.6
+    assert cfg.ANCHOR_SCALES == [2, 4, 8, 16, 32] and cfg.POOLING_SIZE == 7 and cfg.RPN_CHANNELS == 512
+    assert cfg.TRAIN.IMAGE.BBOX_NORMALIZE_STDS == (0.1, 0.1, 0.2, 0.2)
+    C.cfg_from_list(["TEST.RPN_POST_NMS_TOP_N", "100", "POOLING_MODE", "multiscale"])
+    assert cfg.TEST.RPN_POST_NMS_TOP_N == 100 and cfg.POOLING_MODE == "multiscale"
+    with pytest.raises(AssertionError):
+        C.cfg_from_list(["TEST.NO_SUCH_KEY", "1"])
+    with pytest.raises(AssertionError):
+        C.cfg_from_list(["TEST.RPN_POST_NMS_TOP_N", "'three'"])
+    C.reset_cfg()
+    assert cfg.TEST.RPN_POST_NMS_TOP_N == 300
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "frcnn_hip.h")).read()
+    declared = set(re.findall(r"\b(frcnn_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    assert os.path.exists(_hip.library_path()), "libfrcnn_hip.so not built: run __graft_entry__.build()"
+    lib = ctypes.CDLL(_hip.library_path())
+    missing = [name for name in sorted(declared) if not hasattr(lib, name)]
+    assert not missing, "declared in include/frcnn_hip.h but not exported: %s" % missing
+    assert declared == set(_hip.PROTOTYPES), "ctypes prototypes out of sync with the header"
+    lib.frcnn_version.restype = ctypes.c_int
+    assert lib.frcnn_version() >= 100
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    lib = _hip.load()
+    # null pointers / bad shapes are rejected on the host before any launch
+    rc = lib.frcnn_conv2d_fwd(None, None, None, None, None, None, 1, 8, 8, 4, 8, 3, 3, 1, 1, 0, 0, None, 0, None)
+    assert rc == -1 and b"null" in lib.frcnn_last_error()
+    assert lib.frcnn_conv2d_fwd_ws_bytes(1, 8, 8, 3, 8, 3, 3, 1, 1, 0) == 0      # c % 4 != 0 -> invalid
+    assert lib.frcnn_nms_ws_bytes(6000) == 6000 * 94 * 8
+    assert lib.frcnn_conv2d_fwd_ws_bytes(1, 38, 63, 256, 256, 3, 3, 1, 1, 3) == 3 * 38 * 63 * 256 * 4
+
+
+def test_product_has_no_cpu_path():
+    with pytest.raises(_hip.HipError, match="no CPU path"):
+        ops.conv2d_nhwc(torch.zeros(1, 8, 8, 4), torch.zeros(8, 3, 3, 4))
+    from faster_rcnn_pytorch_multimodal_amd.nets.imagenet import imagenet
+    C.reset_cfg()
+    C.cfg.NET_TYPE = "image"
+    net = imagenet(num_layers=101)
+    net.create_architecture(2, tag="default", anchor_scales=C.cfg.ANCHOR_SCALES, anchor_ratios=C.cfg.ANCHOR_RATIOS)
+    net._device = "cpu"
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        net.test_frame(np.zeros((1, 32, 32, 3), np.float32), np.array([0, 32, 0, 32, 0, 0, 1], np.float32))
+
+
+def test_state_dict_keys_follow_the_reference_names():
+    from faster_rcnn_pytorch_multimodal_amd.nets.imagenet import imagenet
+    from oracle.frcnn_oracle import ImageNetOracle
+    C.reset_cfg()
+    C.cfg.NET_TYPE = "image"
+    net = imagenet(num_layers=101)
+    net.create_architecture(2, tag="default", anchor_scales=C.cfg.ANCHOR_SCALES, anchor_ratios=C.cfg.ANCHOR_RATIOS)
+    keys = set(net.state_dict().keys())
+    for k in ("resnet.conv1.weight", "resnet.bn1.running_var", "resnet.layer1.0.downsample.0.weight",
+              "resnet.layer3.22.bn3.num_batches_tracked", "resnet.layer4.2.conv3.weight", "rpn_net.weight",
+              "rpn_cls_score_net.bias", "rpn_bbox_pred_net.weight", "cls_score_net.weight", "bbox_pred_net.bias"):
+        assert k in keys, k
+    assert keys == set(ImageNetOracle().state_dict().keys())
+    assert net.rpn_cls_score_net.weight.shape == (50, 512, 1, 1) and net.bbox_pred_net.weight.shape == (8, 2048)
+    # frozen-parameter policy of lib/nets/imagenet.py:96-116 with FIXED_BLOCKS = 1
+    assert not net.resnet.conv1.weight.requires_grad and not net.resnet.layer1[0].conv1.weight.requires_grad
+    assert net.resnet.layer2[0].conv1.weight.requires_grad and not net.resnet.layer2[0].bn1.weight.requires_grad
+    # caffe stride placement (lib/nets/resnet.py:232-238)
+    assert net.resnet.layer2[0].conv1.stride == (2, 2) and net.resnet.layer2[0].conv2.stride == (1, 1)
+    assert net.resnet.layer4[0].conv2.stride == (1, 1) and net.resnet.layer4[0].downsample[0].stride == (1, 1)
