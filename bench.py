@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""Headline benchmark: frames/s of the res101 image Faster R-CNN forward at 1000x600 (BASELINE.json
+configs[1]) on N MI355X GPUs, one process per GPU, one frame per GPU per step.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one synthetic frame per rank through the whole hot path (channel pad -> ResNet-101 head -> RPN ->
+proposal sort/NMS -> RoIAlign -> layer4 on 300 RoIs -> detection tail -> per-class filter with the
+max_dets cut), replayed as one hipGraph, followed (N > 1) by the RCCL all-gather of the fixed-size
+detection records (the eval collate).  Frames are resident in HBM before the timed region starts.
+Rank 0 prints ONE JSON line; `roofline` is for the dominant kernel (the fp32-MFMA implicit-GEMM conv),
+`cpu_baseline` times the CPU oracle on a bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+H, W, C = 600, 1000, 3
+NUM_CLASSES = 2
+THRESH, MAX_DETS = 0.5, 100          # tools/test_net.py:290
+WEIGHT_SEED, BN_MODE = 3, "tame"     # cfg.RNG_SEED; see DESIGN.md "workload" for why BN is damped
+MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix peak
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_frame(seed):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((1, H, W, C)) * 50).astype(np.float32)
+
+
+def build_net(device):
+    from faster_rcnn_pytorch_multimodal_amd.model import config as Cfg
+    from faster_rcnn_pytorch_multimodal_amd.nets.imagenet import imagenet
+    from faster_rcnn_pytorch_multimodal_amd.utils.init_utils import seeded_state_dict
+    Cfg.reset_cfg()
+    Cfg.cfg.NET_TYPE = "image"
+    net = imagenet(num_layers=101)
+    net.create_architecture(NUM_CLASSES, tag="default", anchor_scales=Cfg.cfg.ANCHOR_SCALES,
+                            anchor_ratios=Cfg.cfg.ANCHOR_RATIOS)
+    sd = seeded_state_dict(net, WEIGHT_SEED, bn_mode=BN_MODE)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    net._device = device
+    net.to(device)
+    return net, sd
+
+
+def conv_roofline(net, frame, info, steps):
+    """Per-launch HIP-event timing of every conv kernel over `steps` eager frames (events are recorded on
+    the launch stream).  Returns the aggregate over all conv launches of a frame."""
+    from faster_rcnn_pytorch_multimodal_amd import ops
+    from faster_rcnn_pytorch_multimodal_amd.model.test import detect_frame_device
+    detect_frame_device(net, frame, info, THRESH, MAX_DETS, MAX_DETS)
+    torch.cuda.synchronize()
+    ops.PROFILE = []
+    for _ in range(steps):
+        detect_frame_device(net, frame, info, THRESH, MAX_DETS, MAX_DETS)
+    torch.cuda.synchronize()
+    prof, ops.PROFILE = ops.PROFILE, None
+    per_layer = {}
+    total_ms, total_flops = 0.0, 0.0
+    for shp, e0, e1 in prof:
+        ms = e0.elapsed_time(e1)
+        fl = shp["flops"] * (3.0 / 4.0 if (shp["r"] == 7 and shp["c"] == 4) else 1.0)  # stem: 3 real channels
+        total_ms += ms
+        total_flops += fl
+        key = "%dx%dx%d c%d k%d r%d s%d" % (shp["n"], shp["h"], shp["w"], shp["c"], shp["k"], shp["r"], shp["stride"])
+        ent = per_layer.setdefault(key, [0, 0.0, 0.0])
+        ent[0] += 1
+        ent[1] += ms
+        ent[2] += fl
+    launches = len(prof) / steps
+    return {"ms_per_frame": total_ms / steps, "flops_per_frame": total_flops / steps, "launches_per_frame": launches,
+            "per_layer": {k: {"calls_per_frame": v[0] / steps, "us_per_call": 1e3 * v[1] / v[0],
+                              "tflops": v[2] / v[1] / 1e9} for k, v in per_layer.items()}}
+
+
+def roi_align_timing(net, steps):
+    """HIP-event timing of the RoIAlign launch on the last frame's feature map / rois."""
+    from faster_rcnn_pytorch_multimodal_amd import ops
+    feat = net._act_summaries["conv"]
+    rois = net._predictions["rois"]
+    ops.roi_align_nhwc(feat, rois, 7, 1.0 / 16.0, 0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        ops.roi_align_nhwc(feat, rois, 7, 1.0 / 16.0, 0)
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / steps
+    n, h, w, c = feat.shape
+    bytes_ = h * w * c * 4 + rois.shape[0] * 7 * 7 * c * 4 + rois.numel() * 4
+    return {"bound": "hbm", "kernel": "roi_align_fwd_nhwc", "achieved": bytes_ / us / 1e3, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": bytes_ / us / 1e3 / HBM_PEAK_GBS, "traffic": None, "us_per_launch": us,
+            "algorithmic_bytes": bytes_}
+
+
+def cpu_baseline(sd, frames, info):
+    """The CPU oracle (PyTorch-CPU restatement of the reference path) on this host: 1 warm-up + len(frames)
+    timed frames of the same workload."""
+    from oracle import frcnn_oracle as O
+    net = O.ImageNetOracle(num_classes=NUM_CLASSES)
+    net.load_state_dict(sd, strict=True)
+    O.frame_detect(net, frames[0], info, NUM_CLASSES, THRESH, MAX_DETS)
+    t0 = time.perf_counter()
+    for f in frames:
+        O.frame_detect(net, f, info, NUM_CLASSES, THRESH, MAX_DETS)
+    dt = time.perf_counter() - t0
+    return {"value": len(frames) / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d frames of the 1000x600 res101 workload (CPU oracle: torch-CPU convs + numpy NMS/RoIAlign), "
+                      "%.1f s, os.cpu_count()=%d" % (len(frames), dt, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--layers", action="store_true", help="print the per-layer conv table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; this package has no CPU execution path")
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(device))
+
+    from faster_rcnn_pytorch_multimodal_amd.model.frame_graph import FrameRunner
+    net, sd = build_net(device)
+    info = np.array([0, W, 0, H, 0, 0, 1.0], np.float32)
+    # frames resident in HBM: rank r gets frames r, r+world, ... (BASELINE configs[4]: seeds 0..7 on 8 GPUs)
+    n_resident = 4
+    frames_host = [synthetic_frame(rank + world * i) for i in range(n_resident)]
+    frames = [torch.from_numpy(f).to(device) for f in frames_host]
+    runner = FrameRunner(net, H, W, C, info, THRESH, MAX_DETS, use_graph=not args.no_graph)
+    rec = torch.zeros((NUM_CLASSES, MAX_DETS, 5), device=device)
+    cnt = torch.zeros((NUM_CLASSES,), dtype=torch.int32, device=device)
+    gathered = torch.zeros((world, NUM_CLASSES * MAX_DETS * 5 + NUM_CLASSES), device=device) if world > 1 else None
+
+    def step(i):
+        dets, counts = runner.run(frames[i % n_resident])
+        if world > 1:
+            # eval collate: one fixed-size record per rank (detections + counts), all-gathered over xGMI
+            record = torch.cat((dets.reshape(-1), counts.to(torch.float32)))
+            dist.all_gather_into_tensor(gathered, record)
+        else:
+            rec.copy_(dets, non_blocking=True)
+            cnt.copy_(counts, non_blocking=True)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    if world > 1:
+        host = gathered.cpu()   # rank-local copy of the collated records (device->host, inside the timed region)
+    else:
+        host = (rec.cpu(), cnt.cpu())
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    del host
+
+    out = None
+    if rank == 0:
+        conv = conv_roofline(net, frames[0], info, steps=min(args.steps, 5))
+        achieved = conv["flops_per_frame"] / (conv["ms_per_frame"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_f32 (all instantiations, %d launches/frame)"
+                    % round(conv["launches_per_frame"]), "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "flops_per_frame": conv["flops_per_frame"], "kernel_ms_per_frame": conv["ms_per_frame"],
+                    "avg_launch_us": 1e3 * conv["ms_per_frame"] / conv["launches_per_frame"]}
+        if args.layers:
+            for k, v in sorted(conv["per_layer"].items(), key=lambda kv: -kv[1]["us_per_call"] * kv[1]["calls_per_frame"]):
+                print("%-40s x%-4.0f %9.1f us/call %7.1f TFLOP/s" % (k, v["calls_per_frame"], v["us_per_call"], v["tflops"]),
+                      file=sys.stderr)
+        out = {
+            "metric": "frames/sec res101 Faster-RCNN 1000x600", "value": world * args.steps / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: res101 image Faster-RCNN forward, 1x(1000x600) synthetic "
+                                   "frame per GPU per step, 6000 pre-NMS / 300 proposals, RoIAlign 7x7, per-class NMS, "
+                                   "thresh %.1f max_dets %d; weights seeded random init (BN tame)" % (THRESH, MAX_DETS),
+                       "frames_per_step": world, "parallelism": "frame-sharded x%d, all-gather of detections" % world,
+                       "launch": "eager" if args.no_graph else "hipGraph replay"},
+            "roofline": roofline,
+            "roofline_roi_align": roi_align_timing(net, 20),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, frames_host[:args.cpu_frames], info)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

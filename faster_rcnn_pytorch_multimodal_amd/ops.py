@@ -11,7 +11,9 @@ import torch
 
 from . import _hip
 
-_DUMMY = {}
+# Optional per-launch timing of the conv kernel (bench.py / tuning): when PROFILE is a list, every
+# conv2d_nhwc call appends (shape dict, start_event, end_event) recorded on the launch stream.
+PROFILE = None
 
 
 def _ptr(t):
@@ -66,9 +68,16 @@ def conv2d_nhwc(x, w_krsc, scale=None, shift=None, residual=None, stride=1, pad=
             raise _hip.HipError("conv2d_nhwc: residual shape %s != output shape %s" % (tuple(residual.shape), (n, ho, wo, k)))
     ws_bytes = lib.frcnn_conv2d_fwd_ws_bytes(n, h, w, c, k, r, s, stride, pad, split_k)
     ws = _workspace(ws_bytes, x.device) if ws_bytes else None
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     _hip.check(lib.frcnn_conv2d_fwd(_ptr(x), _ptr(w_krsc), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out), n, h, w,
                                     c, k, r, s, stride, pad, int(bool(relu)), split_k, _ptr(ws), ws_bytes, _stream()),
                "frcnn_conv2d_fwd")
+    if PROFILE is not None:
+        ev1.record()
+        PROFILE.append(({"n": n, "h": h, "w": w, "c": c, "k": k, "r": r, "s": s, "stride": stride, "pad": pad,
+                         "flops": 2.0 * n * ho * wo * k * r * s * c}, ev0, ev1))
     return out
 
 
