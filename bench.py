@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="frames in flight per GPU: frame i is replayed on HIP stream i %% streams, so the small "
+                         "layers of one frame fill the CUs the other leaves idle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--layers", action="store_true", help="print the per-layer conv table to stderr")
@@ -157,20 +160,27 @@ def main():
     n_resident = 4
     frames_host = [synthetic_frame(rank + world * i) for i in range(n_resident)]
     frames = [torch.from_numpy(f).to(device) for f in frames_host]
-    runner = FrameRunner(net, H, W, C, info, THRESH, MAX_DETS, use_graph=not args.no_graph)
-    rec = torch.zeros((NUM_CLASSES, MAX_DETS, 5), device=device)
-    cnt = torch.zeros((NUM_CLASSES,), dtype=torch.int32, device=device)
-    gathered = torch.zeros((world, NUM_CLASSES * MAX_DETS * 5 + NUM_CLASSES), device=device) if world > 1 else None
+    n_streams = max(1, args.streams)
+    runners = [FrameRunner(net, H, W, C, info, THRESH, MAX_DETS, use_graph=not args.no_graph) for _ in range(n_streams)]
+    streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+    rec = [torch.zeros((NUM_CLASSES, MAX_DETS, 5), device=device) for _ in range(n_streams)]
+    cnt = [torch.zeros((NUM_CLASSES,), dtype=torch.int32, device=device) for _ in range(n_streams)]
+    gathered = [torch.zeros((world, NUM_CLASSES * MAX_DETS * 5 + NUM_CLASSES), device=device)
+                for _ in range(n_streams)] if world > 1 else None
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
 
     def step(i):
-        dets, counts = runner.run(frames[i % n_resident])
-        if world > 1:
-            # eval collate: one fixed-size record per rank (detections + counts), all-gathered over xGMI
-            record = torch.cat((dets.reshape(-1), counts.to(torch.float32)))
-            dist.all_gather_into_tensor(gathered, record)
-        else:
-            rec.copy_(dets, non_blocking=True)
-            cnt.copy_(counts, non_blocking=True)
+        k = i % n_streams
+        with torch.cuda.stream(streams[k]):
+            dets, counts = runners[k].run(frames[i % n_resident])
+            if world > 1:
+                # eval collate: one fixed-size record per rank (detections + counts), all-gathered over xGMI
+                record = torch.cat((dets.reshape(-1), counts.to(torch.float32)))
+                dist.all_gather_into_tensor(gathered[k], record)
+            else:
+                rec[k].copy_(dets, non_blocking=True)
+                cnt[k].copy_(counts, non_blocking=True)
 
     def fence():
         if world > 1:
@@ -183,10 +193,12 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    for st in streams:
+        torch.cuda.current_stream().wait_stream(st)
     if world > 1:
-        host = gathered.cpu()   # rank-local copy of the collated records (device->host, inside the timed region)
+        host = [g.cpu() for g in gathered]   # rank-local copy of the collated records (device->host, timed)
     else:
-        host = (rec.cpu(), cnt.cpu())
+        host = ([r.cpu() for r in rec], [c.cpu() for c in cnt])
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -216,7 +228,7 @@ def main():
                                    "frame per GPU per step, 6000 pre-NMS / 300 proposals, RoIAlign 7x7, per-class NMS, "
                                    "thresh %.1f max_dets %d; weights seeded random init (BN tame)" % (THRESH, MAX_DETS),
                        "frames_per_step": world, "parallelism": "frame-sharded x%d, all-gather of detections" % world,
-                       "launch": "eager" if args.no_graph else "hipGraph replay"},
+                       "launch": "eager" if args.no_graph else "hipGraph replay", "frames_in_flight": n_streams},
             "roofline": roofline,
             "roofline_roi_align": roi_align_timing(net, 20),
         }

@@ -8,11 +8,21 @@
 // Activations are NHWC and filters KRSC, so both operands are contiguous along Kdim: the global->LDS
 // staging moves 16-byte chunks along Kdim and the MFMA fragments are ds_read_b128 along Kdim.
 //
-// Workgroup = 256 threads = 4 waves in a 2x2 grid; each wave owns TM x TN tiles of 32x32 outputs
-// (block tile BM = 64*TM, BN = 64*TN), BK = 32.  LDS rows are padded to 36 floats: the 16-lane groups
-// of ds_read_b128 then hit 16 distinct 16-byte slots (36*m mod 64 = 4*(9m mod 16) is a bijection).
-// Double-buffered LDS with register staging: the global loads of K-step s+1 are issued before the
-// MFMAs of step s and written to the other buffer after them; one barrier per K-step.
+// Workgroup = WM x WN waves, each wave owns TM x TN tiles of 32x32 outputs (block tile BM = 32*TM*WM
+// pixels, BN = 32*TN*WN channels), BK = 32.  The large-GEMM configuration is 8 waves (two per SIMD)
+// on a 256x128 tile, ONE workgroup per CU: both waves of a SIMD belong to the same workgroup, so they
+// reach the per-K-step barrier together and the SIMDs carry identical work (two co-resident 4-wave
+// workgroups couple through their barriers instead and leave ~20 % of the MFMA slots empty).
+// LDS rows are padded to 36 floats: the 16-lane groups of ds_read_b128 then hit 16 distinct 16-byte
+// slots (36*m mod 64 = 4*(9m mod 16) is a bijection).
+//
+// Software pipeline of one K-step (4 groups of k=8, each TM*TN*4 MFMAs per wave):
+//   group 0,1 : MFMAs on fragments prefetched one group ahead
+//   then      : the register-staged global tile of step s+1 is written to the other LDS buffer
+//   group 2   : MFMAs; the global loads of step s+2 are issued (they land ~3/4 step later)
+//   barrier   : placed BEFORE the last group, whose fragments are already in registers
+//   group 3   : MFMAs, overlapped with the first fragment reads of the next buffer
+// so neither the LDS write/barrier/read turn-around nor the HBM/L2 latency is exposed.
 //
 // The MFMA computes an exact k-ordered fp32 fma chain, so results are deterministic and independent
 // of the tile configuration for split_k == 1.
@@ -52,17 +62,20 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   return base + (b >> 3);
 }
 
-template <int TM, int TN, bool ALIGNED>
-__global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
-  constexpr int BM = 64 * TM, BN = 64 * TN;
-  constexpr int PA = BM / 32, PB = BN / 32;  // 16-byte chunks per thread per K-step
+template <int WM, int WN, int TM, int TN, bool ALIGNED>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvParams p) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr int RPP = NT / 8;                // tile rows staged per pass (8 threads x 16 B cover one row)
+  constexpr int PA = BM / RPP, PB = BN / RPP;  // 16-byte chunks per thread per K-step
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                        // [2][BM][36]
   float* Bs = smem + 2 * BM * LDS_PITCH;   // [2][BN][36]
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
 
   const int ntiles = p.tiles_m * p.tiles_n;
   const int tile = xcd_remap(blockIdx.x, ntiles);
@@ -72,12 +85,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
   const int step_begin = blockIdx.z * p.steps_per_split;
   const int step_end = min(step_begin + p.steps_per_split, p.ksteps);
 
-  // ---- per-thread staging geometry: thread t moves chunk kc of rows (t>>3) + 32*i --------------
+  // ---- per-thread staging geometry: thread t moves chunk kc of rows (t>>3) + RPP*i ---------------
   const int kc = t & 7, row0 = t >> 3;
   int a_base[PA], a_hi0[PA], a_wi0[PA];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
-    const int m = m0 + i * 32 + row0;
+    const int m = m0 + i * RPP + row0;
     if (m < p.M) {
       const int img = m / (p.Ho * p.Wo);
       const int rem = m - img * p.Ho * p.Wo;
@@ -103,6 +116,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
     ts = tap - tr * p.S;
   }
 
+  // load_tiles is called for consecutive steps (the ALIGNED tap state advances by one step per call)
   auto load_tiles = [&](int step) {
     const int kflat = step * BK + kc * 4;
     if (ALIGNED) {
@@ -133,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
     }
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
-      const int n = n0 + j * 32 + row0;
+      const int n = n0 + j * RPP + row0;
       const bool ok = n < p.K && kflat < p.Ktot;
       rb[j] = ok ? *reinterpret_cast<const f32x4*>(p.w + (size_t)n * p.Ktot + kflat) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -142,9 +156,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
     float* a = As + buf * BM * LDS_PITCH + row0 * LDS_PITCH + kc * 4;
     float* b = Bs + buf * BN * LDS_PITCH + row0 * LDS_PITCH + kc * 4;
 #pragma unroll
-    for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4*>(a + i * 32 * LDS_PITCH) = ra[i];
+    for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4*>(a + i * RPP * LDS_PITCH) = ra[i];
 #pragma unroll
-    for (int j = 0; j < PB; ++j) *reinterpret_cast<f32x4*>(b + j * 32 * LDS_PITCH) = rb[j];
+    for (int j = 0; j < PB; ++j) *reinterpret_cast<f32x4*>(b + j * RPP * LDS_PITCH) = rb[j];
   };
 
   f32x16 acc[TM][TN];
@@ -160,74 +174,119 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
   const int a_frag = (wr * TM * 32) * LDS_PITCH + frag;
   const int b_frag = (wc * TN * 32) * LDS_PITCH + frag;
 
+  f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];  // two fragment sets: MFMAs on one, LDS reads into the other
+  auto read_frags = [&](f32x4* fa, f32x4* fb, int buf, int kk) {
+    const float* Ab = As + buf * BM * LDS_PITCH + a_frag + kk * 8;
+    const float* Bb = Bs + buf * BN * LDS_PITCH + b_frag + kk * 8;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_PITCH);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_PITCH);
+  };
+  // operands are (weights, activations): D col (lane) = pixel, D row (register) = channel
+  auto mma = [&](const f32x4* fa, const f32x4* fb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][q], fa[i][q], acc[i][j], 0, 0, 0);
+  };
+
   if (step_begin < step_end) {
     load_tiles(step_begin);
     store_tiles(0);
+    if (step_begin + 1 < step_end) load_tiles(step_begin + 1);  // stays in registers until group 1 of step 0
   }
   __syncthreads();
+  if (step_begin < step_end) read_frags(fa0, fb0, 0, 0);
 
   int cur = 0;
   for (int step = step_begin; step < step_end; ++step) {
     const bool more = step + 1 < step_end;
-    if (more) load_tiles(step + 1);
-
-    const float* Ab = As + cur * BM * LDS_PITCH + a_frag;
-    const float* Bb = Bs + cur * BN * LDS_PITCH + b_frag;
-#pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      f32x4 a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_PITCH + kk * 8);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_PITCH + kk * 8);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
-    }
-    if (more) store_tiles(cur ^ 1);
-    __syncthreads();
+    read_frags(fa1, fb1, cur, 1);
+    mma(fa0, fb0);
+    read_frags(fa0, fb0, cur, 2);
+    mma(fa1, fb1);
+#if !defined(FRCNN_ABLATE) || !(FRCNN_ABLATE & 2)
+    if (more) store_tiles(cur ^ 1);  // tile step+1: its loads were issued >= 3/4 step ago
+#endif
+    read_frags(fa1, fb1, cur, 3);
+    mma(fa0, fb0);
+#if !defined(FRCNN_ABLATE) || !(FRCNN_ABLATE & 1)
+    if (step + 2 < step_end) load_tiles(step + 2);
+#endif
+    __syncthreads();  // buffer cur^1 complete; every wave has its last fragments of buffer cur in registers
+    if (more) read_frags(fa0, fb0, cur ^ 1, 0);
+    mma(fa1, fb1);
     cur ^= 1;
   }
 
-  // ---- epilogue: D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ------------
-  const int col = lane & 31, rhalf = 4 * (lane >> 5);
-  if (p.partial != nullptr) {
-    float* slab = p.partial + (size_t)blockIdx.z * p.M * p.K;
+  // ---- epilogue -------------------------------------------------------------------------------
+  // The MFMA operands are (weights, activations), so D has the PIXEL on the lane (col = lane&31) and
+  // the CHANNEL in the registers: row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Registers 4g..4g+3 are four
+  // consecutive channels -> every access of the epilogue is a 16-byte vector per lane, and all
+  // residual loads of a 32x32 tile are issued before its first store (res may alias nothing we
+  // write, but the compiler cannot know: batching keeps 4 loads in flight instead of a
+  // load->wait->store chain per element).
+  const int mlane = lane & 31, nhalf = 4 * (lane >> 5);
+  const bool vec = (p.K & 3) == 0;
+  float* const slab = p.partial ? p.partial + (size_t)blockIdx.z * p.M * p.K : nullptr;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + (wr * TM + i) * 32 + mlane;
+    if (m >= p.M) continue;
+#if defined(FRCNN_ABLATE) && (FRCNN_ABLATE & 4)
+    if (acc[i][0][0] != 123.456f) continue;
+#endif
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wc * TN + j) * 32 + col;
-        if (n >= p.K) continue;
+    for (int j = 0; j < TN; ++j) {
+      const int nb = n0 + (wc * TN + j) * 32 + nhalf;
+      const size_t row = (size_t)m * p.K;
+      if (vec) {
+        if (slab) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int n = nb + 8 * g;
+            if (n < p.K)
+              *reinterpret_cast<f32x4*>(slab + row + n) =
+                  f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          }
+          continue;
+        }
+        f32x4 rv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = nb + 8 * g;
+          rv[g] = (p.res && n < p.K) ? *reinterpret_cast<const f32x4*>(p.res + row + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = nb + 8 * g;
+          if (n >= p.K) continue;
+          const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+          const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = acc[i][j][4 * g + e] * sc[e] + sh[e];
+            t += rv[g][e];
+            v[e] = p.relu ? fmaxf(t, 0.f) : t;
+          }
+          *reinterpret_cast<f32x4*>(p.y + row + n) = v;
+        }
+      } else {
+        // K % 4 != 0: rows are not 16-byte aligned, element-wise accesses
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
-          if (m < p.M) slab[(size_t)m * p.K + n] = acc[i][j][r];
+          const int n = nb + (r & 3) + 8 * (r >> 2);
+          if (n >= p.K) continue;
+          if (slab) { slab[row + n] = acc[i][j][r]; continue; }
+          float t = acc[i][j][r] * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
+          if (p.res) t += p.res[row + n];
+          p.y[row + n] = p.relu ? fmaxf(t, 0.f) : t;
         }
-      }
-    return;
-  }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wc * TN + j) * 32 + col;
-    if (n >= p.K) continue;
-    const float sc = p.scale ? p.scale[n] : 1.f;
-    const float sh = p.shift ? p.shift[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
-        if (m >= p.M) continue;
-        const size_t o = (size_t)m * p.K + n;
-        float v = acc[i][j][r] * sc + sh;
-        if (p.res) v += p.res[o];
-        if (p.relu) v = fmaxf(v, 0.f);
-        p.y[o] = v;
       }
     }
   }
@@ -249,24 +308,42 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue(const float* __restr
   }
 }
 
+// Workgroup configurations: block tile (64*tm) x (64*tn) = (32*TM*WM) x (32*TN*WN).
+struct TileCfg {
+  int tm, tn;          // block tile in units of 64 pixels x 64 channels (the frcnn_conv2d_set_tile key)
+  int wm, wn, wtm, wtn;  // wave grid and 32x32 tiles per wave
+};
+constexpr TileCfg kTiles[] = {
+    {4, 2, 4, 2, 2, 2},  // 256x128, 8 waves, one workgroup per CU
+    {2, 4, 2, 4, 2, 2},  // 128x256, 8 waves
+    {2, 2, 2, 2, 2, 2},  // 128x128, 4 waves, two workgroups per CU
+    {2, 1, 2, 2, 2, 1},  // 128x64
+    {1, 2, 2, 2, 1, 2},  // 64x128
+    {1, 1, 2, 2, 1, 1},  // 64x64
+};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
 struct Plan {
-  int tm, tn, splits, steps_per_split;
+  int cfg, splits, steps_per_split;
 };
 
 // test / tuning hook: force the block tile (0 = automatic choice)
 int g_force_tm = 0, g_force_tn = 0;
 
 // Pick the block tile and the K split that minimise the estimated time on 256 CUs.  Units: MFMA
-// issue cycles of one SIMD (64 per v_mfma_f32_32x32x2_f32).
+// issue cycles of one SIMD (64 per v_mfma_f32_32x32x2_f32); a CU runs one workgroup's K-step in
+// waves_per_simd * TM*TN*16 MFMAs (co-resident 4-wave workgroups share the SIMDs, which the model
+// counts as running one after the other).
 Plan choose_plan(int M, int K, int ksteps, int forced_splits) {
-  static const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
   static const int split_cand[] = {1, 2, 3, 4, 6, 8, 12, 16};
-  Plan best{2, 2, 1, ksteps};
+  Plan best{2, 1, ksteps};
   double best_t = 1e300;
-  for (auto& c : cand) {
-    if (g_force_tm > 0 && (c[0] != g_force_tm || c[1] != g_force_tn)) continue;
-    const int bm = 64 * c[0], bn = 64 * c[1];
+  for (int ci = 0; ci < kNumTiles; ++ci) {
+    const TileCfg& c = kTiles[ci];
+    if (g_force_tm > 0 && (c.tm != g_force_tm || c.tn != g_force_tn)) continue;
+    const int bm = 64 * c.tm, bn = 64 * c.tn;
     const long tiles = (long)((M + bm - 1) / bm) * ((K + bn - 1) / bn);
+    const int waves_per_simd = c.wm * c.wn / 4;
     for (int sp : split_cand) {
       if (forced_splits > 0 && sp != forced_splits) continue;
       if (forced_splits <= 0 && sp > 1 && ksteps / sp < 4) continue;
@@ -275,38 +352,41 @@ Plan choose_plan(int M, int K, int ksteps, int forced_splits) {
       if (real_splits != sp && forced_splits <= 0) continue;
       const long blocks = tiles * real_splits;
       const long rounds = (blocks + NUM_CU - 1) / NUM_CU;
-      const double step_cyc = c[0] * c[1] * 16 * 64 + 400.0;
-      double tcyc = rounds * (sps * step_cyc + 4000.0);
+      const double step_cyc = waves_per_simd * c.wtm * c.wtn * 16 * 64 + 300.0;
+      double tcyc = rounds * (sps * step_cyc + 5000.0);
       if (real_splits > 1) {
         // slab write + read-back at ~3 TB/s (2.4 GHz -> 1250 B/cycle) + one more launch
         tcyc += (double)M * K * 4.0 * (real_splits + 1) / 1250.0 + 4000.0;
       }
       if (tcyc < best_t) {
         best_t = tcyc;
-        best = Plan{c[0], c[1], real_splits, sps};
+        best = Plan{ci, real_splits, sps};
       }
     }
   }
   if (forced_splits > 0 && best_t == 1e300) {
     const int sps = (ksteps + forced_splits - 1) / forced_splits;
-    best = Plan{1, 1, (ksteps + sps - 1) / sps, sps};
+    int ci = kNumTiles - 1;
+    for (int i = 0; i < kNumTiles; ++i)
+      if (g_force_tm > 0 && kTiles[i].tm == g_force_tm && kTiles[i].tn == g_force_tn) ci = i;
+    best = Plan{ci, (ksteps + sps - 1) / sps, sps};
   }
   return best;
 }
 
-template <int TM, int TN, bool ALIGNED>
+template <int WM, int WN, int TM, int TN, bool ALIGNED>
 int launch_conv(const ConvParams& p, int splits, hipStream_t stream) {
-  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_PITCH * sizeof(float);
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<TM, TN, ALIGNED>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, TM, TN, ALIGNED>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return frcnn::fail(FRCNN_ERR_LAUNCH, "conv: set LDS size: %s", hipGetErrorString(e));
     configured = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
-  hipLaunchKernelGGL((conv_igemm_f32<TM, TN, ALIGNED>), grid, dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, ALIGNED>), grid, dim3(64 * WM * WN), lds, stream, p);
   return frcnn::check_launch("conv_igemm_f32");
 }
 
@@ -318,8 +398,10 @@ bool conv_args_ok(int n, int h, int w, int c, int k, int r, int s, int stride, i
 }  // namespace
 
 extern "C" int frcnn_conv2d_set_tile(int tm, int tn) {
-  FRCNN_REQUIRE((tm == 0 && tn == 0) || ((tm == 1 || tm == 2) && (tn == 1 || tn == 2)),
-                "conv2d_set_tile: tiles are 64*tm x 64*tn with tm,tn in {1,2} (0,0 = automatic)");
+  bool known = (tm == 0 && tn == 0);
+  for (int i = 0; i < kNumTiles; ++i) known = known || (kTiles[i].tm == tm && kTiles[i].tn == tn);
+  FRCNN_REQUIRE(known, "conv2d_set_tile: tiles are 64*tm x 64*tn with (tm,tn) in "
+                       "{(4,2),(2,4),(2,2),(2,1),(1,2),(1,1)} ((0,0) = automatic)");
   g_force_tm = tm;
   g_force_tn = tn;
   return FRCNN_OK;
@@ -356,8 +438,9 @@ extern "C" int frcnn_conv2d_fwd(const float* x, const float* wgt, const float* s
   p.ksteps = (p.Ktot + BK - 1) / BK;
   p.relu = relu;
   const Plan pl = choose_plan(p.M, k, p.ksteps, split_k);
+  const TileCfg& tc = kTiles[pl.cfg];
   p.steps_per_split = pl.steps_per_split;
-  const int bm = 64 * pl.tm, bn = 64 * pl.tn;
+  const int bm = 64 * tc.tm, bn = 64 * tc.tn;
   p.tiles_m = (p.M + bm - 1) / bm;
   p.tiles_n = (k + bn - 1) / bn;
   if (pl.splits > 1) {
@@ -368,12 +451,17 @@ extern "C" int frcnn_conv2d_fwd(const float* x, const float* wgt, const float* s
   }
   const bool aligned = (c % BK) == 0;
   int rc;
-#define FRCNN_CONV_CASE(TM_, TN_)                                                          \
-  rc = aligned ? launch_conv<TM_, TN_, true>(p, pl.splits, stream) : launch_conv<TM_, TN_, false>(p, pl.splits, stream)
-  if (pl.tm == 2 && pl.tn == 2) FRCNN_CONV_CASE(2, 2);
-  else if (pl.tm == 2 && pl.tn == 1) FRCNN_CONV_CASE(2, 1);
-  else if (pl.tm == 1 && pl.tn == 2) FRCNN_CONV_CASE(1, 2);
-  else FRCNN_CONV_CASE(1, 1);
+#define FRCNN_CONV_CASE(WM_, WN_, TM_, TN_)                                   \
+  rc = aligned ? launch_conv<WM_, WN_, TM_, TN_, true>(p, pl.splits, stream) \
+               : launch_conv<WM_, WN_, TM_, TN_, false>(p, pl.splits, stream)
+  switch (pl.cfg) {
+    case 0: FRCNN_CONV_CASE(4, 2, 2, 2); break;
+    case 1: FRCNN_CONV_CASE(2, 4, 2, 2); break;
+    case 2: FRCNN_CONV_CASE(2, 2, 2, 2); break;
+    case 3: FRCNN_CONV_CASE(2, 2, 2, 1); break;
+    case 4: FRCNN_CONV_CASE(2, 2, 1, 2); break;
+    default: FRCNN_CONV_CASE(2, 2, 1, 1); break;
+  }
 #undef FRCNN_CONV_CASE
   if (rc != FRCNN_OK) return rc;
   if (pl.splits > 1) {

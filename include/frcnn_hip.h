@@ -49,7 +49,8 @@ int frcnn_conv2d_fwd(const float* x, const float* wgt, const float* scale, const
                      int stride, int pad, int relu, int split_k, void* ws, size_t ws_bytes, void* stream);
 
 /* Tuning / test hook: force the workgroup tile to (64*tm) x (64*tn) output pixels x channels for all
- * following frcnn_conv2d_fwd calls of this process; (0,0) restores the automatic choice. */
+ * following frcnn_conv2d_fwd calls of this process; (tm,tn) in {(4,2),(2,4)} (8 waves, one workgroup per
+ * CU), {(2,2),(2,1),(1,2),(1,1)} (4 waves); (0,0) restores the automatic choice. */
 int frcnn_conv2d_set_tile(int tm, int tn);
 
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1)  (lib/nets/resnet.py:156), NHWC. */

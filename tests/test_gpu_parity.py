@@ -69,7 +69,7 @@ def _conv_ref(x_nhwc, w_kcrs, scale, shift, res_nhwc, stride, pad, relu):
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [(0, 0), (2, 2), (2, 1), (1, 2), (1, 1)])
+@pytest.mark.parametrize("tile", [(0, 0), (4, 2), (2, 4), (2, 2), (2, 1), (1, 2), (1, 1)])
 def test_conv2d_fwd(hip, case, tile):
     ops = _ops()
     n, h, w, c, k, r, stride, pad, relu, use_res, use_bn = case
@@ -102,12 +102,12 @@ def test_conv2d_is_deterministic_and_tile_independent(hip):
     x = torch.randn(1, 38, 63, 256, generator=g).to(DEV)
     w = (torch.randn(256, 3, 3, 256, generator=g) / 48).to(DEV)
     outs = []
-    for tile in ((2, 2), (1, 1), (2, 1)):
+    for tile in ((2, 2), (1, 1), (2, 1), (4, 2), (2, 4)):
         hip.frcnn_conv2d_set_tile(*tile)
         outs.append(ops.conv2d_nhwc(x, w, stride=1, pad=1, split_k=1).cpu())
     hip.frcnn_conv2d_set_tile(0, 0)
     # split_k = 1: the MFMA is an exact k-ordered fma chain, so every tile shape gives the same bits
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
 def test_conv2d_rejects_bad_arguments(hip):

@@ -1,0 +1,88 @@
+#!/usr/bin/env python
+"""Micro-benchmark of frcnn_conv2d_fwd on the convolution shapes of one res101 1000x600 frame
+(tuning aid; bench.py remains the judged measurement).
+
+    python tools/conv_bench.py [--reps 20] [--tile TM,TN] [--split S] [--only substr]
+
+Each shape is launched `reps` times back to back between two HIP events on the launch stream.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+# (name, n, h, w, c, k, r, stride, pad, residual, calls per frame)
+SHAPES = [
+    ("stem 7x7/2", 1, 600, 1000, 4, 64, 7, 2, 3, False, 1),
+    ("l1 1x1 64-64", 1, 150, 250, 64, 64, 1, 1, 0, False, 1),
+    ("l1 3x3 64", 1, 150, 250, 64, 64, 3, 1, 1, False, 3),
+    ("l1 1x1 64-256 +res", 1, 150, 250, 64, 256, 1, 1, 0, True, 4),
+    ("l1 1x1 256-64", 1, 150, 250, 256, 64, 1, 1, 0, False, 2),
+    ("l2 1x1/2 256-128", 1, 150, 250, 256, 128, 1, 2, 0, False, 1),
+    ("l2 ds 1x1/2 256-512", 1, 150, 250, 256, 512, 1, 2, 0, False, 1),
+    ("l2 3x3 128", 1, 75, 125, 128, 128, 3, 1, 1, False, 4),
+    ("l2 1x1 128-512 +res", 1, 75, 125, 128, 512, 1, 1, 0, True, 4),
+    ("l2 1x1 512-128", 1, 75, 125, 512, 128, 1, 1, 0, False, 3),
+    ("l3 1x1/2 512-256", 1, 75, 125, 512, 256, 1, 2, 0, False, 1),
+    ("l3 ds 1x1/2 512-1024", 1, 75, 125, 512, 1024, 1, 2, 0, False, 1),
+    ("l3 3x3 256", 1, 38, 63, 256, 256, 3, 1, 1, False, 23),
+    ("l3 1x1 256-1024 +res", 1, 38, 63, 256, 1024, 1, 1, 0, True, 23),
+    ("l3 1x1 1024-256", 1, 38, 63, 1024, 256, 1, 1, 0, False, 22),
+    ("rpn 3x3 1024-512", 1, 38, 63, 1024, 512, 3, 1, 1, False, 1),
+    ("rpn 1x1 512-152", 1, 38, 63, 512, 152, 1, 1, 0, False, 1),
+    ("l4 1x1 1024-512", 300, 7, 7, 1024, 512, 1, 1, 0, False, 1),
+    ("l4 ds 1x1 1024-2048", 300, 7, 7, 1024, 2048, 1, 1, 0, False, 1),
+    ("l4 3x3 512", 300, 7, 7, 512, 512, 3, 1, 1, False, 3),
+    ("l4 1x1 512-2048 +res", 300, 7, 7, 512, 2048, 1, 1, 0, True, 3),
+    ("l4 1x1 2048-512", 300, 7, 7, 2048, 512, 1, 1, 0, False, 2),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--tile", default="0,0")
+    ap.add_argument("--split", type=int, default=0)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    from faster_rcnn_pytorch_multimodal_amd import _hip, ops
+    lib = _hip.load()
+    tm, tn = (int(v) for v in args.tile.split(","))
+    _hip.check(lib.frcnn_conv2d_set_tile(tm, tn), "set_tile")
+    dev = "cuda:0"
+    g = torch.Generator(device="cpu").manual_seed(0)
+    tot_us = tot_fl = 0.0
+    print("%-24s %6s %9s %9s %8s" % ("shape", "calls", "us/call", "TFLOP/s", "us/frame"))
+    for name, n, h, w, c, k, r, stride, pad, res, calls in SHAPES:
+        if args.only and args.only not in name:
+            continue
+        x = torch.randn((n, h, w, c), generator=g).to(dev)
+        wt = (torch.randn((k, r, r, c), generator=g) * 0.05).to(dev)
+        sc = torch.rand((k,), generator=g).to(dev) + 0.5
+        sh = torch.randn((k,), generator=g).to(dev)
+        ho, wo = ops.conv_out_hw(h, w, r, r, stride, pad)
+        rs = torch.randn((n, ho, wo, k), generator=g).to(dev) if res else None
+        y = torch.empty((n, ho, wo, k), device=dev)
+        for _ in range(2):
+            ops.conv2d_nhwc(x, wt, sc, sh, rs, stride=stride, pad=pad, relu=True, split_k=args.split, out=y)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(args.reps):
+            ops.conv2d_nhwc(x, wt, sc, sh, rs, stride=stride, pad=pad, relu=True, split_k=args.split, out=y)
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / args.reps
+        fl = 2.0 * n * ho * wo * k * r * r * c
+        tot_us += us * calls
+        tot_fl += fl * calls
+        print("%-24s %6d %9.1f %9.1f %8.1f" % (name, calls, us, fl / us / 1e6, us * calls))
+    print("%-24s %6s %9s %9.1f %8.1f" % ("TOTAL", "", "", tot_fl / tot_us / 1e6, tot_us))
+
+
+if __name__ == "__main__":
+    main()
