@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=4,
                     help="frames in flight per GPU: frame i is replayed on HIP stream i %% streams, so the small "
                          "layers of one frame fill the CUs the other leaves idle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -165,8 +165,10 @@ def main():
     streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
     rec = [torch.zeros((NUM_CLASSES, MAX_DETS, 5), device=device) for _ in range(n_streams)]
     cnt = [torch.zeros((NUM_CLASSES,), dtype=torch.int32, device=device) for _ in range(n_streams)]
-    gathered = [torch.zeros((world, NUM_CLASSES * MAX_DETS * 5 + NUM_CLASSES), device=device)
+    from faster_rcnn_pytorch_multimodal_amd.model import collate
+    gathered = [torch.zeros((world, collate.record_numel(NUM_CLASSES, MAX_DETS)), device=device)
                 for _ in range(n_streams)] if world > 1 else None
+    records = [torch.zeros(collate.record_numel(NUM_CLASSES, MAX_DETS), device=device) for _ in range(n_streams)]
     for st in streams:
         st.wait_stream(torch.cuda.current_stream())
 
@@ -176,8 +178,7 @@ def main():
             dets, counts = runners[k].run(frames[i % n_resident])
             if world > 1:
                 # eval collate: one fixed-size record per rank (detections + counts), all-gathered over xGMI
-                record = torch.cat((dets.reshape(-1), counts.to(torch.float32)))
-                dist.all_gather_into_tensor(gathered[k], record)
+                collate.gather_records(collate.pack_record(dets, counts, records[k]), gathered[k])
             else:
                 rec[k].copy_(dets, non_blocking=True)
                 cnt[k].copy_(counts, non_blocking=True)

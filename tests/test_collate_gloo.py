@@ -1,0 +1,67 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the eval collate (model/collate.py) that bench.py and the
+8-GPU eval use with RCCL.  Each rank fabricates the per-class detections of its frames; after the
+all-gather every rank must rebuild the same all_boxes, equal to what a single process computes."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from faster_rcnn_pytorch_multimodal_amd.model import collate
+
+K, MAX_OUT, FRAMES = 3, 10, 5
+
+
+def _fake_frame(i):
+    rng = np.random.default_rng(100 + i)
+    dets = np.zeros((K, MAX_OUT, 5), np.float32)
+    counts = np.zeros((K,), np.int32)
+    for j in range(1, K):
+        counts[j] = rng.integers(0, MAX_OUT + 1)
+        dets[j, :counts[j]] = rng.random((counts[j], 5), dtype=np.float32) * 600
+    return dets, counts
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    all_frames = {}
+    mine = collate.shard_frames(FRAMES, rank, world)
+    steps = (FRAMES + world - 1) // world
+    for s in range(steps):
+        if s < len(mine):
+            dets, counts = _fake_frame(mine[s])
+        else:  # ragged tail: this rank has no frame left, contributes an empty record
+            dets, counts = np.zeros((K, MAX_OUT, 5), np.float32), np.zeros((K,), np.int32)
+        rec = collate.pack_record(torch.from_numpy(dets), torch.from_numpy(counts))
+        gathered = collate.gather_records(rec)
+        for r, per_class in enumerate(collate.unpack_records(gathered, K, MAX_OUT)):
+            frame = s * world + r
+            if frame < FRAMES:
+                all_frames[frame] = per_class
+    torch.save(all_frames, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collate_world2_gloo(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(2)]
+    for frame in range(FRAMES):
+        dets, counts = _fake_frame(frame)
+        for j in range(1, K):
+            for r in range(2):   # every rank holds the full collate
+                np.testing.assert_array_equal(got[r][frame][j], dets[j, :counts[j]])
+            assert got[0][frame][0].shape == (0, 5)
+
+
+def test_shard_frames_partition():
+    for world in (1, 2, 3, 8):
+        seen = sorted(i for r in range(world) for i in collate.shard_frames(11, r, world))
+        assert seen == list(range(11))
