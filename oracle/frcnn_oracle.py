@@ -476,3 +476,252 @@ def average_precision(dets, gt_boxes, iou_thresh=0.7):
     rec = tp / float(len(gt_boxes))
     prec = tp / np.maximum(tp + fp, np.finfo(np.float64).eps)
     return voc_ap(rec, prec)
+
+
+# ==============================================================================================
+# LiDAR-BEV variant
+# ==============================================================================================
+LIDAR_X_RANGE, LIDAR_Y_RANGE, LIDAR_Z_RANGE = (0, 70), (-40, 40), (-3, 3)   # config.py:397-399
+LIDAR_VOXEL_LEN, LIDAR_VOXEL_HEIGHT = 0.1, 0.5                              # config.py:400-401
+LIDAR_NUM_CHANNEL = 15                                                      # config.py:402-404
+LIDAR_ANCHORS = np.array([[4.73, 2.08, 1.77]])                              # config.py:421
+LIDAR_ANCHOR_SCALES = (1,)                                                  # config.py:422
+LIDAR_ANCHOR_ANGLES = np.array([0, np.pi / 2])                              # config.py:423
+LIDAR_NUM_BBOX_ELEM = 7                                                     # config.py:425
+LIDAR_REG_LOSS_WEIGHT = (1.0,) * 7                                          # config.py:426
+LIDAR_BBOX_NORMALIZE_MEANS = (0.0,) * 7                                     # config.py:219
+LIDAR_BBOX_NORMALIZE_STDS = (0.1, 0.1, 0.1, 0.2, 0.2, 0.2, 1.0)             # config.py:220
+
+
+def generate_anchors_3d(height, width, feature_stride, anchor_scales=LIDAR_ANCHOR_SCALES,
+                        anchor_rotations=LIDAR_ANCHOR_ANGLES, frame_scale=1.0):
+    """generate_3d_anchors.py:15-118: grid of [x, y, z=h/2, l, w, h, ry] in voxel units, order (H, W, size, rot)
+    with rot fastest; centres arange(0, W*stride-1, stride) (float32)."""
+    assert len(anchor_scales) == 1
+    voxel_len = LIDAR_VOXEL_LEN / frame_scale                                    # :37
+    sizes = LIDAR_ANCHORS / np.array([voxel_len, voxel_len, 1]) * anchor_scales[0]  # :38
+    rots = np.asarray(anchor_rotations)
+    xs = np.arange(0, width * feature_stride - 1, feature_stride).astype(np.float32)
+    ys = np.arange(0, height * feature_stride - 1, feature_stride).astype(np.float32)
+    n = len(ys) * len(xs) * len(sizes) * len(rots)
+    out = np.zeros((len(ys), len(xs), len(sizes), len(rots), 7), dtype=np.float32)
+    out[..., 0] = xs[None, :, None, None]
+    out[..., 1] = ys[:, None, None, None]
+    out[..., 2] = sizes[0][2] / 2.0                                              # :100 (first size only)
+    out[..., 3:6] = sizes[None, None, :, None, :]
+    out[..., 6] = rots[None, None, None, :]
+    return n, out.reshape(n, 7)
+
+
+def bbaa_graphics_gems(bboxes):
+    """utils/bbox.py:256-293 with clip=False: axis-aligned BEV box of [xc,yc,zc,l,w,h,ry].  The rotation
+    matrix keeps the dtype of the boxes (float32), the half extents are float64, the sum of per-axis
+    min/max products is cast to float32 and the float32 centre is added last."""
+    b = np.asarray(bboxes)
+    rot = b[:, 6]
+    c, s = np.cos(rot), np.sin(rot)                          # dtype of b
+    m = np.stack((np.stack((c, s), 1), np.stack((-s, c), 1)), 1)      # (N, 2, 2) = [[cos, sin], [-sin, cos]]
+    amin = np.stack((-(b[:, 3] / 2.0), -(b[:, 4] / 2.0)), 1).astype(np.float64)
+    amax = -amin
+    lo = m * amin[:, None, :]
+    hi = m * amax[:, None, :]
+    bmin = np.minimum(lo, hi).sum(2).astype(np.float32) + b[:, 0:2]
+    bmax = np.maximum(lo, hi).sum(2).astype(np.float32) + b[:, 0:2]
+    return np.concatenate((bmin[:, 0:1], bmin[:, 1:2], bmax[:, 0:1], bmax[:, 1:2]), 1)
+
+
+def lidar_3d_bbox_transform(ex_rois, ex_anchors, gt_rois):
+    """bbox_transform.py:16-49: centre deltas over the RoI diagonal, z/h from the 3-D anchor, ry = raw gt yaw."""
+    ln = ex_rois[:, 2] - ex_rois[:, 0] + 1
+    wd = ex_rois[:, 3] - ex_rois[:, 1] + 1
+    ht = ex_anchors[:, 5]
+    cx, cy, cz = ex_rois[:, 0] + ln / 2.0, ex_rois[:, 1] + wd / 2.0, ex_anchors[:, 2]
+    diag = torch.sqrt(torch.pow(ln, 2) + torch.pow(wd, 2))
+    return torch.stack(((gt_rois[:, 0] - cx) / diag, (gt_rois[:, 1] - cy) / diag, (gt_rois[:, 2] - cz) / ht,
+                        torch.log(gt_rois[:, 3] / ln), torch.log(gt_rois[:, 4] / wd), torch.log(gt_rois[:, 5] / ht),
+                        gt_rois[:, 6]), 1)
+
+
+def lidar_3d_bbox_transform_inv(rois, boxes, deltas, scales=None):
+    """bbox_transform.py:174-233.  rois (N,4) axis-aligned, boxes (N,7) 3-D anchors, deltas (N,7K)."""
+    if scales is not None:
+        rois = rois / scales          # the anchors' x,y,l,w are scaled too (:177-178) but never read afterwards
+    if len(boxes) == 0:
+        return deltas.detach() * 0
+    ln = rois[:, 2] - rois[:, 0] + 1
+    wd = rois[:, 3] - rois[:, 1] + 1
+    ht = boxes[:, 5]
+    cx, cy, cz = rois[:, 0] + ln / 2.0, rois[:, 1] + wd / 2.0, boxes[:, 2]
+    diag = torch.sqrt(torch.pow(ln, 2) + torch.pow(wd, 2))
+    d = [deltas[:, i::7] for i in range(7)]
+    parts = [d[0] * diag.unsqueeze(1) + cx.unsqueeze(1), d[1] * diag.unsqueeze(1) + cy.unsqueeze(1),
+             d[2] * ht.unsqueeze(1) + cz.unsqueeze(1), torch.exp(d[3]) * ln.unsqueeze(1),
+             torch.exp(d[4]) * wd.unsqueeze(1), torch.exp(d[5]) * ht.unsqueeze(1), d[6]]
+    return torch.cat([p.unsqueeze(2) for p in parts], 2).view(len(boxes), -1)
+
+
+def lidar_extents():
+    return [LIDAR_X_RANGE[0], LIDAR_Y_RANGE[0], LIDAR_Z_RANGE[0], LIDAR_X_RANGE[1], LIDAR_Y_RANGE[1], LIDAR_Z_RANGE[1]]
+
+
+def bbox_voxel_grid_to_pc(bboxes, bev_extents, info):
+    """utils/bbox.py:140-162 (aabb=False): voxel-grid [xc,yc,zc,l,w,h,ry] -> metres; numpy in place."""
+    scale = info[6]
+    s_info = np.asarray(info[0:6]) * 1 / scale
+    kx = (bev_extents[3] - bev_extents[0]) / (s_info[1] - s_info[0])
+    ky = (bev_extents[4] - bev_extents[1]) / (s_info[3] - s_info[2])
+    bboxes[:, 0] = bboxes[:, 0] * kx + bev_extents[0]
+    bboxes[:, 1] = bboxes[:, 1] * ky + bev_extents[1]
+    bboxes[:, 3] = bboxes[:, 3] * kx
+    bboxes[:, 4] = bboxes[:, 4] * ky
+    return bboxes
+
+
+def proposal_top_layer(rpn_cls_prob, rpn_bbox_pred, info, anchors, num_anchors, rpn_top_n=5000, rng=None):
+    """proposal_top_layer.py:18-59: top-N by fg score, no NMS; random choice WITH replacement when fewer
+    scores than N (:32-37, numpy RNG)."""
+    scores = rpn_cls_prob[:, :, :, num_anchors:].contiguous().view(-1, 1)
+    deltas = rpn_bbox_pred.reshape(-1, 4)
+    length = scores.size(0)
+    if length < rpn_top_n:
+        rng = rng or np.random
+        top = torch.from_numpy(rng.choice(length, size=rpn_top_n, replace=True)).long()
+    else:
+        top = stable_desc_order(scores)[:rpn_top_n]
+    anchors, deltas, scores = anchors[top, :], deltas[top, :], scores[top]
+    proposals = clip_boxes(bbox_transform_inv(anchors, deltas), info)
+    return torch.cat((proposals.new_zeros(proposals.size(0), 1), proposals), 1), scores, anchors
+
+
+# ==============================================================================================
+# Training targets and losses
+# ==============================================================================================
+TRAIN_RPN_POSITIVE_OVERLAP, TRAIN_RPN_NEGATIVE_OVERLAP = 0.7, 0.3      # config.py:174-177
+TRAIN_RPN_FG_FRACTION, TRAIN_RPN_BATCHSIZE = 0.5, 256                  # config.py:181-184
+TRAIN_ROI_BATCH_SIZE, TRAIN_FG_FRACTION = 256, 0.25                    # config.py:123-126
+TRAIN_FG_THRESH, TRAIN_BG_THRESH_HI, TRAIN_BG_THRESH_LO = 0.6, 0.5, 0.0  # config.py:129-134
+
+
+def anchor_target_layer(gt_boxes, info, all_anchors, num_anchors, height, width, rpn_batchsize=TRAIN_RPN_BATCHSIZE,
+                        fg_fraction=TRAIN_RPN_FG_FRACTION, generator=None):
+    """anchor_target_layer.py:22-165 (torch variant, IGNORE_DC off, CLOBBER off, uniform weights)."""
+    total = all_anchors.shape[0]
+    inside = torch.where((all_anchors[:, 0] >= info[0]) & (all_anchors[:, 1] >= info[2]) &
+                         (all_anchors[:, 2] < info[1]) & (all_anchors[:, 3] < info[3]))[0]
+    anchors = all_anchors[inside, :]
+    labels = torch.full((len(inside),), -1, dtype=torch.int64)
+    ov = bbox_overlaps(anchors.contiguous(), gt_boxes[:, :4].contiguous())
+    argmax = ov.argmax(dim=1)
+    max_ov = ov[torch.arange(len(inside)), argmax]
+    gt_max = ov[ov.argmax(dim=0), torch.arange(ov.shape[1])]
+    gt_max = torch.clamp(gt_max, torch.finfo(torch.float32).eps, float("inf"))
+    gt_argmax = torch.where(ov == gt_max)[0]                     # every anchor tying a gt's best overlap
+    labels[max_ov < TRAIN_RPN_NEGATIVE_OVERLAP] = 0
+    labels[gt_argmax] = 1
+    labels[max_ov >= TRAIN_RPN_POSITIVE_OVERLAP] = 1
+    num_fg = int(fg_fraction * rpn_batchsize)
+    fg = torch.where(labels == 1)[0]
+    if len(fg) > num_fg:
+        labels[fg[torch.randperm(fg.numel(), generator=generator)[num_fg:]]] = -1
+    num_bg = rpn_batchsize - int(torch.sum(labels == 1))
+    bg = torch.where(labels == 0)[0]
+    if len(bg) > num_bg:
+        labels[bg[torch.randperm(bg.numel(), generator=generator)[num_bg:]]] = -1
+    targets = bbox_transform(anchors, gt_boxes[argmax, :4])
+    inside_w = torch.zeros((len(inside), 4))
+    inside_w[labels == 1, :] = 1.0                                # RPN_BBOX_INSIDE_WEIGHTS (1,1,1,1)
+    outside_w = torch.zeros((len(inside), 4))
+    w = 1.0 / float(torch.sum(labels >= 0))
+    outside_w[labels == 1, :] = w
+    outside_w[labels == 0, :] = w
+
+    def unmap(data, fill):
+        shape = (total,) + tuple(data.shape[1:])
+        ret = torch.full(shape, float(fill), dtype=torch.float32)
+        ret[inside] = data.float()
+        return ret
+
+    a = num_anchors
+    return (unmap(labels, -1).reshape(1, height, width, a).permute(0, 3, 1, 2),
+            unmap(targets, 0).reshape(1, height, width, a * 4), unmap(inside_w, 0).reshape(1, height, width, a * 4),
+            unmap(outside_w, 0).reshape(1, height, width, a * 4))
+
+
+def _choice(n, k, replace, generator):
+    """proposal_target_layer.py:265-284."""
+    if replace:
+        return torch.randint(n, (k,), generator=generator)
+    if k > n:
+        idx = torch.arange(n).repeat(math.ceil(k / n))
+        return idx[torch.randperm(idx.shape[0], generator=generator)][:k]
+    return torch.randperm(n, generator=generator)[:k]
+
+
+def proposal_target_layer(rpn_rois, rpn_scores, anchors_3d, gt_boxes, true_gt_boxes, num_classes, num_bbox_elem,
+                          net_type="image", generator=None):
+    """proposal_target_layer.py:22-262 (USE_GT off, IGNORE_DC off, targets normalised by the configured
+    means/stds :144-147,160-163).  Returns labels (R,1), rois (R,5), anchors_3d, roi_scores, targets, inside, outside."""
+    rois_per_frame = TRAIN_ROI_BATCH_SIZE
+    fg_quota = int(round(TRAIN_FG_FRACTION * rois_per_frame))
+    ov = bbox_overlaps(rpn_rois[:, 1:5], gt_boxes[:, :4])
+    max_ov, assign = ov.max(1)
+    labels = gt_boxes[assign, 4]
+    fg = (max_ov >= TRAIN_FG_THRESH).nonzero().view(-1)
+    bg = ((max_ov < TRAIN_BG_THRESH_HI) & (max_ov >= TRAIN_BG_THRESH_LO)).nonzero().view(-1)
+    if fg.numel() > 0 and bg.numel() > 0:
+        n_fg = min(fg_quota, fg.numel())
+        fg = fg[_choice(fg.numel(), int(n_fg), False, generator)]
+        n_bg = rois_per_frame - n_fg
+        bg = bg[_choice(bg.numel(), int(n_bg), bg.numel() < n_bg, generator)]
+    elif fg.numel() > 0:
+        fg = fg[_choice(fg.numel(), int(rois_per_frame), fg.numel() < rois_per_frame, generator)]
+        n_fg = rois_per_frame
+    elif bg.numel() > 0:
+        bg = bg[_choice(bg.numel(), int(rois_per_frame), bg.numel() < rois_per_frame, generator)]
+        n_fg = 0
+    else:
+        raise RuntimeError("no foreground and no background RoI (the reference drops into pdb here)")
+    keep = torch.cat([fg, bg], 0)
+    labels = labels[keep].contiguous()
+    labels[int(n_fg):] = 0
+    rois, scores, a3 = rpn_rois[keep].contiguous(), rpn_scores[keep].contiguous(), anchors_3d[keep].contiguous()
+    if net_type == "lidar":
+        t = lidar_3d_bbox_transform(rois[:, 1:5], a3, true_gt_boxes[assign[keep]][:, :-1])
+        t = (t - t.new_tensor(LIDAR_BBOX_NORMALIZE_MEANS)) / t.new_tensor(LIDAR_BBOX_NORMALIZE_STDS)
+    else:
+        t = bbox_transform(rois[:, 1:5], gt_boxes[assign[keep]][:, :4])
+        t = (t - t.new_tensor(BBOX_NORMALIZE_MEANS)) / t.new_tensor(BBOX_NORMALIZE_STDS)
+    e = num_bbox_elem
+    targets = labels.new_zeros(labels.numel(), e * num_classes)
+    inside = labels.new_zeros(targets.shape)
+    for i in (labels > 0).nonzero().view(-1).tolist():
+        c = int(labels[i])
+        targets[i, e * c:e * c + e] = t[i]
+        inside[i, e * c:e * c + e] = 1.0
+    return labels.view(-1, 1), rois.view(-1, 5), a3, scores.view(-1), targets, inside, (inside > 0).float()
+
+
+def huber_loss(pred, targets, delta=1.0, sin_en=False):
+    """loss_utils.py:28-37."""
+    diff = pred - targets
+    if sin_en:
+        diff = torch.sin(diff)
+    a = torch.abs(diff)
+    small = (a < delta).detach().float()
+    return 0.5 * torch.pow(diff, 2) * small + delta * (a - 0.5 * delta) * (1.0 - small)
+
+
+def smooth_l1_loss(stage, bbox_pred, bbox_targets, inside_w, outside_w, dim=(1,), net_type="image"):
+    """loss_utils.py:39-101 with the aleatoric branch off (cfg.UC.* default False)."""
+    pred = bbox_pred * inside_w
+    tgt = bbox_targets * inside_w
+    if net_type == "lidar" and stage == "DET":
+        p7, t7 = pred.reshape(-1, 7), tgt.reshape(-1, 7)
+        loss = torch.cat((huber_loss(p7[:, 0:6], t7[:, 0:6]), huber_loss(p7[:, 6:7], t7[:, 6:7], sin_en=True)), 1)
+        loss = (loss * loss.new_tensor(LIDAR_REG_LOSS_WEIGHT)).reshape(pred.shape)
+    else:
+        loss = huber_loss(pred, tgt)
+    loss = outside_w * loss
+    for i in sorted(dim, reverse=True):
+        loss = loss.sum(i)
+    return loss.mean()

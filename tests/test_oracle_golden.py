@@ -149,3 +149,78 @@ def test_proposal_layer_shapes_and_order():
     assert (rois[:, 0] == 0).all()
     assert (scores[:-1, 0] >= scores[1:, 0]).all()
     assert rois[:, 1].min() >= 0 and rois[:, 3].max() <= 143 and rois[:, 4].max() <= 95
+
+
+# ------------------------------------------------------------------------------------------------
+# LiDAR variant + training-target layers against vectors produced by the reference
+# (tests/golden/make_golden_lidar_train.py)
+# ------------------------------------------------------------------------------------------------
+def _lt(golden_dir):
+    return np.load(os.path.join(golden_dir, "lidar_train.npz"))
+
+
+def test_3d_anchors_and_bev_boxes_match_reference(golden_dir):
+    z = _lt(golden_dir)
+    for tag, (h, w, fs) in {"25x22_fs0.5": (25, 22, 0.5), "50x44_fs1": (50, 44, 1.0), "7x5_fs0.3": (7, 5, 0.3)}.items():
+        n, a3 = O.generate_anchors_3d(h, w, 16, frame_scale=fs)
+        assert n == z["a3d_" + tag].shape[0]
+        np.testing.assert_array_equal(a3, z["a3d_" + tag])
+        np.testing.assert_array_equal(O.bbaa_graphics_gems(a3), z["a2d_" + tag])
+
+
+def test_lidar_codec_matches_reference(golden_dir):
+    z = _lt(golden_dir)
+    rois, anc, d, gt = (torch.from_numpy(z[k]) for k in ("l_rois", "l_anchors", "l_deltas", "l_gt"))
+    np.testing.assert_array_equal(O.lidar_3d_bbox_transform_inv(rois, anc, d).numpy(), z["l_inv"])
+    np.testing.assert_array_equal(O.lidar_3d_bbox_transform_inv(rois, anc, d, 0.5).numpy(), z["l_inv_scale0.5"])
+    np.testing.assert_array_equal(O.lidar_3d_bbox_transform(rois, anc, gt).numpy(), z["l_fwd"])
+    np.testing.assert_array_equal(np.asarray(O.lidar_extents(), np.float32), z["l_extents"])
+    got = O.bbox_voxel_grid_to_pc(z["l_inv"][:, 7:14].copy(), O.lidar_extents(), z["l_info"])
+    np.testing.assert_array_equal(got, z["l_vg_to_pc"])
+
+
+def test_proposal_top_layer_matches_reference(golden_dir):
+    z = _lt(golden_dir)
+    blob, sc, anc = O.proposal_top_layer(torch.from_numpy(z["top_prob"]), torch.from_numpy(z["top_deltas"]),
+                                         z["top_info"], torch.from_numpy(z["top_anchors"]), 25, rpn_top_n=120)
+    np.testing.assert_array_equal(blob.numpy(), z["top_blob"])
+    np.testing.assert_array_equal(sc.numpy(), z["top_scores"])
+    np.testing.assert_array_equal(anc.numpy(), z["top_sel_anchors"])
+
+
+def test_anchor_target_layer_matches_reference(golden_dir):
+    z = _lt(golden_dir)
+    h, w = (int(v) for v in z["atl_hw"])
+    lab, tgt, inw, outw = O.anchor_target_layer(torch.from_numpy(z["atl_gt"]), z["atl_info"],
+                                                torch.from_numpy(z["atl_anchors"]), 25, h, w, rpn_batchsize=10 ** 7)
+    np.testing.assert_array_equal(lab.numpy(), z["atl_labels"])
+    np.testing.assert_array_equal(tgt.numpy(), z["atl_targets"])
+    np.testing.assert_array_equal(inw.numpy(), z["atl_inside"])
+    np.testing.assert_array_equal(outw.numpy(), z["atl_outside"])
+    assert (z["atl_labels"] == 1).sum() >= 6 and (z["atl_labels"] == 0).sum() > 100   # the case is not degenerate
+
+
+def test_proposal_target_layer_matches_reference(golden_dir):
+    z = _lt(golden_dir)
+    rois, sc, gt = (torch.from_numpy(z[k]) for k in ("ptl_rois", "ptl_scores", "ptl_gt"))
+    lab, r, _, s, bt, biw, bow = O.proposal_target_layer(rois, sc, torch.zeros(rois.shape[0], 7), gt,
+                                                         torch.zeros(4, 8), 2, 4,
+                                                         generator=torch.Generator().manual_seed(1))
+    packed = torch.cat((r, lab, s.view(-1, 1), bt, biw, bow), 1).numpy()
+    packed = packed[np.lexsort(packed.T[::-1])]
+    # every candidate is taken (40 fg == quota share, 216 bg == the rest), so only the row order is random
+    np.testing.assert_array_equal(packed, z["ptl_packed_sorted"])
+    assert int((lab > 0).sum()) == int(z["ptl_num_fg"][0]) == 40
+
+
+def test_losses_match_reference(golden_dir):
+    z = _lt(golden_dir)
+    p, t, iw, ow = (torch.from_numpy(a) for a in z["sl1_rpn_in"])
+    assert abs(O.smooth_l1_loss("RPN", p, t, iw, ow, dim=(1, 2, 3)).item() - z["sl1_rpn"][0]) <= 1e-7
+    p, t, iw, ow = (torch.from_numpy(a) for a in z["sl1_det_in"])
+    assert abs(O.smooth_l1_loss("DET", p, t, iw, ow).item() - z["sl1_det"][0]) <= 1e-7
+    p, t = (torch.from_numpy(a) for a in z["huber_in"])
+    np.testing.assert_array_equal(O.huber_loss(p, t).numpy(), z["huber"])
+    np.testing.assert_array_equal(O.huber_loss(p, t, sin_en=True).numpy(), z["huber_sin"])
+    p, t, iw, ow = (torch.from_numpy(a) for a in z["sl1_lidar_in"])
+    assert abs(O.smooth_l1_loss("DET", p, t, iw, ow, net_type="lidar").item() - z["sl1_lidar"][0]) <= 1e-7
