@@ -27,6 +27,7 @@ PROTOTYPES = {
     "frcnn_rpn_decode_clip": (c_int, [_P, c_int, _P, _P, _P, POINTER(c_float), c_int, c_int, _P, _P, _P]),
     "frcnn_bbox_transform_inv": (c_int, [_P, c_int, _P, c_int, c_int, c_float, _P, _P]),
     "frcnn_clip_boxes": (c_int, [_P, c_int, POINTER(c_float), _P, _P]),
+    "frcnn_lidar_bbox_transform_inv": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_float, _P, _P]),
     "frcnn_sort_topk_desc_ws_bytes": (c_size_t, [c_int, c_int]),
     "frcnn_sort_topk_desc": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "frcnn_gather_rows": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
@@ -36,6 +37,11 @@ PROTOTYPES = {
     "frcnn_roi_align_fwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_float, c_int, _P, c_int, _P, _P]),
     "frcnn_head_fc_softmax_decode": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, POINTER(c_float),
                                              POINTER(c_float), c_float, _P, _P, _P, _P, _P, _P]),
+    "frcnn_head_fc_softmax_decode_lidar": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P,
+                                                   POINTER(c_float), POINTER(c_float), c_float, _P, _P, _P, _P, _P, _P]),
+    "frcnn_generate_anchors_3d": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "frcnn_filter_per_class_lidar": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, c_int, c_int, _P, _P, _P,
+                                             c_size_t, _P]),
     "frcnn_filter_per_class_ws_bytes": (c_size_t, [c_int, c_int]),
     "frcnn_filter_per_class": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int,
                                        c_int, _P, _P, _P, c_size_t, _P]),

@@ -31,6 +31,23 @@ __device__ __forceinline__ void decode_box(float x1, float y1, float x2, float y
   out[3] = pcy + 0.5f * ph;
 }
 
+// lidar_3d_bbox_transform_inv for one (roi, 3-D anchor, delta) triple — lib/model/bbox_transform.py:185-222:
+// length/width/centre from the axis-aligned RoI (+1 convention, centre = x1 + len/2), height and z from the
+// 3-D anchor, centre deltas scaled by the RoI diagonal, heading = raw delta.
+__device__ __forceinline__ void decode_box_lidar(float x1, float y1, float x2, float y2, const float* anchor3d,
+                                                 const float d[7], float out[7]) {
+  const float ln = x2 - x1 + 1.0f, wd = y2 - y1 + 1.0f, ht = anchor3d[5];
+  const float cx = x1 + ln / 2.0f, cy = y1 + wd / 2.0f, cz = anchor3d[2];
+  const float diag = sqrtf(ln * ln + wd * wd);
+  out[0] = d[0] * diag + cx;
+  out[1] = d[1] * diag + cy;
+  out[2] = d[2] * ht + cz;
+  out[3] = exp_f32(d[3]) * ln;
+  out[4] = exp_f32(d[4]) * wd;
+  out[5] = exp_f32(d[5]) * ht;
+  out[6] = d[6];
+}
+
 // torch.clamp(v, lo, hi) = min(max(v, lo), hi)
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 

@@ -31,6 +31,28 @@ __global__ __launch_bounds__(256) void anchors_kernel(const double* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// GridAnchor3dGenerator — lib/layer_utils/generate_3d_anchors.py:15-118, plus the axis-aligned BEV box of
+// every 3-D anchor (lib/utils/bbox.py:256-293, clip=False) that the RPN regresses against.
+// `base` holds one row per anchor type t = size*R + rot (the order of the meshgrid, rot fastest):
+//   [lo_x, lo_y, hi_x, hi_y, z, l, w, h, ry]   lo/hi = float32 BEV half extents of the rotated box.
+// Layout (H, W, T): anchors3d[i] = [x, y, z, l, w, h, ry], anchors2d[i] = [lo_x+x, lo_y+y, hi_x+x, hi_y+y]
+// with x = float(col*stride), y = float(row*stride) and fp32 adds like the reference's float32 arrays.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void anchors3d_kernel(const float* __restrict__ base, int T, int H, int W,
+                                                       int stride, float* __restrict__ a3, float* __restrict__ a2) {
+  const int total = H * W * T;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int t = i % T;
+    const int pix = i / T;
+    const float xc = (float)((pix % W) * stride), yc = (float)((pix / W) * stride);
+    const float* b = base + t * 9;
+    float* o = a3 + (size_t)i * 7;
+    o[0] = xc; o[1] = yc; o[2] = b[4]; o[3] = b[5]; o[4] = b[6]; o[5] = b[7]; o[6] = b[8];
+    reinterpret_cast<float4*>(a2)[i] = make_float4(b[0] + xc, b[1] + yc, b[2] + xc, b[3] + yc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // proposal_layer.py:32-36: fg score, bbox_transform_inv, clip_boxes for anchor i = pix*A + a.
 // ------------------------------------------------------------------------------------------------
 struct ClipInfo {
@@ -264,7 +286,9 @@ __global__ __launch_bounds__(256) void clamp_pred_boxes_kernel(float* __restrict
 constexpr int FILTER_THREADS = 256;
 
 // One workgroup per foreground class.  ws per class: sorted boxes [R][4] floats, mask [R][nb] u64,
-// keep_idx [R] int64.
+// keep_idx [R] int64.  E = 4: image boxes; E = 7: LiDAR boxes [xc,yc,zc,l,w,h,ry], suppressed on the
+// yaw-less BEV rectangle xc -+ l/2, yc -+ w/2 (filter_predictions.py:55-62,67); rows of dets are E+1 wide.
+template <int E>
 __global__ __launch_bounds__(FILTER_THREADS) void filter_class_kernel(
     const float* __restrict__ pred_boxes, const float* __restrict__ cls_prob, const int* __restrict__ roi_count,
     int num_rois, int num_classes, float thresh, float nms_thresh, int max_dets, int max_out, int npad, int nb,
@@ -297,8 +321,13 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_class_kernel(
   block_bitonic_sort(keys, npad);  // (score desc, roi index asc)
   for (int i = t; i < n; i += FILTER_THREADS) {
     const uint32_t r = (uint32_t)(keys[i] & 0xFFFFFFFFu);
-    reinterpret_cast<float4*>(sboxes)[i] =
-        *reinterpret_cast<const float4*>(pred_boxes + ((size_t)r * num_classes + cls) * 4);
+    const float* pb = pred_boxes + ((size_t)r * num_classes + cls) * E;
+    if (E == 4) {
+      reinterpret_cast<float4*>(sboxes)[i] = make_float4(pb[0], pb[1], pb[2], pb[3]);
+    } else {
+      reinterpret_cast<float4*>(sboxes)[i] =
+          make_float4(pb[0] - pb[3] / 2.0f, pb[1] - pb[4] / 2.0f, pb[0] + pb[3] / 2.0f, pb[1] + pb[4] / 2.0f);
+    }
   }
   __syncthreads();
   // suppression bit-matrix (words on/right of the diagonal)
@@ -331,16 +360,18 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_class_kernel(
     kept = m;
   }
   kept = min(kept, max_out);
-  float* out = dets + (size_t)cls * max_out * 5;
+  float* out = dets + (size_t)cls * max_out * (E + 1);
   for (int i = t; i < max_out; i += FILTER_THREADS) {
-    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float v[E + 1];
+    for (int q = 0; q <= E; ++q) v[q] = 0.f;
     if (i < kept) {
       const int64_t k = keep_idx[i];
       const uint32_t r = (uint32_t)(keys[k] & 0xFFFFFFFFu);
-      v[0] = sboxes[k * 4 + 0]; v[1] = sboxes[k * 4 + 1]; v[2] = sboxes[k * 4 + 2]; v[3] = sboxes[k * 4 + 3];
-      v[4] = cls_prob[(size_t)r * num_classes + cls];
+      const float* pb = pred_boxes + ((size_t)r * num_classes + cls) * E;
+      for (int q = 0; q < E; ++q) v[q] = pb[q];
+      v[E] = cls_prob[(size_t)r * num_classes + cls];
     }
-    for (int q = 0; q < 5; ++q) out[i * 5 + q] = v[q];
+    for (int q = 0; q <= E; ++q) out[i * (E + 1) + q] = v[q];
   }
   if (t == 0) det_count[cls] = kept;
 }
@@ -361,6 +392,25 @@ __global__ __launch_bounds__(256) void bbox_transform_inv_kernel(const float* __
     float o[4];
     decode_box(x1, y1, x2, y2, d.x, d.y, d.z, d.w, o);
     reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// lidar_3d_bbox_transform_inv for (N rois) x (Kc classes) — lib/model/bbox_transform.py:174-233.
+__global__ __launch_bounds__(256) void lidar_bbox_transform_inv_kernel(const float* __restrict__ rois, int roi_ld,
+                                                                      const float* __restrict__ anchors3d,
+                                                                      const float* __restrict__ deltas, int n, int kc,
+                                                                      float scale, int use_scale,
+                                                                      float* __restrict__ out) {
+  const int total = n * kc;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int r = i / kc;
+    const float* b = rois + (size_t)r * roi_ld;
+    float x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3];
+    if (use_scale) { x1 = x1 / scale; y1 = y1 / scale; x2 = x2 / scale; y2 = y2 / scale; }
+    float d[7], o[7];
+    for (int q = 0; q < 7; ++q) d[q] = deltas[(size_t)i * 7 + q];
+    decode_box_lidar(x1, y1, x2, y2, anchors3d + (size_t)r * 7, d, o);
+    for (int q = 0; q < 7; ++q) out[(size_t)i * 7 + q] = o[q];
   }
 }
 
@@ -491,39 +541,68 @@ extern "C" size_t frcnn_filter_per_class_ws_bytes(int num_rois, int num_classes)
   return filter_ws_per_class(num_rois) * (size_t)(num_classes - 1);
 }
 
-extern "C" int frcnn_filter_per_class(float* pred_boxes, const float* cls_prob, const int* roi_count, int num_rois,
-                                      int num_classes, float frame_w, float frame_h, float scale, float thresh,
-                                      float nms_thresh, int max_dets, int max_out, float* dets, int* det_count,
-                                      void* ws, size_t ws_bytes, void* stream_) {
+template <int E>
+static int launch_filter(float* pred_boxes, const float* cls_prob, const int* roi_count, int num_rois, int num_classes,
+                         float frame_w, float frame_h, float scale, float thresh, float nms_thresh, int max_dets,
+                         int max_out, float* dets, int* det_count, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   FRCNN_REQUIRE(pred_boxes && cls_prob && dets && det_count && num_rois > 0 && num_classes > 1 && max_out > 0,
                 "filter_per_class: bad arguments");
   FRCNN_REQUIRE(num_rois <= 8192, "filter_per_class: num_rois %d > 8192", num_rois);
   const size_t need = frcnn_filter_per_class_ws_bytes(num_rois, num_classes);
   if (!ws || ws_bytes < need) return fail(FRCNN_ERR_WS, "filter_per_class: workspace %zu < %zu bytes", ws_bytes, need);
-  // frame_width/scale - 1 evaluated in fp32 like the numpy float32 scalars of filter_predictions.py:77-91
-  const float x_hi = frame_w / scale - 1.0f, y_hi = frame_h / scale - 1.0f;
-  const int total_boxes = num_rois * num_classes;
-  hipLaunchKernelGGL(clamp_pred_boxes_kernel, dim3(std::min((total_boxes + 255) / 256, 1024)), dim3(256), 0, stream,
-                     pred_boxes, total_boxes, x_hi, y_hi);
-  int rc = check_launch("clamp_pred_boxes_kernel");
-  if (rc != FRCNN_OK) return rc;
+  if (E == 4) {
+    // frame_width/scale - 1 evaluated in fp32 like the numpy float32 scalars of filter_predictions.py:77-91
+    const float x_hi = frame_w / scale - 1.0f, y_hi = frame_h / scale - 1.0f;
+    const int total_boxes = num_rois * num_classes;
+    hipLaunchKernelGGL(clamp_pred_boxes_kernel, dim3(std::min((total_boxes + 255) / 256, 1024)), dim3(256), 0, stream,
+                       pred_boxes, total_boxes, x_hi, y_hi);
+    int rc = check_launch("clamp_pred_boxes_kernel");
+    if (rc != FRCNN_OK) return rc;
+  }  // LiDAR boxes are not clamped (filter_predictions.py:92-93)
   const int npad = next_pow2(std::max(num_rois, 2));
   const int nb = (num_rois + 63) / 64;
   const size_t lds = (size_t)npad * 8;
   static size_t configured = 0;
   if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_class_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_class_kernel<E>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "filter_per_class: set LDS size: %s", hipGetErrorString(e));
     configured = lds;
   }
   hipError_t e = hipMemsetAsync(det_count, 0, sizeof(int) * num_classes, stream);
   if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "filter_per_class: memset: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(filter_class_kernel, dim3(num_classes - 1), dim3(FILTER_THREADS), lds, stream, pred_boxes, cls_prob,
-                     roi_count, num_rois, num_classes, thresh, nms_thresh, max_dets, max_out, npad, nb, dets, det_count,
-                     static_cast<unsigned char*>(ws), filter_ws_per_class(num_rois));
+  hipLaunchKernelGGL(filter_class_kernel<E>, dim3(num_classes - 1), dim3(FILTER_THREADS), lds, stream, pred_boxes,
+                     cls_prob, roi_count, num_rois, num_classes, thresh, nms_thresh, max_dets, max_out, npad, nb, dets,
+                     det_count, static_cast<unsigned char*>(ws), filter_ws_per_class(num_rois));
   return check_launch("filter_class_kernel");
+}
+
+extern "C" int frcnn_filter_per_class(float* pred_boxes, const float* cls_prob, const int* roi_count, int num_rois,
+                                      int num_classes, float frame_w, float frame_h, float scale, float thresh,
+                                      float nms_thresh, int max_dets, int max_out, float* dets, int* det_count,
+                                      void* ws, size_t ws_bytes, void* stream_) {
+  return launch_filter<4>(pred_boxes, cls_prob, roi_count, num_rois, num_classes, frame_w, frame_h, scale, thresh,
+                          nms_thresh, max_dets, max_out, dets, det_count, ws, ws_bytes, stream_);
+}
+
+extern "C" int frcnn_filter_per_class_lidar(const float* pred_boxes, const float* cls_prob, const int* roi_count,
+                                            int num_rois, int num_classes, float thresh, float nms_thresh,
+                                            int max_dets, int max_out, float* dets, int* det_count, void* ws,
+                                            size_t ws_bytes, void* stream_) {
+  return launch_filter<7>(const_cast<float*>(pred_boxes), cls_prob, roi_count, num_rois, num_classes, 0.f, 0.f, 1.f,
+                          thresh, nms_thresh, max_dets, max_out, dets, det_count, ws, ws_bytes, stream_);
+}
+
+extern "C" int frcnn_generate_anchors_3d(const float* base, int num_types, int height, int width, int feat_stride,
+                                         float* anchors_3d, float* anchors_2d, void* stream_) {
+  FRCNN_REQUIRE(base && anchors_3d && anchors_2d && num_types > 0 && height > 0 && width > 0 && feat_stride > 0,
+                "generate_anchors_3d: bad arguments");
+  const int total = height * width * num_types;
+  hipLaunchKernelGGL(anchors3d_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), base, num_types, height, width, feat_stride, anchors_3d,
+                     anchors_2d);
+  return check_launch("anchors3d_kernel");
 }
 
 extern "C" int frcnn_bbox_transform_inv(const float* boxes, int box_ld, const float* deltas, int n, int num_classes,
@@ -534,6 +613,18 @@ extern "C" int frcnn_bbox_transform_inv(const float* boxes, int box_ld, const fl
                      static_cast<hipStream_t>(stream_), boxes, box_ld, deltas, n, num_classes, scale, scale > 0.f ? 1 : 0,
                      out);
   return check_launch("bbox_transform_inv_kernel");
+}
+
+extern "C" int frcnn_lidar_bbox_transform_inv(const float* rois, int roi_ld, const float* anchors_3d,
+                                              const float* deltas, int n, int num_classes, float scale, float* out,
+                                              void* stream_) {
+  FRCNN_REQUIRE(rois && anchors_3d && deltas && out && n > 0 && num_classes > 0 && roi_ld >= 4,
+                "lidar_bbox_transform_inv: bad arguments");
+  const int total = n * num_classes;
+  hipLaunchKernelGGL(lidar_bbox_transform_inv_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), rois, roi_ld, anchors_3d, deltas, n, num_classes, scale,
+                     scale > 0.f ? 1 : 0, out);
+  return check_launch("lidar_bbox_transform_inv_kernel");
 }
 
 extern "C" int frcnn_clip_boxes(const float* boxes, int num_boxes, const float* info_host, float* out, void* stream_) {

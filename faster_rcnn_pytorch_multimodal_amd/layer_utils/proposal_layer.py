@@ -13,7 +13,7 @@ from .. import ops
 from ..model.config import cfg
 
 ProposalResult = collections.namedtuple(
-    'ProposalResult', 'rois roi_scores count order keep_idx sorted_boxes sorted_scores scores proposals')
+    'ProposalResult', 'rois roi_scores count order keep_idx sorted_boxes sorted_scores scores proposals sorted_count')
 
 
 def proposal_layer_device(anchors, info, num_anchors, pre_nms_top_n, post_nms_top_n, nms_thresh, rpn=None,
@@ -29,7 +29,8 @@ def proposal_layer_device(anchors, info, num_anchors, pre_nms_top_n, post_nms_to
     max_keep = post_nms_top_n if post_nms_top_n > 0 else order.numel()
     keep_idx, keep_count, _ = ops.nms_sorted(sorted_boxes, nms_thresh, max_keep=max_keep, n_dev=n_sorted)
     rois, roi_scores = ops.make_rois(sorted_boxes, sorted_scores, keep_idx, keep_count)
-    return ProposalResult(rois, roi_scores, keep_count, order, keep_idx, sorted_boxes, sorted_scores, scores, proposals)
+    return ProposalResult(rois, roi_scores, keep_count, order, keep_idx, sorted_boxes, sorted_scores, scores, proposals,
+                          n_sorted)
 
 
 def proposal_layer(rpn_cls_prob, rpn_bbox_pred, info, cfg_key, anchors, anchors_3d, num_anchors):
@@ -46,6 +47,6 @@ def proposal_layer(rpn_cls_prob, rpn_bbox_pred, info, cfg_key, anchors, anchors_
     blob = res.rois[:n]
     scores = res.roi_scores[:n]
     if anchors_3d is not None:
-        picked = res.order[res.keep_idx[:n]]
-        anchors_3d = anchors_3d[picked, :]
+        a3_sorted = ops.gather_rows(anchors_3d.contiguous(), res.order, res.sorted_count)   # :44
+        anchors_3d = ops.gather_rows(a3_sorted, res.keep_idx, res.count)[:n]                # :52
     return blob, scores, anchors_3d

@@ -15,3 +15,10 @@ def bbox_transform_inv(boxes, deltas, scales=None):
 def clip_boxes(boxes, shape):
     """Clamp x to [shape[0], shape[1]-1] and y to [shape[2], shape[3]-1].  bbox_transform.py:235-257."""
     return ops.clip_boxes(boxes.contiguous(), [float(v) for v in list(shape)[:4]])
+
+
+def lidar_3d_bbox_transform_inv(rois, boxes, deltas, scales=None):
+    """rois (N,4) axis-aligned BEV RoIs, boxes (N,7) their 3-D anchors, deltas (N,7K) -> (N,7K)
+    [xc,yc,zc,l,w,h,ry].  lib/model/bbox_transform.py:174-233 (the reference also divides the anchors' x,y,l,w
+    by ``scales`` in place, :177-178, but never reads them afterwards; that side effect is not reproduced)."""
+    return ops.lidar_bbox_transform_inv(rois.contiguous(), boxes.contiguous(), deltas.contiguous(), scales)

@@ -26,6 +26,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..layer_utils.proposal_layer import proposal_layer_device
+from ..layer_utils.generate_3d_anchors import generate_anchors_3d
 from ..layer_utils.snippets import generate_anchors_pre
 from ..model.config import cfg
 from . import resnet as custom_resnet
@@ -108,9 +109,20 @@ class Network(nn.Module):
     _input_to_head = _image_to_head  # name used by the other backbones of the reference (vgg16.py:49)
 
     def _anchor_component(self, height, width):
+        """Image: dense 2-D anchors (snippets.py:13-40).  LiDAR: 3-D grid anchors (generate_3d_anchors.py) and
+        their axis-aligned BEV rectangles, which the RPN regresses against; ``anchor_scales`` is the single size
+        multiplier and ``anchor_ratios`` carries the yaw angles (tools/test_net.py:267-271)."""
+        if cfg.NET_TYPE == 'lidar':
+            length, a3, a2 = generate_anchors_3d(height, width, self._feat_stride, self._anchor_scales,
+                                                 self._anchor_ratios, self._frame_scale, device=self._image.device)
+            self._anchors_3d = a3
+            self._anchors = a2
+            self._anchor_length = np.int32(length)
+            return a2
         anchors, length = generate_anchors_pre(height, width, self._feat_stride, self._anchor_scales,
                                                self._anchor_ratios, self._frame_scale, device=self._image.device)
         self._anchors = anchors
+        self._anchors_3d = None
         self._anchor_length = length
         return anchors
 
@@ -155,6 +167,10 @@ class Network(nn.Module):
         self._predictions['rois'] = res.rois
         self._predictions['roi_scores'] = res.roi_scores
         self._predictions['rois_count'] = res.count
+        if self._anchors_3d is not None:
+            # proposal_layer.py:44,52: the 3-D anchors follow the same order -> keep selection as the boxes
+            a3_sorted = ops.gather_rows(self._anchors_3d, res.order, res.sorted_count)
+            self._predictions['roi_anchors_3d'] = ops.gather_rows(a3_sorted, res.keep_idx, res.count)
         return res.rois
 
     def _crop_pool_layer(self, bottom, rois):
@@ -168,12 +184,11 @@ class Network(nn.Module):
 
     def _tail_kernel(self, x_nhwc, rois):
         key = cfg.NET_TYPE.upper() if cfg.NET_TYPE in ('image', 'lidar') else 'IMAGE'
-        if key != 'IMAGE':
-            raise NotImplementedError("the fused detection tail handles the image detector (4-DoF boxes)")
         return ops.head_fc_softmax_decode(
             x_nhwc, self.cls_score_net.weight.detach(), self.cls_score_net.bias.detach(),
             self.bbox_pred_net.weight.detach(), self.bbox_pred_net.bias.detach(), rois.contiguous(),
-            cfg.TRAIN[key].BBOX_NORMALIZE_STDS, cfg.TRAIN[key].BBOX_NORMALIZE_MEANS, self._frame_scale)
+            cfg.TRAIN[key].BBOX_NORMALIZE_STDS, cfg.TRAIN[key].BBOX_NORMALIZE_MEANS, self._frame_scale,
+            roi_anchors_3d=self._predictions.get('roi_anchors_3d') if key == 'LIDAR' else None)
 
     def _head_to_tail(self, pool5):
         """layer4 on the pooled RoIs then ``.mean(3).mean(2)`` -> fc7 (R, 2048)."""

@@ -158,6 +158,21 @@ def bbox_transform_inv(boxes, deltas, scale=None):
     return out
 
 
+def lidar_bbox_transform_inv(rois, anchors_3d, deltas, scale=None):
+    """rois (N, >=4) [x1,y1,x2,y2,...], anchors_3d (N,7), deltas (N,7K) -> (N,7K) [xc,yc,zc,l,w,h,ry] per class."""
+    lib = _hip.load()
+    _dev_f32(rois, "rois"); _dev_f32(anchors_3d, "anchors_3d"); _dev_f32(deltas, "deltas")
+    n = rois.shape[0]
+    if n == 0:
+        return deltas.detach() * 0  # reference: bbox_transform.py:181-182
+    k = deltas.shape[1] // 7
+    out = torch.empty((n, 7 * k), dtype=torch.float32, device=rois.device)
+    _hip.check(lib.frcnn_lidar_bbox_transform_inv(_ptr(rois), rois.shape[1], _ptr(anchors_3d), _ptr(deltas), n, k,
+                                                  float(scale) if scale is not None else 0.0, _ptr(out), _stream()),
+               "frcnn_lidar_bbox_transform_inv")
+    return out
+
+
 def clip_boxes(boxes, info):
     lib = _hip.load()
     _dev_f32(boxes, "boxes")
@@ -236,26 +251,68 @@ def roi_align_nhwc(feat, rois, pooled, spatial_scale, sampling_ratio=0, roi_coun
     return out
 
 
-def head_fc_softmax_decode(x, w_cls, b_cls, w_box, b_box, rois, stds, means, scale):
-    """x (R,P,P,C) -> dict(fc7, cls_score, cls_prob, bbox_pred, pred_boxes)."""
+def head_fc_softmax_decode(x, w_cls, b_cls, w_box, b_box, rois, stds, means, scale, roi_anchors_3d=None):
+    """x (R,P,P,C) -> dict(fc7, cls_score, cls_prob, bbox_pred, pred_boxes).  With ``roi_anchors_3d`` (R,7) the
+    boxes are the 7-DoF LiDAR boxes (frcnn_head_fc_softmax_decode_lidar), otherwise 4-DoF image boxes."""
     lib = _hip.load()
     for nm, t in (("x", x), ("w_cls", w_cls), ("b_cls", b_cls), ("w_box", w_box), ("b_box", b_box), ("rois", rois)):
         _dev_f32(t, nm)
     r, p, _, c = x.shape
     k = w_cls.shape[0]
-    if w_box.shape[0] != 4 * k or w_cls.shape[1] != c or w_box.shape[1] != c:
-        raise _hip.HipError("head_fc_softmax_decode: inconsistent head weights")
+    e = 4 if roi_anchors_3d is None else 7
+    if w_box.shape[0] != e * k or w_cls.shape[1] != c or w_box.shape[1] != c or len(stds) != e or len(means) != e:
+        raise _hip.HipError("head_fc_softmax_decode: inconsistent head weights / normalisation for %d-DoF boxes" % e)
     dev = x.device
     fc7 = torch.empty((r, c), dtype=torch.float32, device=dev)
     cls_score = torch.empty((r, k), dtype=torch.float32, device=dev)
     cls_prob = torch.empty((r, k), dtype=torch.float32, device=dev)
-    bbox_pred = torch.empty((r, 4 * k), dtype=torch.float32, device=dev)
-    pred_boxes = torch.empty((r, 4 * k), dtype=torch.float32, device=dev)
-    _hip.check(lib.frcnn_head_fc_softmax_decode(_ptr(x), r, p, c, _ptr(w_cls), _ptr(b_cls), _ptr(w_box), _ptr(b_box), k,
-                                                _ptr(rois), _hip.float_array(stds), _hip.float_array(means), float(scale),
-                                                _ptr(fc7), _ptr(cls_score), _ptr(cls_prob), _ptr(bbox_pred),
-                                                _ptr(pred_boxes), _stream()), "frcnn_head_fc_softmax_decode")
+    bbox_pred = torch.empty((r, e * k), dtype=torch.float32, device=dev)
+    pred_boxes = torch.empty((r, e * k), dtype=torch.float32, device=dev)
+    if e == 4:
+        _hip.check(lib.frcnn_head_fc_softmax_decode(
+            _ptr(x), r, p, c, _ptr(w_cls), _ptr(b_cls), _ptr(w_box), _ptr(b_box), k, _ptr(rois),
+            _hip.float_array(stds), _hip.float_array(means), float(scale), _ptr(fc7), _ptr(cls_score), _ptr(cls_prob),
+            _ptr(bbox_pred), _ptr(pred_boxes), _stream()), "frcnn_head_fc_softmax_decode")
+    else:
+        _dev_f32(roi_anchors_3d, "roi_anchors_3d")
+        if tuple(roi_anchors_3d.shape) != (r, 7):
+            raise _hip.HipError("head_fc_softmax_decode: roi_anchors_3d must be (%d, 7)" % r)
+        _hip.check(lib.frcnn_head_fc_softmax_decode_lidar(
+            _ptr(x), r, p, c, _ptr(w_cls), _ptr(b_cls), _ptr(w_box), _ptr(b_box), k, _ptr(rois), _ptr(roi_anchors_3d),
+            _hip.float_array(stds), _hip.float_array(means), float(scale), _ptr(fc7), _ptr(cls_score), _ptr(cls_prob),
+            _ptr(bbox_pred), _ptr(pred_boxes), _stream()), "frcnn_head_fc_softmax_decode_lidar")
     return {"fc7": fc7, "cls_score": cls_score, "cls_prob": cls_prob, "bbox_pred": bbox_pred, "pred_boxes": pred_boxes}
+
+
+def generate_anchors_3d(base, height, width, feat_stride):
+    """base: DEVICE float32 (T, 9) anchor-type table -> (anchors_3d (H*W*T, 7), anchors_2d (H*W*T, 4))."""
+    lib = _hip.load()
+    _dev_f32(base, "base")
+    t = base.shape[0]
+    a3 = torch.empty((height * width * t, 7), dtype=torch.float32, device=base.device)
+    a2 = torch.empty((height * width * t, 4), dtype=torch.float32, device=base.device)
+    _hip.check(lib.frcnn_generate_anchors_3d(_ptr(base), t, height, width, feat_stride, _ptr(a3), _ptr(a2), _stream()),
+               "frcnn_generate_anchors_3d")
+    return a3, a2
+
+
+def filter_per_class_lidar(pred_boxes, cls_prob, thresh, nms_thresh, max_dets, max_out=None, roi_count=None):
+    """7-DoF form: returns (dets (K, max_out, 8) [xc,yc,zc,l,w,h,ry,score], det_count int32 (K,))."""
+    lib = _hip.load()
+    _dev_f32(pred_boxes, "pred_boxes"); _dev_f32(cls_prob, "cls_prob")
+    r, k = cls_prob.shape
+    if pred_boxes.shape[1] != 7 * k:
+        raise _hip.HipError("filter_per_class_lidar: pred_boxes must be (R, 7K)")
+    max_out = r if max_out is None else max_out
+    dets = torch.zeros((k, max_out, 8), dtype=torch.float32, device=cls_prob.device)
+    det_count = torch.zeros((k,), dtype=torch.int32, device=cls_prob.device)
+    ws_bytes = lib.frcnn_filter_per_class_ws_bytes(r, k)
+    ws = _workspace(ws_bytes, cls_prob.device)
+    _hip.check(lib.frcnn_filter_per_class_lidar(_ptr(pred_boxes), _ptr(cls_prob), _ptr(roi_count), r, k, float(thresh),
+                                                float(nms_thresh), int(max_dets), int(max_out), _ptr(dets),
+                                                _ptr(det_count), _ptr(ws), ws_bytes, _stream()),
+               "frcnn_filter_per_class_lidar")
+    return dets, det_count
 
 
 def filter_per_class(pred_boxes, cls_prob, frame_w, frame_h, scale, thresh, nms_thresh, max_dets, max_out=None,

@@ -11,9 +11,13 @@ from .. import ops
 from ..model.config import cfg
 
 
-def filter_device(rois_count, cls_prob, pred_boxes, info, thresh=0.1, max_dets=0, max_out=None):
-    """Asynchronous form: returns (dets (K, max_out, 5), det_count (K,)) device tensors.
-    ``pred_boxes`` is clamped IN PLACE like the reference (:85-91)."""
+def filter_device(rois_count, cls_prob, pred_boxes, info, thresh=0.1, max_dets=0, max_out=None, db_type='image'):
+    """Asynchronous form: returns (dets (K, max_out, E+1), det_count (K,)) device tensors, E = 4 image /
+    7 LiDAR.  Image ``pred_boxes`` are clamped IN PLACE like the reference (:85-91); LiDAR boxes are not clamped
+    and are suppressed on their yaw-less BEV rectangle (:55-62,67)."""
+    if db_type == 'lidar':
+        return ops.filter_per_class_lidar(pred_boxes, cls_prob, thresh, cfg.TEST.NMS_THRESH, max_dets, max_out,
+                                          roi_count=rois_count)
     info = np.asarray(info, dtype=np.float32)
     frame_w, frame_h, scale = info[1] - info[0], info[3] - info[2], info[6]
     return ops.filter_per_class(pred_boxes, cls_prob, float(frame_w), float(frame_h), float(scale), thresh,
@@ -21,13 +25,11 @@ def filter_device(rois_count, cls_prob, pred_boxes, info, thresh=0.1, max_dets=0
 
 
 def filter_and_draw_prep(rois, cls_score, pred_boxes, uncertainties, info, num_classes, thresh=0.1, db_type='none'):
-    """Reference signature and return value: (rois_np (R,4), all_boxes[K] of (n_j,5) float32 arrays,
+    """Reference signature and return value: (rois_np (R,4), all_boxes[K] of (n_j,5) (LiDAR (n_j,8)) float32 arrays,
     all_uncertainty[K] dicts).  ``cls_score`` is the class-probability tensor (lib/model/test.py:75-93)."""
-    if db_type != 'image':
-        if db_type == 'lidar':
-            raise NotImplementedError("LiDAR (7-DoF) post-processing is not on the HIP path yet")
+    if db_type not in ('image', 'lidar'):
         return None
-    dets, det_count = filter_device(None, cls_score.contiguous(), pred_boxes, info, thresh)
+    dets, det_count = filter_device(None, cls_score.contiguous(), pred_boxes, info, thresh, db_type=db_type)
     dets_np = dets.cpu().numpy()          # the one device->host copy (+ implicit sync)
     counts = det_count.cpu().numpy()
     all_boxes = [[] for _ in range(num_classes)]

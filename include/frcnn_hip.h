@@ -70,6 +70,14 @@ int frcnn_pad_channels(const float* x, float* y, int64_t pixels, int c, int c_pa
 int frcnn_generate_anchors(const double* base, int num_base, int height, int width, int feat_stride,
                            float* anchors, void* stream);
 
+/* GridAnchor3dGenerator._generate (lib/layer_utils/generate_3d_anchors.py:15-118) and the axis-aligned BEV
+ * box of each 3-D anchor (bbaa_graphics_gems, lib/utils/bbox.py:256-293, clip=False) for the LiDAR RPN.
+ * base (DEVICE, num_types x 9 floats), one row per (size, rotation) type, rotation fastest:
+ *   [lo_x, lo_y, hi_x, hi_y, z, l, w, h, ry]  (host-computed like generate_3d_anchors.py:37-38,100 and
+ *   bbox.py:258-279).  anchors_3d (H*W*T, 7) [x,y,z,l,w,h,ry], anchors_2d (H*W*T, 4), order (H, W, T). */
+int frcnn_generate_anchors_3d(const float* base, int num_types, int height, int width, int feat_stride,
+                              float* anchors_3d, float* anchors_2d, void* stream);
+
 /* Fused front half of proposal_layer (lib/layer_utils/proposal_layer.py:32-36) on the raw RPN head
  * output `rpn` (H*W, ld) NHWC with channels [0,A) = bg logits, [A,2A) = fg logits, [2A,6A) = deltas:
  *   fg prob of the 2-way softmax, bbox_transform_inv (lib/model/bbox_transform.py:75-105) and
@@ -87,6 +95,10 @@ int frcnn_rpn_decode_clip(const float* rpn, int ld, const float* probs_in, const
 int frcnn_bbox_transform_inv(const float* boxes, int box_ld, const float* deltas, int n, int num_classes,
                              float scale, float* out, void* stream);
 int frcnn_clip_boxes(const float* boxes, int num_boxes, const float* info_host, float* out, void* stream);
+/* lidar_3d_bbox_transform_inv (lib/model/bbox_transform.py:174-233): rois rows of roi_ld floats whose first 4
+ * are [x1,y1,x2,y2]; anchors_3d (n,7); deltas/out (n, 7*num_classes); scale <= 0 = None. */
+int frcnn_lidar_bbox_transform_inv(const float* rois, int roi_ld, const float* anchors_3d, const float* deltas,
+                                   int n, int num_classes, float scale, float* out, void* stream);
 
 /* scores.sort(descending=True)[:top_n] (proposal_layer.py:39-42) with the canonical total order
  * (score desc, index asc).  order_out[top_n] int64 source indices, scores_out[top_n];
@@ -140,6 +152,16 @@ int frcnn_head_fc_softmax_decode(const float* x, int num_rois, int pooled, int c
                                  const float* means_host, float scale, float* fc7, float* cls_score,
                                  float* cls_prob, float* bbox_pred, float* pred_boxes, void* stream);
 
+/* LiDAR tail: as above with 7-DoF boxes — bbox_pred (R,7K), pred_boxes = lidar_3d_bbox_transform_inv(
+ * rois[:,1:5], roi_anchors_3d, deltas*stds+means, scale) (lib/model/bbox_transform.py:174-233);
+ * roi_anchors_3d (R,7) are the 3-D anchors of the RoIs (proposal_layer.py:44,52); stds/means 7 floats. */
+int frcnn_head_fc_softmax_decode_lidar(const float* x, int num_rois, int pooled, int c, const float* w_cls,
+                                       const float* b_cls, const float* w_box, const float* b_box,
+                                       int num_classes, const float* rois, const float* roi_anchors_3d,
+                                       const float* stds_host, const float* means_host, float scale, float* fc7,
+                                       float* cls_score, float* cls_prob, float* bbox_pred, float* pred_boxes,
+                                       void* stream);
+
 /* filter_and_draw_prep + nms_hstack_torch + the max_dets cut (lib/utils/filter_predictions.py:75-130,
  * 45-72; lib/model/test.py:210-221) for the image detector, all on the device:
  * clamp to [0, frame/scale-1] in place, per class j>=1 keep score > thresh, NMS(nms_thresh) in
@@ -150,6 +172,13 @@ int frcnn_filter_per_class(float* pred_boxes, const float* cls_prob, const int* 
                            int num_classes, float frame_w, float frame_h, float scale, float thresh,
                            float nms_thresh, int max_dets, int max_out, float* dets, int* det_count,
                            void* ws, size_t ws_bytes, void* stream);
+
+/* LiDAR form (filter_predictions.py:55-62,67, db_type 'lidar'): no clamp, NMS on the yaw-less BEV rectangle
+ * xc -+ l/2, yc -+ w/2 of the 7-DoF boxes, dets (K, max_out, 8) [xc,yc,zc,l,w,h,ry,score].
+ * Workspace: frcnn_filter_per_class_ws_bytes. */
+int frcnn_filter_per_class_lidar(const float* pred_boxes, const float* cls_prob, const int* roi_count,
+                                 int num_rois, int num_classes, float thresh, float nms_thresh, int max_dets,
+                                 int max_out, float* dets, int* det_count, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -725,3 +725,83 @@ def smooth_l1_loss(stage, bbox_pred, bbox_targets, inside_w, outside_w, dim=(1,)
     for i in sorted(dim, reverse=True):
         loss = loss.sum(i)
     return loss.mean()
+
+
+# ----------------------------------------------------------------------------------------------
+# LiDAR-BEV detector — lib/nets/lidarnet.py:28-151 on the RECONSTRUCTED Network contract: 15-plane stem,
+# layer4 without BatchNorm (non-FPN), 3-D anchors + their BEV rectangles for the RPN, 7-DoF decode.
+# ----------------------------------------------------------------------------------------------
+class LidarNetOracle(ImageNetOracle):
+    def __init__(self, num_classes=2):
+        nn.Module.__init__(self)
+        self._num_classes = num_classes
+        self._num_anchors = len(LIDAR_ANCHOR_SCALES) * len(LIDAR_ANCHOR_ANGLES)
+        self._feat_stride = 16                                     # lidarnet.py:48
+        self.resnet = ResNet101(in_channels=LIDAR_NUM_CHANNEL, batchnorm_en=False)   # lidarnet.py:52,107
+        a = self._num_anchors
+        self.rpn_net = nn.Conv2d(1024, RPN_CHANNELS, 3, padding=1)
+        self.rpn_cls_score_net = nn.Conv2d(RPN_CHANNELS, 2 * a, 1)
+        self.rpn_bbox_pred_net = nn.Conv2d(RPN_CHANNELS, 4 * a, 1)
+        self.cls_score_net = nn.Linear(2048, num_classes)
+        self.bbox_pred_net = nn.Linear(2048, num_classes * LIDAR_NUM_BBOX_ELEM)
+        self.eval()
+
+    def _region_proposal(self, net_conv, info, structured=None):
+        a = self._num_anchors
+        h, w = net_conv.shape[2], net_conv.shape[3]
+        _, a3 = generate_anchors_3d(h, w, self._feat_stride, frame_scale=float(info[6]))
+        anchors = torch.from_numpy(bbaa_graphics_gems(a3))
+        rpn = F.relu(self.rpn_net(net_conv))
+        cls_score = self.rpn_cls_score_net(rpn)
+        bbox_pred = self.rpn_bbox_pred_net(rpn).permute(0, 2, 3, 1).contiguous()
+        if structured is not None:
+            cls_score, bbox_pred = structured
+        prob = F.softmax(cls_score.view(1, 2, a * h, w), dim=1).view(1, 2 * a, h, w).permute(0, 2, 3, 1).contiguous()
+        rois, scores, dbg = proposal_layer(prob, bbox_pred, info, anchors, a, return_debug=True)
+        roi_a3 = torch.from_numpy(a3)[dbg["order"]][dbg["keep"]]   # proposal_layer.py:44,52
+        self._dbg = {"anchors": anchors, "anchors_3d": torch.from_numpy(a3), "roi_anchors_3d": roi_a3,
+                     "rpn_cls_prob": prob, "rpn_bbox_pred": bbox_pred, "rpn_cls_score": cls_score, **dbg}
+        return rois, scores
+
+    @torch.no_grad()
+    def test_frame(self, data, info, structured=None):
+        image = torch.from_numpy(np.ascontiguousarray(data)).permute(0, 3, 1, 2).contiguous()
+        net_conv = self._image_to_head(image)
+        rois, _ = self._region_proposal(net_conv, info, structured)
+        pool5 = self._crop_pool_layer(net_conv, rois)
+        fc7 = self._head_to_tail(pool5)
+        cls_score, cls_prob, bbox_pred = self._region_classification(fc7)
+        stds = torch.tensor(LIDAR_BBOX_NORMALIZE_STDS).repeat(self._num_classes).unsqueeze(0)
+        means = torch.tensor(LIDAR_BBOX_NORMALIZE_MEANS).repeat(self._num_classes).unsqueeze(0)
+        deltas = bbox_pred.mul(stds).add(means)
+        pred_boxes = lidar_3d_bbox_transform_inv(rois[:, 1:5], self._dbg["roi_anchors_3d"], deltas, float(info[6]))
+        self._dbg.update({"net_conv": net_conv, "pool5": pool5, "fc7": fc7, "bbox_pred": bbox_pred})
+        return cls_score, cls_prob, pred_boxes, rois, {}
+
+
+def filter_and_draw_prep_lidar(rois, cls_prob, pred_boxes, num_classes, thresh=0.1, nms_thresh=TEST_NMS_THRESH):
+    """filter_predictions.py:45-72,92-93 with db_type 'lidar': no clamp, NMS on xc -+ l/2, yc -+ w/2, dets rows
+    [xc,yc,zc,l,w,h,ry,score]."""
+    all_boxes = [np.empty((0, 8), dtype=np.float32) for _ in range(num_classes)]
+    for j in range(1, num_classes):
+        inds = torch.where(cls_prob[:, j] > thresh)[0]
+        if inds.numel() == 0:
+            continue
+        cs = cls_prob[inds, j]
+        cb = pred_boxes[inds, j * 7:(j + 1) * 7]
+        aabb = torch.cat((cb[:, 0:1] - cb[:, 3:4] / 2.0, cb[:, 1:2] - cb[:, 4:5] / 2.0,
+                          cb[:, 0:1] + cb[:, 3:4] / 2.0, cb[:, 1:2] + cb[:, 4:5] / 2.0), dim=1)
+        dets = np.hstack((cb.numpy(), cs.unsqueeze(1).numpy())).astype(np.float32, copy=False)
+        all_boxes[j] = dets[nms(aabb, cs, nms_thresh).numpy(), :]
+    return rois[:, 1:5].numpy(), all_boxes
+
+
+def frame_detect_lidar(net, data, info, num_classes, thresh=0.5, max_dets=100, structured=None):
+    """lib/model/test.py:68-93,210-228 for one LiDAR frame: detections in METRES (bbox_voxel_grid_to_pc)."""
+    _, probs, boxes, rois, _ = net.test_frame(data, info, structured)
+    _, all_boxes = filter_and_draw_prep_lidar(rois, probs, boxes, num_classes, thresh)
+    out = []
+    for b in all_boxes:
+        b = max_dets_cut(b, max_dets)
+        out.append(bbox_voxel_grid_to_pc(b.copy(), lidar_extents(), info) if len(b) else b)
+    return out

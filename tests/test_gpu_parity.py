@@ -495,3 +495,134 @@ def test_full_size_frame_properties(hip):
     # determinism: a second run gives identical bits
     dets2, counts2 = detect_frame_device(net, data, info, thresh=0.0, max_dets=100)
     assert torch.equal(dets, dets2) and torch.equal(counts, counts2)
+
+
+# ------------------------------------------------------------------------------------------------
+# LiDAR-BEV variant (BASELINE config 3)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,h,w,fs", [("25x22_fs0.5", 25, 22, 0.5), ("50x44_fs1", 50, 44, 1.0), ("7x5_fs0.3", 7, 5, 0.3)])
+def test_anchors_3d_bit_exact_against_reference_golden(hip, golden_dir, tag, h, w, fs):
+    from faster_rcnn_pytorch_multimodal_amd.layer_utils.generate_3d_anchors import generate_anchors_3d
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    C.reset_cfg()
+    z = np.load(os.path.join(golden_dir, "lidar_train.npz"))
+    n, a3, a2 = generate_anchors_3d(h, w, 16, C.cfg.LIDAR.ANCHOR_SCALES[0], C.cfg.LIDAR.ANCHOR_ANGLES, fs, device=DEV)
+    assert n == z["a3d_" + tag].shape[0]
+    np.testing.assert_array_equal(a3.cpu().numpy(), z["a3d_" + tag])
+    np.testing.assert_array_equal(a2.cpu().numpy(), z["a2d_" + tag])
+
+
+def test_lidar_codec_against_reference_golden(hip, golden_dir):
+    ops = _ops()
+    z = np.load(os.path.join(golden_dir, "lidar_train.npz"))
+    rois, anc, d = (torch.from_numpy(z[k]).to(DEV) for k in ("l_rois", "l_anchors", "l_deltas"))
+    np.testing.assert_allclose(ops.lidar_bbox_transform_inv(rois, anc, d).cpu().numpy(), z["l_inv"], rtol=3e-7, atol=1e-4)
+    np.testing.assert_allclose(ops.lidar_bbox_transform_inv(rois, anc, d, 0.5).cpu().numpy(), z["l_inv_scale0.5"],
+                               rtol=3e-7, atol=1e-4)
+    # exp() and sqrt() are the only inexact steps (this torch build's CPU sqrt is itself off by one ulp in ~1 % of
+    # the lanes): with zero centre-x/y and size deltas the result must match the oracle bit for bit
+    d0 = d.clone()
+    for q in (0, 1, 3, 4, 5):
+        d0[:, q::7] = 0
+    ref = O.lidar_3d_bbox_transform_inv(rois.cpu(), anc.cpu(), d0.cpu())
+    np.testing.assert_array_equal(ops.lidar_bbox_transform_inv(rois, anc, d0).cpu().numpy(), ref.numpy())
+
+
+def _build_lidar_pair(seed=9):
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.nets.lidarnet import lidarnet
+    C.reset_cfg()
+    C.cfg.NET_TYPE = "lidar"
+    oracle = O.LidarNetOracle(num_classes=2)
+    sd = O.seeded_state_dict(oracle, seed, bn_mode="tame")
+    oracle.load_state_dict(sd, strict=True)
+    net = lidarnet(num_layers=101)
+    net.create_architecture(2, tag="default", anchor_scales=C.cfg.LIDAR.ANCHOR_SCALES[0],
+                            anchor_ratios=C.cfg.LIDAR.ANCHOR_ANGLES)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    net._device = DEV
+    net.to(DEV)
+    return net, oracle
+
+
+def _bev_blob(h, w, seed):
+    rng = np.random.default_rng(seed)
+    return (rng.random((1, h, w, 15)) * (rng.random((1, h, w, 15)) < 0.05)).astype(np.float32)
+
+
+def test_lidar_detector_stagewise_against_oracle(hip):
+    """LiDAR detector on a 208x176 BEV blob (scale 0.5).  As for the image detector, the index-producing stages
+    are re-run on the ORACLE's intermediate tensors so that conv rounding noise cannot blur index parity."""
+    from faster_rcnn_pytorch_multimodal_amd import ops
+    from faster_rcnn_pytorch_multimodal_amd.layer_utils.proposal_layer import proposal_layer
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.utils.filter_predictions import filter_and_draw_prep
+    net, oracle = _build_lidar_pair()
+    data = _bev_blob(208, 176, 3)
+    info = np.array([0, 176, 0, 208, 0, 12, 0.5], np.float32)
+    cs_r, cp_r, pb_r, rois_r, _ = oracle.test_frame(data, info)
+    d = oracle._dbg
+    cs, cp, pb, rois, _ = net.test_frame(data, info)
+    p = net._predictions
+    assert net.resnet.conv1.weight.shape[1] == 15 and pb.shape[1] == 14
+    _close_feat(net._act_summaries["conv"].cpu().permute(0, 3, 1, 2).numpy(), d["net_conv"].numpy(), "net_conv", 5e-5)
+    np.testing.assert_array_equal(net._anchors.cpu().numpy(), d["anchors"].numpy())
+    np.testing.assert_array_equal(net._anchors_3d.cpu().numpy(), d["anchors_3d"].numpy())
+    # proposal_layer with the reference signature on the oracle's probabilities / deltas (13*11*2 = 286 anchors)
+    blob, scores, a3 = proposal_layer(d["rpn_cls_prob"].to(DEV), d["rpn_bbox_pred"].to(DEV), info, "TEST",
+                                      d["anchors"].to(DEV), d["anchors_3d"].to(DEV), 2)
+    assert blob.shape[0] == rois_r.shape[0]
+    np.testing.assert_allclose(blob.cpu().numpy(), rois_r.numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_array_equal(a3.cpu().numpy(), d["roi_anchors_3d"].numpy())      # same anchors picked, in order
+    # tail on the oracle's pooled features / rois / anchors
+    with torch.no_grad():
+        y = net.resnet.layer4(d["pool5"].permute(0, 2, 3, 1).contiguous().to(DEV))
+        net._frame_scale = 0.5
+        net._predictions["roi_anchors_3d"] = d["roi_anchors_3d"].contiguous().to(DEV)
+        tail = net._tail_kernel(y, rois_r.contiguous().to(DEV))
+    _close_feat(tail["fc7"].cpu().numpy(), d["fc7"].numpy(), "fc7", 5e-5)
+    np.testing.assert_allclose(tail["cls_prob"].cpu().numpy(), cp_r.numpy(), rtol=0, atol=1e-4)
+    own = O.lidar_3d_bbox_transform_inv(rois_r[:, 1:5], d["roi_anchors_3d"],
+                                        tail["bbox_pred"].cpu() * torch.tensor(O.LIDAR_BBOX_NORMALIZE_STDS).repeat(2), 0.5)
+    np.testing.assert_allclose(tail["pred_boxes"].cpu().numpy(), own.numpy(), rtol=3e-7, atol=1e-4)
+    np.testing.assert_allclose(tail["pred_boxes"].cpu().numpy(), pb_r.numpy(), rtol=1e-4, atol=2e-3)
+    # per-class filter on the oracle's probabilities / boxes: identical detections (7 box values + score)
+    _, ref_boxes = O.filter_and_draw_prep_lidar(rois_r, cp_r, pb_r, 2, thresh=0.3)
+    _, got_boxes, _ = filter_and_draw_prep(rois_r.to(DEV), cp_r.contiguous().to(DEV), pb_r.contiguous().to(DEV), {},
+                                           info, 2, 0.3, "lidar")
+    assert len(ref_boxes[1]) > 0
+    np.testing.assert_array_equal(np.asarray(got_boxes[1]), ref_boxes[1])
+    C.reset_cfg()
+
+
+@pytest.mark.parametrize("thresh,max_dets", [(0.1, 100), (0.5, 30)])
+def test_filter_per_class_lidar_matches_oracle(hip, thresh, max_dets):
+    ops = _ops()
+    g = torch.Generator().manual_seed(17)
+    r, k = 300, 3
+    prob = torch.softmax(torch.randn(r, k, generator=g) * 2, 1)
+    boxes = torch.zeros(r, k * 7)
+    ctr = torch.rand(40, 2, generator=g) * 300                       # clustered centres -> real suppression
+    for j in range(k):
+        c = ctr[torch.randint(0, 40, (r,), generator=g)] + torch.randn(r, 2, generator=g) * 3
+        boxes[:, j * 7 + 0:j * 7 + 2] = c
+        boxes[:, j * 7 + 2] = torch.rand(r, generator=g)
+        boxes[:, j * 7 + 3:j * 7 + 6] = torch.tensor([23.6, 10.4, 1.8]) * (0.8 + 0.4 * torch.rand(r, 3, generator=g))
+        boxes[:, j * 7 + 6] = (torch.rand(r, generator=g) - 0.5) * 3.14159
+    rois = torch.zeros(r, 5)
+    _, ref = O.filter_and_draw_prep_lidar(rois, prob, boxes, k, thresh)
+    ref = [O.max_dets_cut(b, max_dets) for b in ref]
+    dets, cnt = ops.filter_per_class_lidar(boxes.to(DEV), prob.to(DEV), thresh, 0.6, max_dets)
+    cnt = cnt.cpu().numpy()
+    for j in range(1, k):
+        assert cnt[j] == len(ref[j]), (j, cnt[j], len(ref[j]))
+        got = dets[j, :cnt[j]].cpu().numpy()
+        if max_dets < 100 and len(ref[j]) >= max_dets:
+            # the cut keeps the survivors in NMS order on the device, score-filtered order in the reference: same set
+            got = got[np.lexsort(got.T[::-1])]
+            want = ref[j][np.lexsort(ref[j].T[::-1])]
+            np.testing.assert_array_equal(got, want)
+        else:
+            np.testing.assert_array_equal(got, ref[j])
+    assert cnt[0] == 0
