@@ -294,11 +294,12 @@ def test_proposal_layer_matches_oracle(hip, shape):
 # ------------------------------------------------------------------------------------------------
 # RoIAlign / detection tail / per-class filter
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c", [64, 256])
 @pytest.mark.parametrize("sampling", [0, 2])
-def test_roi_align_matches_oracle(hip, sampling):
+def test_roi_align_matches_oracle(hip, sampling, c):
     ops = _ops()
     g = torch.Generator().manual_seed(21)
-    c, h, w = 64, 38, 63
+    h, w = 38, 63
     feat = torch.randn(1, c, h, w, generator=g)
     rois = torch.cat((torch.zeros(60, 1), _rand_boxes(60, g)), 1)
     rois[0, 1:] = torch.tensor([0., 0, 999, 599])            # whole frame
