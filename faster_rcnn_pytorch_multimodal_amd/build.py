@@ -21,6 +21,7 @@ ARCH = "gfx950"
 SOURCES = {
     "common.hip": [],
     "conv_igemm.hip": [],
+    "conv_wgrad.hip": [],
     "boxes.hip": ["-ffp-contract=off"],
     "roi_align.hip": ["-ffp-contract=off"],
     "head.hip": ["-ffp-contract=off"],

@@ -52,6 +52,7 @@ struct ConvParams {
   int steps_per_split;
   int tiles_m, tiles_n;
   int relu;
+  int ys, Hy, Wy;  // output pixel (ho, wo) is written at (ho*ys, wo*ys) of an Hy x Wy map (ys = 1: dense)
 };
 
 // XCD-aware bijective remap (guide T1): blocks b and b+8 share an XCD; give each XCD a contiguous
@@ -237,6 +238,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + (wr * TM + i) * 32 + mlane;
     if (m >= p.M) continue;
+    size_t orow = (size_t)m * p.K;  // row of y / residual
+    if (p.ys != 1) {
+      const int img = m / (p.Ho * p.Wo);
+      const int rem = m - img * p.Ho * p.Wo;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      orow = ((size_t)(img * p.Hy + ho * p.ys) * p.Wy + wo * p.ys) * p.K;
+    }
 #if defined(FRCNN_ABLATE) && (FRCNN_ABLATE & 4)
     if (acc[i][0][0] != 123.456f) continue;
 #endif
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = nb + 8 * g;
-          rv[g] = (p.res && n < p.K) ? *reinterpret_cast<const f32x4*>(p.res + row + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+          rv[g] = (p.res && n < p.K) ? *reinterpret_cast<const f32x4*>(p.res + orow + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
             t += rv[g][e];
             v[e] = p.relu ? fmaxf(t, 0.f) : t;
           }
-          *reinterpret_cast<f32x4*>(p.y + row + n) = v;
+          *reinterpret_cast<f32x4*>(p.y + orow + n) = v;
         }
       } else {
         // K % 4 != 0: rows are not 16-byte aligned, element-wise accesses
@@ -284,8 +292,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
           if (n >= p.K) continue;
           if (slab) { slab[row + n] = acc[i][j][r]; continue; }
           float t = acc[i][j][r] * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
-          if (p.res) t += p.res[row + n];
-          p.y[row + n] = p.relu ? fmaxf(t, 0.f) : t;
+          if (p.res) t += p.res[orow + n];
+          p.y[orow + n] = p.relu ? fmaxf(t, 0.f) : t;
         }
       }
     }
@@ -417,26 +425,26 @@ extern "C" size_t frcnn_conv2d_fwd_ws_bytes(int n, int h, int w, int c, int k, i
   return pl.splits > 1 ? (size_t)pl.splits * M * k * sizeof(float) : 0;
 }
 
-extern "C" int frcnn_conv2d_fwd(const float* x, const float* wgt, const float* scale, const float* shift,
-                                const float* residual, float* y, int n, int h, int w, int c, int k, int r, int s,
-                                int stride, int pad, int relu, int split_k, void* ws, size_t ws_bytes,
-                                void* stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  FRCNN_REQUIRE(x && wgt && y, "conv2d_fwd: null tensor");
-  FRCNN_REQUIRE(conv_args_ok(n, h, w, c, k, r, s, stride, pad),
-                "conv2d_fwd: bad shape n=%d h=%d w=%d c=%d k=%d r=%d s=%d stride=%d pad=%d (need c%%4==0)", n, h, w, c,
-                k, r, s, stride, pad);
+namespace {
+// Shared driver of the forward entry point and of the data-gradient entry point (which is a forward
+// convolution of dy with the flipped/transposed filter).  out_stride > 1 scatters the output pixels onto
+// a (hy x wy) map at stride out_stride (the map must be zero-filled by the caller); split-K is disabled then.
+int run_conv(const float* x, const float* wgt, const float* scale, const float* shift, const float* residual,
+             float* y, int n, int h, int w, int c, int k, int r, int s, int stride, int pad, int relu, int split_k,
+             void* ws, size_t ws_bytes, hipStream_t stream, int out_stride, int hy, int wy) {
   ConvParams p;
   p.x = x; p.w = wgt; p.scale = scale; p.shift = shift; p.res = residual; p.y = y; p.partial = nullptr;
   p.H = h; p.W = w; p.C = c; p.K = k; p.R = r; p.S = s; p.stride = stride; p.pad = pad;
   p.Ho = (h + 2 * pad - r) / stride + 1;
   p.Wo = (w + 2 * pad - s) / stride + 1;
   const long M = (long)n * p.Ho * p.Wo;
-  FRCNN_REQUIRE(M * (long)k < (1L << 31) && (long)n * h * w * c < (1L << 31), "conv2d_fwd: tensor too large for int32 indexing");
+  FRCNN_REQUIRE(M * (long)k < (1L << 31) && (long)n * h * w * c < (1L << 31), "conv2d: tensor too large for int32 indexing");
   p.M = (int)M;
   p.Ktot = r * s * c;
   p.ksteps = (p.Ktot + BK - 1) / BK;
   p.relu = relu;
+  p.ys = out_stride; p.Hy = hy; p.Wy = wy;
+  if (out_stride != 1) split_k = 1;
   const Plan pl = choose_plan(p.M, k, p.ksteps, split_k);
   const TileCfg& tc = kTiles[pl.cfg];
   p.steps_per_split = pl.steps_per_split;
@@ -446,7 +454,7 @@ extern "C" int frcnn_conv2d_fwd(const float* x, const float* wgt, const float* s
   if (pl.splits > 1) {
     const size_t need = (size_t)pl.splits * M * k * sizeof(float);
     if (!ws || ws_bytes < need)
-      return frcnn::fail(FRCNN_ERR_WS, "conv2d_fwd: workspace %zu < %zu bytes", ws_bytes, need);
+      return frcnn::fail(FRCNN_ERR_WS, "conv2d: workspace %zu < %zu bytes", ws_bytes, need);
     p.partial = static_cast<float*>(ws);
   }
   const bool aligned = (c % BK) == 0;
@@ -472,6 +480,132 @@ extern "C" int frcnn_conv2d_fwd(const float* x, const float* wgt, const float* s
     return frcnn::check_launch("conv_splitk_epilogue");
   }
   return FRCNN_OK;
+}
+}  // namespace
+
+extern "C" int frcnn_conv2d_fwd(const float* x, const float* wgt, const float* scale, const float* shift,
+                                const float* residual, float* y, int n, int h, int w, int c, int k, int r, int s,
+                                int stride, int pad, int relu, int split_k, void* ws, size_t ws_bytes,
+                                void* stream_) {
+  FRCNN_REQUIRE(x && wgt && y, "conv2d_fwd: null tensor");
+  FRCNN_REQUIRE(conv_args_ok(n, h, w, c, k, r, s, stride, pad),
+                "conv2d_fwd: bad shape n=%d h=%d w=%d c=%d k=%d r=%d s=%d stride=%d pad=%d (need c%%4==0)", n, h, w, c,
+                k, r, s, stride, pad);
+  return run_conv(x, wgt, scale, shift, residual, y, n, h, w, c, k, r, s, stride, pad, relu, split_k, ws, ws_bytes,
+                  static_cast<hipStream_t>(stream_), 1, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Data gradient: dx = conv_transpose(dy, w).  For stride 1 this is a forward convolution of dy with the
+// filter flipped in (r, s) and transposed in (k, c); a strided 1x1 scatters a 1x1 convolution onto the
+// even pixels; a strided RxS first zero-inserts dy.  Replaces autograd's conv backward for the
+// trainable part of lib/nets/resnet.py / lib/nets/fpn.py (lib/model/train_val.py:458 -> loss.backward()).
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void transpose_filter_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                              int K, int R, int S, int C) {
+  const size_t total = (size_t)K * R * S * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    // i enumerates the OUTPUT [c][r'][s'][k] so that writes are coalesced
+    const int k = (int)(i % K);
+    size_t t = i / K;
+    const int s2 = (int)(t % S);
+    t /= S;
+    const int r2 = (int)(t % R);
+    const int c = (int)(t / R);
+    wt[i] = w[(((size_t)k * R + (R - 1 - r2)) * S + (S - 1 - s2)) * C + c];
+  }
+}
+
+// dyd[n, ho*stride, wo*stride, :] = dy[n, ho, wo, :], zeros elsewhere (Hd x Wd map), 16 B per thread
+__global__ __launch_bounds__(256) void dilate_kernel(const float* __restrict__ dy, float* __restrict__ dyd, int N,
+                                                    int Ho, int Wo, int K4, int stride, int Hd, int Wd) {
+  const size_t total = (size_t)N * Hd * Wd * K4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k4 = (int)(i % K4);
+    size_t t = i / K4;
+    const int wd = (int)(t % Wd);
+    t /= Wd;
+    const int hd = (int)(t % Hd);
+    const int n = (int)(t / Hd);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (hd % stride == 0 && wd % stride == 0 && hd / stride < Ho && wd / stride < Wo)
+      v = reinterpret_cast<const f32x4*>(dy)[(((size_t)n * Ho + hd / stride) * Wo + wd / stride) * K4 + k4];
+    reinterpret_cast<f32x4*>(dyd)[i] = v;
+  }
+}
+
+struct DgradGeom {
+  int ho, wo, hd, wd, pad_t;
+  bool dilate;
+};
+DgradGeom dgrad_geom(int h, int w, int r, int s, int stride, int pad) {
+  DgradGeom g;
+  g.ho = (h + 2 * pad - r) / stride + 1;
+  g.wo = (w + 2 * pad - s) / stride + 1;
+  g.pad_t = r - 1 - pad;
+  g.dilate = stride > 1 && (r > 1 || s > 1);
+  // zero-inserted map, extended by the rows/cols the strided forward pass never reached
+  g.hd = (g.ho - 1) * stride + 1 + (h + 2 * pad - r) % stride;
+  g.wd = (g.wo - 1) * stride + 1 + (w + 2 * pad - s) % stride;
+  return g;
+}
+bool dgrad_args_ok(int n, int h, int w, int c, int k, int r, int s, int stride, int pad) {
+  return conv_args_ok(n, h, w, c, k, r, s, stride, pad) && (k % 4) == 0 && r == s && r - 1 - pad >= 0;
+}
+}  // namespace
+
+extern "C" int frcnn_conv2d_transpose_filter(const float* w_krsc, float* w_crsk_flipped, int k, int r, int s, int c,
+                                             void* stream_) {
+  FRCNN_REQUIRE(w_krsc && w_crsk_flipped && k > 0 && r > 0 && s > 0 && c > 0, "conv2d_transpose_filter: bad arguments");
+  const size_t total = (size_t)k * r * s * c;
+  hipLaunchKernelGGL(transpose_filter_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), w_krsc, w_crsk_flipped, k, r, s, c);
+  return frcnn::check_launch("transpose_filter_kernel");
+}
+
+extern "C" size_t frcnn_conv2d_bwd_data_ws_bytes(int n, int h, int w, int c, int k, int r, int s, int stride,
+                                                 int pad) {
+  if (!dgrad_args_ok(n, h, w, c, k, r, s, stride, pad)) return 0;
+  const DgradGeom g = dgrad_geom(h, w, r, s, stride, pad);
+  if (stride > 1 && !g.dilate) return 0;  // strided 1x1: scattered output, no split-K
+  if (!g.dilate) return frcnn_conv2d_fwd_ws_bytes(n, g.ho, g.wo, k, c, r, s, 1, g.pad_t, 0);
+  const size_t dil = frcnn::align_up((size_t)n * g.hd * g.wd * k * sizeof(float), 256);
+  return dil + frcnn_conv2d_fwd_ws_bytes(n, g.hd, g.wd, k, c, r, s, 1, g.pad_t, 0);
+}
+
+extern "C" int frcnn_conv2d_bwd_data(const float* dy, const float* w_crsk_flipped, const float* add, float* dx, int n,
+                                     int h, int w, int c, int k, int r, int s, int stride, int pad, void* ws,
+                                     size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FRCNN_REQUIRE(dy && w_crsk_flipped && dx, "conv2d_bwd_data: null tensor");
+  FRCNN_REQUIRE(dgrad_args_ok(n, h, w, c, k, r, s, stride, pad),
+                "conv2d_bwd_data: bad shape n=%d h=%d w=%d c=%d k=%d r=%d s=%d stride=%d pad=%d (need c%%4==0, k%%4==0, "
+                "r==s, pad<=r-1)", n, h, w, c, k, r, s, stride, pad);
+  const DgradGeom g = dgrad_geom(h, w, r, s, stride, pad);
+  const size_t need = frcnn_conv2d_bwd_data_ws_bytes(n, h, w, c, k, r, s, stride, pad);
+  if (need > 0 && (!ws || ws_bytes < need))
+    return frcnn::fail(FRCNN_ERR_WS, "conv2d_bwd_data: workspace %zu < %zu bytes", ws_bytes, need);
+  if (stride == 1)  // dx (n,h,w,c) = conv(dy (n,ho,wo,k), w^T flipped), same-size output
+    return run_conv(dy, w_crsk_flipped, nullptr, nullptr, add, dx, n, g.ho, g.wo, k, c, r, s, 1, g.pad_t, 0, 0, ws,
+                    ws_bytes, stream, 1, 0, 0);
+  if (!g.dilate) {
+    // strided 1x1: only pixels (ho*stride, wo*stride) receive a gradient; the rest is `add` (or zero)
+    const size_t bytes = (size_t)n * h * w * c * sizeof(float);
+    hipError_t e = add ? hipMemcpyAsync(dx, add, bytes, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dx, 0, bytes, stream);
+    if (e != hipSuccess) return frcnn::fail(FRCNN_ERR_LAUNCH, "conv2d_bwd_data: init dx: %s", hipGetErrorString(e));
+    return run_conv(dy, w_crsk_flipped, nullptr, nullptr, add, dx, n, g.ho, g.wo, k, c, 1, 1, 1, 0, 0, 1, nullptr, 0,
+                    stream, stride, h, w);
+  }
+  float* dyd = static_cast<float*>(ws);
+  const size_t dil = frcnn::align_up((size_t)n * g.hd * g.wd * k * sizeof(float), 256);
+  const size_t total = (size_t)n * g.hd * g.wd * (k / 4);
+  hipLaunchKernelGGL(dilate_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, stream, dy,
+                     dyd, n, g.ho, g.wo, k / 4, stride, g.hd, g.wd);
+  int rc = frcnn::check_launch("dilate_kernel");
+  if (rc != FRCNN_OK) return rc;
+  return run_conv(dyd, w_crsk_flipped, nullptr, nullptr, add, dx, n, g.hd, g.wd, k, c, r, s, 1, g.pad_t, 0, 0,
+                  static_cast<char*>(ws) + dil, ws_bytes - dil, stream, 1, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,256 @@
+// Filter gradient of the convolution on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32):
+//
+//     dw[k][r][s][c] = sum over output pixels m = (n, ho, wo) of  dy[m][k] * x[n, ho*stride-pad+r, wo*stride-pad+s, c]
+//
+// Replaces autograd's conv weight gradient for the trainable convolutions of lib/nets/resnet.py:98-127,
+// lib/nets/fpn.py:33-39 and the RPN / tail layers (lib/model/train_val.py:458 -> loss.backward()).
+//
+// GEMM view: rows = k (output channels), columns = q = (r*S+s)*C + c, reduction over the M pixels.
+// Both operands are contiguous along their ROW/COLUMN index and strided along the reduction index (the
+// opposite of the forward kernel), so tiles are staged as [32 pixels][128 k] and [32 pixels][128 q] with
+// 16-byte chunks along k / q and the MFMA fragments are ds_read_b32 with the lanes running along k / q
+// (32 consecutive floats per half wave: conflict-free without padding).  A thread's q chunk — hence its
+// filter tap (r, s) and channel c — is fixed for the whole kernel; only the pixel advances.
+// The pixel range is split over gridDim.z; partial sums go to slabs that a second kernel adds in z order,
+// so the result is deterministic.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BR = 32;    // pixels per reduction step
+constexpr int BT = 128;   // tile edge (k rows x q columns)
+constexpr int NUM_CU = 256;
+
+struct WgradParams {
+  const float* x;
+  const float* dy;
+  float* out;  // dw [K][RSC] (splits == 1) or slabs [splits][K][RSC]
+  int H, W, C, K, R, S, stride, pad, Ho, Wo;
+  int M, Q;  // pixels, R*S*C
+  int steps, steps_per_split;
+  int tiles_k, tiles_q;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const WgradParams p) {
+  __shared__ __attribute__((aligned(16))) float As[2][BR][BT];  // dy tile   [pixel][k]
+  __shared__ __attribute__((aligned(16))) float Bs[2][BR][BT];  // x tile    [pixel][q]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tile_k = blockIdx.x / p.tiles_q, tile_q = blockIdx.x - tile_k * p.tiles_q;
+  const int k0 = tile_k * BT, q0 = tile_q * BT;
+  const int step_begin = blockIdx.z * p.steps_per_split;
+  const int step_end = min(step_begin + p.steps_per_split, p.steps);
+
+  // staging: thread t moves 16-byte chunk (t & 31) of pixel rows (t >> 5) + 8*i, i < 4
+  const int ch = t & 31, prow = t >> 5;
+  const int ka = k0 + ch * 4;            // first of this thread's 4 output channels
+  const bool ka_ok = ka < p.K;           // K % 4 == 0: a chunk is all in or all out
+  const int qb = q0 + ch * 4;            // first of this thread's 4 filter elements
+  const bool qb_ok = qb < p.Q;
+  const int tap = qb_ok ? qb / p.C : 0;
+  const int cb = qb - tap * p.C;
+  const int tr = tap / p.S, ts = tap - tr * p.S;
+
+  f32x4 ra[4], rb[4];
+  auto load_tiles = [&](int step) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = step * BR + prow + 8 * i;
+      const bool m_ok = m < p.M;
+      ra[i] = (m_ok && ka_ok) ? *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.K + ka) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m_ok && qb_ok) {
+        const int img = m / (p.Ho * p.Wo);
+        const int rem = m - img * p.Ho * p.Wo;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        const int hi = ho * p.stride - p.pad + tr, wi = wo * p.stride - p.pad + ts;
+        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+          v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(img * p.H + hi) * p.W + wi) * p.C + cb);
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<f32x4*>(&As[buf][prow + 8 * i][ch * 4]) = ra[i];
+      *reinterpret_cast<f32x4*>(&Bs[buf][prow + 8 * i][ch * 4]) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  if (step_begin < step_end) {
+    load_tiles(step_begin);
+    store_tiles(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int step = step_begin; step < step_end; ++step) {
+    const bool more = step + 1 < step_end;
+    if (more) load_tiles(step + 1);
+#pragma unroll
+    for (int kk = 0; kk < BR / 2; ++kk) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[cur][2 * kk + lh][(wr * 2 + i) * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[cur][2 * kk + lh][(wc * 2 + j) * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tiles(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // D: column (lane & 31) = q, row (r&3) + 8*(r>>2) + 4*(lane>>5) = k
+  float* out = p.out + (size_t)blockIdx.z * p.K * p.Q;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = q0 + (wc * 2 + j) * 32 + l31;
+    if (q >= p.Q) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = k0 + (wr * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (k < p.K) out[(size_t)k * p.Q + q] = acc[i][j][r];
+      }
+  }
+}
+
+// dw = sum_z slab[z] (z order), 16 bytes per thread
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, size_t n4,
+                                                          float* __restrict__ dw) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 v = reinterpret_cast<const f32x4*>(slabs)[i];
+    for (int z = 1; z < splits; ++z) {
+      const f32x4 u = reinterpret_cast<const f32x4*>(slabs)[(size_t)z * n4 + i];
+      v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+    }
+    reinterpret_cast<f32x4*>(dw)[i] = v;
+  }
+}
+
+// db[k] = sum_m dy[m][k] in two deterministic passes: BIAS_GROUPS x (K/64) workgroups sum interleaved pixel
+// subsets (4 waves each) into partial[g][k], then one pass adds the groups in g order.
+constexpr int BIAS_GROUPS = 64;
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __restrict__ dy, int M, int K,
+                                                               float* __restrict__ partial) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (k < K)
+    for (int m = blockIdx.y * 4 + wave; m < M; m += 4 * BIAS_GROUPS) s += dy[(size_t)m * K + k];
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && k < K)
+    partial[(size_t)blockIdx.y * K + k] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+}
+__global__ __launch_bounds__(256) void bias_grad_final_kernel(const float* __restrict__ partial, int K,
+                                                             float* __restrict__ db) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  float s = partial[k];
+  for (int g = 1; g < BIAS_GROUPS; ++g) s += partial[(size_t)g * K + k];
+  db[k] = s;
+}
+
+int choose_splits(int tiles, int steps) {
+  int best = 1;
+  double best_t = 1e300;
+  for (int sp = 1; sp <= 64; ++sp) {
+    const int sps = (steps + sp - 1) / sp;
+    const int real = (steps + sps - 1) / sps;
+    if (real != sp) continue;
+    const long rounds = ((long)tiles * real + 2 * NUM_CU - 1) / (2 * NUM_CU);  // two workgroups per CU
+    const double tcyc = rounds * (sps * 2.0 * 4096.0 + 6000.0) + (real > 1 ? real * 300.0 : 0.0);
+    if (tcyc < best_t) {
+      best_t = tcyc;
+      best = real;
+    }
+  }
+  return best;
+}
+
+bool wgrad_args_ok(int n, int h, int w, int c, int k, int r, int s, int stride, int pad) {
+  return n > 0 && h > 0 && w > 0 && c > 0 && (c % 4) == 0 && k > 0 && (k % 4) == 0 && r > 0 && s > 0 && stride > 0 &&
+         pad >= 0 && (h + 2 * pad - r) >= 0 && (w + 2 * pad - s) >= 0;
+}
+
+}  // namespace
+
+extern "C" size_t frcnn_conv2d_bwd_weight_ws_bytes(int n, int h, int w, int c, int k, int r, int s, int stride,
+                                                   int pad) {
+  if (!wgrad_args_ok(n, h, w, c, k, r, s, stride, pad)) return 0;
+  const int ho = (h + 2 * pad - r) / stride + 1, wo = (w + 2 * pad - s) / stride + 1;
+  const long M = (long)n * ho * wo;
+  const int q = r * s * c;
+  const int tiles = ((k + BT - 1) / BT) * ((q + BT - 1) / BT);
+  const int splits = choose_splits(tiles, (int)((M + BR - 1) / BR));
+  // slabs (when the pixel range is split) + the bias-gradient partials
+  return (splits > 1 ? (size_t)splits * k * q * sizeof(float) : 0) + (size_t)BIAS_GROUPS * k * sizeof(float);
+}
+
+extern "C" int frcnn_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, int n, int h, int w,
+                                       int c, int k, int r, int s, int stride, int pad, void* ws, size_t ws_bytes,
+                                       void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FRCNN_REQUIRE(x && dy && dw, "conv2d_bwd_weight: null tensor");
+  FRCNN_REQUIRE(wgrad_args_ok(n, h, w, c, k, r, s, stride, pad),
+                "conv2d_bwd_weight: bad shape n=%d h=%d w=%d c=%d k=%d r=%d s=%d stride=%d pad=%d (need c%%4==0, k%%4==0)",
+                n, h, w, c, k, r, s, stride, pad);
+  WgradParams p;
+  p.x = x; p.dy = dy;
+  p.H = h; p.W = w; p.C = c; p.K = k; p.R = r; p.S = s; p.stride = stride; p.pad = pad;
+  p.Ho = (h + 2 * pad - r) / stride + 1;
+  p.Wo = (w + 2 * pad - s) / stride + 1;
+  const long M = (long)n * p.Ho * p.Wo;
+  FRCNN_REQUIRE(M * (long)k < (1L << 31) && (long)n * h * w * c < (1L << 31), "conv2d_bwd_weight: tensor too large");
+  p.M = (int)M;
+  p.Q = r * s * c;
+  p.steps = (p.M + BR - 1) / BR;
+  p.tiles_k = (k + BT - 1) / BT;
+  p.tiles_q = (p.Q + BT - 1) / BT;
+  const int splits = choose_splits(p.tiles_k * p.tiles_q, p.steps);
+  p.steps_per_split = (p.steps + splits - 1) / splits;
+  const size_t slab_bytes = splits > 1 ? (size_t)splits * k * p.Q * sizeof(float) : 0;
+  const size_t need = slab_bytes + (db ? (size_t)BIAS_GROUPS * k * sizeof(float) : 0);
+  if (need > 0 && (!ws || ws_bytes < need))
+    return frcnn::fail(FRCNN_ERR_WS, "conv2d_bwd_weight: workspace %zu < %zu bytes", ws_bytes, need);
+  p.out = splits > 1 ? static_cast<float*>(ws) : dw;
+  hipLaunchKernelGGL(conv_wgrad_f32, dim3(p.tiles_k * p.tiles_q, 1, splits), dim3(256), 0, stream, p);
+  int rc = frcnn::check_launch("conv_wgrad_f32");
+  if (rc != FRCNN_OK) return rc;
+  if (splits > 1) {
+    const size_t n4 = (size_t)k * p.Q / 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0,
+                       stream, static_cast<const float*>(ws), splits, n4, dw);
+    rc = frcnn::check_launch("wgrad_reduce_kernel");
+    if (rc != FRCNN_OK) return rc;
+  }
+  if (db) {
+    float* partial = reinterpret_cast<float*>(static_cast<char*>(ws) + slab_bytes);
+    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((k + 63) / 64, BIAS_GROUPS), dim3(256), 0, stream, dy, p.M, k,
+                       partial);
+    rc = frcnn::check_launch("bias_grad_partial_kernel");
+    if (rc != FRCNN_OK) return rc;
+    hipLaunchKernelGGL(bias_grad_final_kernel, dim3((k + 255) / 256), dim3(256), 0, stream, partial, k, db);
+    rc = frcnn::check_launch("bias_grad_final_kernel");
+  }
+  return rc;
+}

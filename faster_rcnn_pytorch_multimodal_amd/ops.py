@@ -81,6 +81,56 @@ def conv2d_nhwc(x, w_krsc, scale=None, shift=None, residual=None, stride=1, pad=
     return out
 
 
+def conv2d_transpose_filter(w_krsc):
+    """(K,R,S,C) -> (C,R,S,K) with flipped taps: the filter of the data-gradient convolution."""
+    lib = _hip.load()
+    _dev_f32(w_krsc, "w")
+    k, r, s, c = w_krsc.shape
+    out = torch.empty((c, r, s, k), dtype=torch.float32, device=w_krsc.device)
+    _hip.check(lib.frcnn_conv2d_transpose_filter(_ptr(w_krsc), _ptr(out), k, r, s, c, _stream()),
+               "frcnn_conv2d_transpose_filter")
+    return out
+
+
+def conv2d_bwd_data(dy, w_t, x_shape, stride=1, pad=0, add=None):
+    """dx (n,h,w,c) = conv_transpose(dy, w) [+ add].  w_t = conv2d_transpose_filter(w); x_shape = forward input shape."""
+    lib = _hip.load()
+    _dev_f32(dy, "dy"); _dev_f32(w_t, "w_t")
+    n, h, w, c = x_shape
+    c2, r, s, k = w_t.shape
+    if c2 != c or dy.shape[-1] != k:
+        raise _hip.HipError("conv2d_bwd_data: filter (C=%d,K=%d) does not match x C=%d / dy K=%d" % (c2, k, c, dy.shape[-1]))
+    if tuple(dy.shape[:3]) != (n,) + conv_out_hw(h, w, r, s, stride, pad):
+        raise _hip.HipError("conv2d_bwd_data: dy shape %s does not match the forward output" % (tuple(dy.shape),))
+    if add is not None:
+        _dev_f32(add, "add")
+        if tuple(add.shape) != tuple(x_shape):
+            raise _hip.HipError("conv2d_bwd_data: add shape %s != x shape %s" % (tuple(add.shape), tuple(x_shape)))
+    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    ws_bytes = lib.frcnn_conv2d_bwd_data_ws_bytes(n, h, w, c, k, r, s, stride, pad)
+    ws = _workspace(ws_bytes, dy.device) if ws_bytes else None
+    _hip.check(lib.frcnn_conv2d_bwd_data(_ptr(dy), _ptr(w_t), _ptr(add), _ptr(dx), n, h, w, c, k, r, s, stride, pad,
+                                         _ptr(ws), ws_bytes, _stream()), "frcnn_conv2d_bwd_data")
+    return dx
+
+
+def conv2d_bwd_weight(x, dy, r, s, stride=1, pad=0, want_bias=False):
+    """Returns (dw (K,R,S,C), db (K,) or None)."""
+    lib = _hip.load()
+    _dev_f32(x, "x"); _dev_f32(dy, "dy")
+    n, h, w, c = x.shape
+    k = dy.shape[-1]
+    if tuple(dy.shape[:3]) != (n,) + conv_out_hw(h, w, r, s, stride, pad):
+        raise _hip.HipError("conv2d_bwd_weight: dy shape %s does not match the forward output" % (tuple(dy.shape),))
+    dw = torch.empty((k, r, s, c), dtype=torch.float32, device=x.device)
+    db = torch.empty((k,), dtype=torch.float32, device=x.device) if want_bias else None
+    ws_bytes = lib.frcnn_conv2d_bwd_weight_ws_bytes(n, h, w, c, k, r, s, stride, pad)
+    ws = _workspace(ws_bytes, x.device) if ws_bytes else None
+    _hip.check(lib.frcnn_conv2d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), n, h, w, c, k, r, s, stride, pad,
+                                           _ptr(ws), ws_bytes, _stream()), "frcnn_conv2d_bwd_weight")
+    return dw, db
+
+
 def maxpool3x3s2_nhwc(x):
     lib = _hip.load()
     _dev_f32(x, "x")

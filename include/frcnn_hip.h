@@ -48,6 +48,27 @@ int frcnn_conv2d_fwd(const float* x, const float* wgt, const float* scale, const
                      const float* residual, float* y, int n, int h, int w, int c, int k, int r, int s,
                      int stride, int pad, int relu, int split_k, void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Convolution backward (autograd of the same nn.Conv2d call sites; lib/model/train_val.py:458 train_step ->
+ * loss.backward()).  Gradients w.r.t. the folded-BN scale/shift are not produced: BatchNorm is frozen on
+ * this path (lib/nets/imagenet.py:110-116).
+ *
+ * frcnn_conv2d_transpose_filter: w (K,R,S,C) -> w_t (C,R,S,K) with the taps flipped, the filter of the
+ *   data-gradient convolution (prepare once per weight version).
+ * frcnn_conv2d_bwd_data: dx (n,h,w,c) = conv_transpose(dy (n,ho,wo,k), w) [+ add (n,h,w,c), may be NULL].
+ *   n,h,w,c,k,r,s,stride,pad describe the FORWARD convolution.  Needs k % 4 == 0, r == s, pad <= r-1.
+ * frcnn_conv2d_bwd_weight: dw (K,R,S,C) = sum_pixels dy x patch(x); db (K) = sum_pixels dy (db may be NULL).
+ * ------------------------------------------------------------------------------------------- */
+int frcnn_conv2d_transpose_filter(const float* w_krsc, float* w_crsk_flipped, int k, int r, int s, int c,
+                                  void* stream);
+size_t frcnn_conv2d_bwd_data_ws_bytes(int n, int h, int w, int c, int k, int r, int s, int stride, int pad);
+int frcnn_conv2d_bwd_data(const float* dy, const float* w_crsk_flipped, const float* add, float* dx, int n, int h,
+                          int w, int c, int k, int r, int s, int stride, int pad, void* ws, size_t ws_bytes,
+                          void* stream);
+size_t frcnn_conv2d_bwd_weight_ws_bytes(int n, int h, int w, int c, int k, int r, int s, int stride, int pad);
+int frcnn_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, int n, int h, int w, int c, int k,
+                            int r, int s, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+
 /* Tuning / test hook: force the workgroup tile to (64*tm) x (64*tn) output pixels x channels for all
  * following frcnn_conv2d_fwd calls of this process; (tm,tn) in {(4,2),(2,4)} (8 waves, one workgroup per
  * CU), {(2,2),(2,1),(1,2),(1,1)} (4 waves); (0,0) restores the automatic choice. */

@@ -627,3 +627,53 @@ def test_filter_per_class_lidar_matches_oracle(hip, thresh, max_dets):
         else:
             np.testing.assert_array_equal(got, ref[j])
     assert cnt[0] == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution backward (training path, BASELINE config 4): against torch-CPU autograd in float64
+# ------------------------------------------------------------------------------------------------
+CONV_BWD_CASES = [
+    # n, h, w, c, k, r, stride, pad
+    (1, 19, 23, 64, 256, 1, 1, 0),      # 1x1
+    (1, 20, 26, 256, 128, 1, 2, 0),     # strided 1x1 (caffe placement): scattered data gradient
+    (1, 21, 27, 128, 64, 1, 2, 0),      # strided 1x1, odd input size
+    (1, 17, 21, 128, 128, 3, 1, 1),     # 3x3
+    (2, 14, 14, 32, 48, 3, 2, 1),       # strided 3x3 (FPN layer4[0].conv2), even size: remainder row/col
+    (1, 19, 33, 64, 32, 3, 2, 1),       # strided 3x3, odd size
+    (1, 12, 15, 512, 152, 1, 1, 0),     # fused RPN head padded to 152 outputs
+    (7, 7, 7, 96, 160, 3, 1, 1),        # RoI batch
+    (37, 1, 1, 1024, 64, 1, 1, 0),      # Linear layer as a 1x1 convolution over 37 "pixels"
+    (1, 40, 60, 256, 256, 3, 1, 1),     # long pixel reduction -> split slabs in the weight gradient
+]
+
+
+@pytest.mark.parametrize("case", CONV_BWD_CASES)
+def test_conv2d_backward_matches_autograd(hip, case):
+    ops = _ops()
+    n, h, w, c, k, r, stride, pad = case
+    g = torch.Generator().manual_seed(hash(case) % 2 ** 31)
+    x = torch.randn(n, h, w, c, generator=g)
+    wt = torch.randn(k, c, r, r, generator=g) / np.sqrt(c * r * r)
+    ho, wo = ops.conv_out_hw(h, w, r, r, stride, pad)
+    dy = torch.randn(n, ho, wo, k, generator=g)
+    add = torch.randn(n, h, w, c, generator=g)
+    xd = x.permute(0, 3, 1, 2).double().requires_grad_(True)
+    wd = wt.double().requires_grad_(True)
+    bd = torch.zeros(k, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(xd, wd, bd, stride=stride, padding=pad)
+    y.backward(dy.permute(0, 3, 1, 2).double())
+    dx_ref = xd.grad.permute(0, 2, 3, 1).float()
+    dw_ref = wd.grad.permute(0, 2, 3, 1).float()       # KRSC
+    db_ref = bd.grad.float()
+    w_krsc = wt.permute(0, 2, 3, 1).contiguous().to(DEV)
+    w_t = ops.conv2d_transpose_filter(w_krsc)
+    np.testing.assert_array_equal(w_t.cpu().numpy(), wt.flip(2, 3).permute(1, 2, 3, 0).contiguous().numpy())
+    dx = ops.conv2d_bwd_data(dy.to(DEV), w_t, (n, h, w, c), stride=stride, pad=pad)
+    _close_feat(dx.cpu().numpy(), dx_ref.numpy(), "dgrad %s" % (case,), frac=1e-5)
+    dx2 = ops.conv2d_bwd_data(dy.to(DEV), w_t, (n, h, w, c), stride=stride, pad=pad, add=add.to(DEV))
+    _close_feat(dx2.cpu().numpy(), (dx_ref + add).numpy(), "dgrad+add %s" % (case,), frac=1e-5)
+    dw, db = ops.conv2d_bwd_weight(x.to(DEV), dy.to(DEV), r, r, stride=stride, pad=pad, want_bias=True)
+    _close_feat(dw.cpu().numpy(), dw_ref.numpy(), "wgrad %s" % (case,), frac=2e-5)
+    _close_feat(db.cpu().numpy(), db_ref.numpy(), "bias grad %s" % (case,), frac=2e-5)
+    dw2, _ = ops.conv2d_bwd_weight(x.to(DEV), dy.to(DEV), r, r, stride=stride, pad=pad)
+    assert torch.equal(dw, dw2)                                   # deterministic
