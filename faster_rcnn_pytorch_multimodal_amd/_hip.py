@@ -47,6 +47,13 @@ PROTOTYPES = {
     "frcnn_generate_anchors_3d": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "frcnn_filter_per_class_lidar": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, c_int, c_int, _P, _P, _P,
                                              c_size_t, _P]),
+    "frcnn_act_bwd": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, _P]),
+    "frcnn_upsample_bilinear_add_fwd": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P]),
+    "frcnn_upsample_bilinear_bwd": (c_int, [_P, _P] + [c_int] * 6 + [_P]),
+    "frcnn_roi_align_bwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_float, c_int, _P, c_int, _P, _P]),
+    "frcnn_rpn_loss_ws_bytes": (c_size_t, []),
+    "frcnn_rpn_loss": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, c_size_t, _P]),
+    "frcnn_det_loss": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_float, c_float, _P, _P, _P, _P]),
     "frcnn_filter_per_class_ws_bytes": (c_size_t, [c_int, c_int]),
     "frcnn_filter_per_class": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int,
                                        c_int, _P, _P, _P, c_size_t, _P]),

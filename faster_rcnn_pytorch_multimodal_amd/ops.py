@@ -382,3 +382,94 @@ def filter_per_class(pred_boxes, cls_prob, frame_w, frame_h, scale, thresh, nms_
                                           int(max_out), _ptr(dets), _ptr(det_count), _ptr(ws), ws_bytes, _stream()),
                "frcnn_filter_per_class")
     return dets, det_count
+
+
+# ----------------------------------------------------------------------------------------------
+# training path
+# ----------------------------------------------------------------------------------------------
+def act_bwd(dy, y=None, scale=None, relu=False, want_res=False):
+    """Backward of act(conv*scale + shift + res): returns (d_conv, d_res or None)."""
+    lib = _hip.load()
+    _dev_f32(dy, "dy")
+    k = dy.shape[-1]
+    rows = dy.numel() // k
+    if relu:
+        _dev_f32(y, "y")
+    d_conv = torch.empty_like(dy)
+    d_res = torch.empty_like(dy) if want_res else None
+    _hip.check(lib.frcnn_act_bwd(_ptr(dy), _ptr(y) if relu else None, _ptr(scale), int(bool(relu)), rows, k, _ptr(d_conv),
+                                 _ptr(d_res), _stream()), "frcnn_act_bwd")
+    return d_conv, d_res
+
+
+def upsample_bilinear_add(x, lateral):
+    """F.interpolate(x, size=lateral.shape[1:3], mode='bilinear', align_corners=False) + lateral, NHWC."""
+    lib = _hip.load()
+    _dev_f32(x, "x"); _dev_f32(lateral, "lateral")
+    n, h, w, c = x.shape
+    n2, oh, ow, c2 = lateral.shape
+    if n2 != n or c2 != c:
+        raise _hip.HipError("upsample_bilinear_add: %s vs %s" % (tuple(x.shape), tuple(lateral.shape)))
+    out = torch.empty_like(lateral)
+    _hip.check(lib.frcnn_upsample_bilinear_add_fwd(_ptr(x), _ptr(lateral), _ptr(out), n, h, w, oh, ow, c, _stream()),
+               "frcnn_upsample_bilinear_add_fwd")
+    return out
+
+
+def upsample_bilinear_bwd(dout, in_hw):
+    lib = _hip.load()
+    _dev_f32(dout, "dout")
+    n, oh, ow, c = dout.shape
+    h, w = in_hw
+    dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dout.device)
+    _hip.check(lib.frcnn_upsample_bilinear_bwd(_ptr(dout), _ptr(dx), n, h, w, oh, ow, c, _stream()),
+               "frcnn_upsample_bilinear_bwd")
+    return dx
+
+
+def roi_align_bwd(dout, feat_shape, rois, spatial_scale, sampling_ratio=0, roi_count=None, level_of_roi=None, level=-1,
+                  dfeat=None):
+    """Scatter dout (R,P,P,C) into dfeat (1,H,W,C) (created zero-filled unless given, then accumulated into)."""
+    lib = _hip.load()
+    _dev_f32(dout, "dout"); _dev_f32(rois, "rois")
+    _, h, w, c = feat_shape
+    r, p = dout.shape[0], dout.shape[1]
+    if dfeat is None:
+        dfeat = torch.zeros(tuple(feat_shape), dtype=torch.float32, device=dout.device)
+    _hip.check(lib.frcnn_roi_align_bwd(_ptr(dout), h, w, c, _ptr(rois), _ptr(roi_count), r, p, float(spatial_scale),
+                                       int(sampling_ratio), _ptr(level_of_roi), int(level), _ptr(dfeat), _stream()),
+               "frcnn_roi_align_bwd")
+    return dfeat
+
+
+def rpn_loss(rpn, num_anchors, labels, targets, inside, outside, grad_ce=1.0, grad_box=1.0, want_grad=True):
+    """rpn (HW, ld) fused head output.  Returns (losses (3,) [ce, box, count], drpn or None)."""
+    lib = _hip.load()
+    for nm, t in (("rpn", rpn), ("labels", labels), ("targets", targets), ("inside", inside), ("outside", outside)):
+        _dev_f32(t, nm)
+    hw, ld = rpn.shape
+    losses = torch.empty((3,), dtype=torch.float32, device=rpn.device)
+    drpn = torch.empty_like(rpn) if want_grad else None
+    ws_bytes = lib.frcnn_rpn_loss_ws_bytes()
+    ws = _workspace(ws_bytes, rpn.device)
+    _hip.check(lib.frcnn_rpn_loss(_ptr(rpn), ld, num_anchors, hw, _ptr(labels), _ptr(targets), _ptr(inside), _ptr(outside),
+                                  float(grad_ce), float(grad_box), _ptr(losses), _ptr(drpn), _ptr(ws), ws_bytes, _stream()),
+               "frcnn_rpn_loss")
+    return losses, drpn
+
+
+def det_loss(cls_score, labels, bbox_pred, targets, inside, outside, bbox_elem=4, grad_ce=1.0, grad_box=1.0,
+             want_grad=True):
+    """Returns (losses (2,) [ce, box], dcls, dbox)."""
+    lib = _hip.load()
+    for nm, t in (("cls_score", cls_score), ("labels", labels), ("bbox_pred", bbox_pred), ("targets", targets),
+                  ("inside", inside), ("outside", outside)):
+        _dev_f32(t, nm)
+    r, k = cls_score.shape
+    losses = torch.empty((2,), dtype=torch.float32, device=cls_score.device)
+    dcls = torch.empty_like(cls_score) if want_grad else None
+    dbox = torch.empty_like(bbox_pred) if want_grad else None
+    _hip.check(lib.frcnn_det_loss(_ptr(cls_score), _ptr(labels), r, k, _ptr(bbox_pred), _ptr(targets), _ptr(inside),
+                                  _ptr(outside), int(bbox_elem), float(grad_ce), float(grad_box), _ptr(losses), _ptr(dcls),
+                                  _ptr(dbox), _stream()), "frcnn_det_loss")
+    return losses, dcls, dbox

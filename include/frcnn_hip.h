@@ -194,6 +194,47 @@ int frcnn_filter_per_class(float* pred_boxes, const float* cls_prob, const int* 
                            float nms_thresh, int max_dets, int max_out, float* dets, int* det_count,
                            void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training path (BASELINE config 4: FPN forward + backward of one train_step, lib/model/train_val.py:458)
+ * ------------------------------------------------------------------------------------------- */
+/* Backward of act(conv*scale + shift + residual): dz = relu ? (y > 0 ? dy : 0) : dy; d_res = dz (may be NULL);
+ * d_conv = dz * scale[k] (scale may be NULL).  rows x k fp32, k % 4 == 0.  (F.relu / frozen BatchNorm / the
+ * residual add of lib/nets/resnet.py:98-127.) */
+int frcnn_act_bwd(const float* dy, const float* y, const float* scale, int relu, int64_t rows, int k,
+                  float* d_conv, float* d_res, void* stream);
+
+/* fpn._upsample_add (lib/nets/fpn.py:42-45): out (n,out_h,out_w,c) = F.interpolate(x (n,h,w,c), size=(out_h,out_w),
+ * mode='bilinear', align_corners=False) + lateral.  Backward: dx = interpolate^T(dout) (deterministic gather);
+ * the gradient of `lateral` is dout itself. */
+int frcnn_upsample_bilinear_add_fwd(const float* x, const float* lateral, float* out, int n, int h, int w,
+                                    int out_h, int out_w, int c, void* stream);
+int frcnn_upsample_bilinear_bwd(const float* dout, float* dx, int n, int h, int w, int out_h, int out_w, int c,
+                                void* stream);
+
+/* Backward of frcnn_roi_align_fwd: dfeat (1,H,W,C) += scatter(dout (R,P,P,C)); dfeat must be zero-filled by the
+ * caller (float atomics: the only non-deterministic kernel of the library). */
+int frcnn_roi_align_bwd(const float* dout, int h, int w, int c, const float* rois, const int* roi_count,
+                        int num_rois, int pooled, float spatial_scale, int sampling_ratio, const int* level_of_roi,
+                        int level, float* dfeat, void* stream);
+
+/* RPN losses on the fused head output rpn (hw, ld) = [A bg | A fg | 4A deltas | pad]:
+ *   losses[0] = F.cross_entropy over anchors with labels != -1 (mean), losses[1] = smooth_l1_loss('RPN', ...,
+ *   dim=[1,2,3]) (lib/utils/loss_utils.py:39-101), losses[2] = number of labelled anchors.
+ * labels (hw*A) in (H,W,A) order with values -1/0/1; targets/inside/outside (hw*A, 4).
+ * drpn (hw, ld), may be NULL: gradient of grad_ce*losses[0] + grad_box*losses[1]. */
+size_t frcnn_rpn_loss_ws_bytes(void);
+int frcnn_rpn_loss(const float* rpn, int ld, int num_anchors, int hw, const float* labels, const float* targets,
+                   const float* inside, const float* outside, float grad_ce, float grad_box, float* losses,
+                   float* drpn, void* ws, size_t ws_bytes, void* stream);
+
+/* Detection losses on the sampled RoIs: losses[0] = F.cross_entropy(cls_score (R,K), labels (R) as floats),
+ * losses[1] = smooth_l1_loss('DET', bbox_pred (R,E*K), targets, inside, outside) (image boxes);
+ * dcls / dbox (may be NULL): gradients of grad_ce*losses[0] + grad_box*losses[1]. */
+int frcnn_det_loss(const float* cls_score, const float* labels, int num_rois, int num_classes,
+                   const float* bbox_pred, const float* targets, const float* inside, const float* outside,
+                   int bbox_elem, float grad_ce, float grad_box, float* losses, float* dcls, float* dbox,
+                   void* stream);
+
 /* LiDAR form (filter_predictions.py:55-62,67, db_type 'lidar'): no clamp, NMS on the yaw-less BEV rectangle
  * xc -+ l/2, yc -+ w/2 of the 7-DoF boxes, dets (K, max_out, 8) [xc,yc,zc,l,w,h,ry,score].
  * Workspace: frcnn_filter_per_class_ws_bytes. */

@@ -677,3 +677,111 @@ def test_conv2d_backward_matches_autograd(hip, case):
     _close_feat(db.cpu().numpy(), db_ref.numpy(), "bias grad %s" % (case,), frac=2e-5)
     dw2, _ = ops.conv2d_bwd_weight(x.to(DEV), dy.to(DEV), r, r, stride=stride, pad=pad)
     assert torch.equal(dw, dw2)                                   # deterministic
+
+
+# ------------------------------------------------------------------------------------------------
+# other training-path kernels
+# ------------------------------------------------------------------------------------------------
+def test_act_bwd(hip):
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    dy, y, sc = torch.randn(3, 5, 7, 64, generator=g), torch.randn(3, 5, 7, 64, generator=g), torch.rand(64, generator=g) + 0.5
+    dconv, dres = ops.act_bwd(dy.to(DEV), y.to(DEV), sc.to(DEV), relu=True, want_res=True)
+    mask = (y > 0).float()
+    assert torch.equal(dres.cpu(), dy * mask) and torch.equal(dconv.cpu(), dy * mask * sc)
+    dconv, dres = ops.act_bwd(dy.to(DEV), None, None, relu=False)
+    assert dres is None and torch.equal(dconv.cpu(), dy)
+
+
+@pytest.mark.parametrize("shape", [(19, 32, 38, 63), (38, 63, 75, 125), (5, 7, 10, 14), (4, 3, 9, 8), (6, 6, 6, 6)])
+def test_upsample_bilinear_add_fwd_bwd(hip, shape):
+    """lib/nets/fpn.py:42-45 against F.interpolate(bilinear, align_corners=False) and its autograd (fp64)."""
+    ops = _ops()
+    h, w, oh, ow = shape
+    g = torch.Generator().manual_seed(h * 100 + w)
+    c = 32
+    x = torch.randn(2, h, w, c, generator=g)
+    lat = torch.randn(2, oh, ow, c, generator=g)
+    dout = torch.randn(2, oh, ow, c, generator=g)
+    ref32 = F.interpolate(x.permute(0, 3, 1, 2), size=(oh, ow), mode="bilinear", align_corners=False) + lat.permute(0, 3, 1, 2)
+    got = ops.upsample_bilinear_add(x.to(DEV), lat.to(DEV))
+    np.testing.assert_allclose(got.cpu().permute(0, 3, 1, 2).numpy(), ref32.numpy(), rtol=0, atol=1e-5)
+    # fp32 reference: the sampling coordinates themselves are fp32 on both sides (an fp64 reference differs by the
+    # coordinate rounding, ~1e-5)
+    xd = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    F.interpolate(xd, size=(oh, ow), mode="bilinear", align_corners=False).backward(dout.permute(0, 3, 1, 2).contiguous())
+    dx = ops.upsample_bilinear_bwd(dout.to(DEV), (h, w))
+    np.testing.assert_allclose(dx.cpu().permute(0, 3, 1, 2).numpy(), xd.grad.numpy(), rtol=0, atol=2e-5)
+    assert torch.equal(dx, ops.upsample_bilinear_bwd(dout.to(DEV), (h, w)))          # deterministic
+
+
+@pytest.mark.parametrize("sampling", [0, 2])
+def test_roi_align_bwd_is_the_adjoint_of_fwd(hip, sampling):
+    """RoIAlign is linear in the feature map: <fwd(f), g> == <f, bwd(g)> for random f, g pins the backward to the
+    (oracle-checked) forward without a second reference."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    c, h, w = 32, 38, 63
+    feat = torch.randn(1, h, w, c, generator=g).to(DEV)
+    rois = torch.cat((torch.zeros(40, 1), _rand_boxes(40, g)), 1)
+    rois[0, 1:] = torch.tensor([0., 0, 999, 599])
+    rois[1, 1:] = torch.tensor([990., 590, 1200, 800])
+    rois[2, 1:] = torch.tensor([-40., -30, 20, 10])
+    rois = rois.to(DEV)
+    gout = torch.randn(40, 7, 7, c, generator=g).to(DEV)
+    out = ops.roi_align_nhwc(feat, rois, 7, 1 / 16.0, sampling)
+    dfeat = ops.roi_align_bwd(gout, feat.shape, rois, 1 / 16.0, sampling)
+    lhs = (out.double() * gout.double()).sum().item()
+    rhs = (feat.double() * dfeat.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0), (lhs, rhs)
+    # level mask + device-side count: only the selected rois contribute
+    lvl = (torch.arange(40) % 2).to(torch.int32).to(DEV)
+    cnt = torch.tensor([30], dtype=torch.int32, device=DEV)
+    d1 = ops.roi_align_bwd(gout, feat.shape, rois, 1 / 16.0, sampling, roi_count=cnt, level_of_roi=lvl, level=1)
+    sel = (torch.arange(40) % 2 == 1) & (torch.arange(40) < 30)
+    g2 = gout.clone()
+    g2[~sel.to(DEV)] = 0
+    d2 = ops.roi_align_bwd(g2, feat.shape, rois, 1 / 16.0, sampling)
+    np.testing.assert_allclose(d1.cpu().numpy(), d2.cpu().numpy(), rtol=0, atol=1e-4)
+
+
+def test_rpn_and_det_losses_match_oracle_and_autograd(hip):
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    a, h, w, ld = 25, 12, 17, 152
+    hw = h * w
+    rpn = torch.randn(hw, ld, generator=g)
+    labels = torch.randint(-1, 2, (hw * a,), generator=g).float()
+    targets = torch.randn(hw * a, 4, generator=g) * 1.5
+    inside = (labels == 1).float().view(-1, 1).expand(-1, 4).contiguous()
+    outside = ((labels >= 0).float() / max(1.0, float((labels >= 0).sum()))).view(-1, 1).expand(-1, 4).contiguous()
+    rd = rpn.double().requires_grad_(True)
+    logits = torch.stack((rd[:, :a].reshape(-1), rd[:, a:2 * a].reshape(-1)), 1)      # (HWA, 2): [bg, fg]
+    sel = labels >= 0
+    ce_ref = F.cross_entropy(logits[sel], labels[sel].long())
+    pred = rd[:, 2 * a:6 * a].reshape(1, h, w, 4 * a)
+    box_ref = O.smooth_l1_loss("RPN", pred, targets.double().view(1, h, w, 4 * a), inside.double().view(1, h, w, 4 * a),
+                               outside.double().view(1, h, w, 4 * a), dim=(1, 2, 3))
+    (0.7 * ce_ref + 1.3 * box_ref).backward()
+    losses, drpn = ops.rpn_loss(rpn.to(DEV), a, labels.to(DEV), targets.to(DEV), inside.to(DEV), outside.to(DEV), 0.7, 1.3)
+    lo = losses.cpu().numpy()
+    assert abs(lo[0] - ce_ref.item()) <= 1e-5 and abs(lo[1] - box_ref.item()) <= 1e-5 and lo[2] == float(sel.sum())
+    np.testing.assert_allclose(drpn.cpu().numpy(), rd.grad.float().numpy(), rtol=0, atol=1e-6)
+    assert (drpn[:, 6 * a:] == 0).all()
+    # detection losses
+    r, k = 256, 2
+    cs = torch.randn(r, k, generator=g)
+    lab = torch.randint(0, k, (r,), generator=g).float()
+    bp, bt = torch.randn(r, 4 * k, generator=g), torch.randn(r, 4 * k, generator=g) * 2
+    biw = torch.zeros(r, 4 * k)
+    biw[lab > 0, 4:] = 1.0
+    bow = (biw > 0).float()
+    csd, bpd = cs.double().requires_grad_(True), bp.double().requires_grad_(True)
+    ce = F.cross_entropy(csd, lab.long())
+    bl = O.smooth_l1_loss("DET", bpd, bt.double(), biw.double(), bow.double())
+    (ce + bl).backward()
+    losses, dcls, dbox = ops.det_loss(cs.to(DEV), lab.to(DEV), bp.to(DEV), bt.to(DEV), biw.to(DEV), bow.to(DEV))
+    lo = losses.cpu().numpy()
+    assert abs(lo[0] - ce.item()) <= 1e-5 and abs(lo[1] - bl.item()) <= 1e-5
+    np.testing.assert_allclose(dcls.cpu().numpy(), csd.grad.float().numpy(), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(dbox.cpu().numpy(), bpd.grad.float().numpy(), rtol=0, atol=1e-7)
