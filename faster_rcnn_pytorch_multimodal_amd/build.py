@@ -26,6 +26,7 @@ SOURCES = {
     "roi_align.hip": ["-ffp-contract=off"],
     "head.hip": ["-ffp-contract=off"],
     "train_ops.hip": ["-ffp-contract=off"],
+    "targets.hip": ["-ffp-contract=off"],
 }
 COMMON_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 if os.environ.get("FRCNN_ABLATE"):   # tuning experiments only (tools/): skips parts of the conv kernel

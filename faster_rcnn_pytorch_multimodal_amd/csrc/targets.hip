@@ -1,0 +1,401 @@
+// Training targets on the device: pairwise IoU, RPN anchor targets, second-stage RoI sampling.
+// Replaces lib/utils/bbox.py:5-33 (bbox_overlaps, +1 area convention), lib/layer_utils/anchor_target_layer.py:22-165
+// and lib/layer_utils/proposal_target_layer.py:22-262.  Integer/latency work: no matrix cores; counts are integer
+// atomics (order-independent), maxima are atomicMax on the (non-negative) float bit patterns, random
+// sub-sampling draws a counter-based hash key per candidate and takes the smallest keys (what
+// torch.randperm(n)[:k] does in distribution; the reference's own draws depend on the torch RNG stream and are
+// not reproducible across devices either).  Built with -ffp-contract=off.
+#include "common.h"
+#include "box_math.h"
+
+using namespace frcnn;
+
+namespace {
+
+// IoU with the +1 convention of lib/utils/bbox.py:22-32
+__device__ __forceinline__ float iou_plus1(const float* a, const float* b) {
+  const float aa = (a[2] - a[0] + 1.f) * (a[3] - a[1] + 1.f);
+  const float ab = (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f);
+  const float iw = fmaxf(fminf(a[2], b[2]) - fmaxf(a[0], b[0]) + 1.f, 0.f);
+  const float ih = fmaxf(fminf(a[3], b[3]) - fmaxf(a[1], b[1]) + 1.f, 0.f);
+  const float ua = aa + ab - iw * ih;
+  return iw * ih / ua;
+}
+
+// bbox_transform (lib/model/bbox_transform.py:52-70): centre deltas over the box diagonal, log size ratios
+__device__ __forceinline__ void encode_box(const float* ex, const float* gt, float out[4]) {
+  const float ew = ex[2] - ex[0] + 1.0f, eh = ex[3] - ex[1] + 1.0f;
+  const float diag = sqrtf(ew * ew + eh * eh);
+  const float ecx = ex[0] + 0.5f * ew, ecy = ex[1] + 0.5f * eh;
+  const float gw = gt[2] - gt[0] + 1.0f, gh = gt[3] - gt[1] + 1.0f;
+  const float gcx = gt[0] + 0.5f * gw, gcy = gt[1] + 0.5f * gh;
+  out[0] = (gcx - ecx) / diag;
+  out[1] = (gcy - ecy) / diag;
+  out[2] = (float)log((double)(gw / ew));
+  out[3] = (float)log((double)(gh / eh));
+}
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {  // lowbias32
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t rand_key(uint32_t seed, uint32_t stream, uint32_t i) {
+  return hash32(hash32(seed ^ (stream * 0x9e3779b9U)) + i * 0x85ebca6bU);
+}
+
+__global__ __launch_bounds__(256) void overlaps_kernel(const float* __restrict__ boxes, int box_ld, int n,
+                                                      const float* __restrict__ query, int q_ld, int k,
+                                                      float* __restrict__ out) {
+  const size_t total = (size_t)n * k;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / k), q = (int)(i - (size_t)r * k);
+    out[i] = iou_plus1(boxes + (size_t)r * box_ld, query + (size_t)q * q_ld);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// anchor_target_layer.  State in ws: gt_max[G] (uint bits), counters[4] = {fg, bg, examples, unused},
+// max_ov[N], argmax[N] (int), keys_fg[N], keys_bg[N] (float scores for the top-k selection), keep[N] bytes.
+// ---------------------------------------------------------------------------------------------
+struct AtlFrame {
+  float x_lo, x_hi, y_lo, y_hi;  // inside test: x1 >= x_lo, y1 >= y_lo, x2 < x_hi, y2 < y_hi  (:37-42)
+};
+
+__global__ __launch_bounds__(256) void atl_overlap_kernel(const float* __restrict__ anchors, int n,
+                                                         const float* __restrict__ gt, int g, AtlFrame fr,
+                                                         float* __restrict__ max_ov, int* __restrict__ argmax,
+                                                         unsigned* __restrict__ gt_max) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 a4 = reinterpret_cast<const float4*>(anchors)[i];
+    const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+    const bool inside = a[0] >= fr.x_lo && a[1] >= fr.y_lo && a[2] < fr.x_hi && a[3] < fr.y_hi;
+    float best = -1.f;
+    int arg = 0;
+    if (inside) {
+      for (int j = 0; j < g; ++j) {
+        const float ov = iou_plus1(a, gt + (size_t)j * 5);
+        if (ov > best) { best = ov; arg = j; }            // first maximum, like argmax(dim=1)
+        atomicMax(gt_max + j, __float_as_uint(ov));         // ov >= 0: the bit pattern orders like the value
+      }
+    }
+    max_ov[i] = inside ? best : -1.f;                      // -1 marks an anchor outside the frame
+    argmax[i] = arg;
+  }
+}
+
+__global__ __launch_bounds__(256) void atl_label_kernel(const float* __restrict__ anchors, int n,
+                                                       const float* __restrict__ gt, int g,
+                                                       const float* __restrict__ max_ov,
+                                                       const unsigned* __restrict__ gt_max, float neg_ov, float pos_ov,
+                                                       uint32_t seed, float* __restrict__ labels,
+                                                       float* __restrict__ key_fg, float* __restrict__ key_bg,
+                                                       int* __restrict__ counters) {
+  const float eps = 1.1920929e-07f;  // torch.finfo(float32).eps (:62)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float mo = max_ov[i];
+    float lab = -1.f;
+    if (mo >= 0.f) {
+      if (mo < neg_ov) lab = 0.f;                          // :66-69 (RPN_CLOBBER_POSITIVES off)
+      const float4 a4 = reinterpret_cast<const float4*>(anchors)[i];
+      const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+      for (int j = 0; j < g; ++j) {                        // :63,73: every anchor tying a gt's best overlap
+        const float gm = fmaxf(__uint_as_float(gt_max[j]), eps);
+        if (iou_plus1(a, gt + (size_t)j * 5) == gm) { lab = 1.f; break; }
+      }
+      if (mo >= pos_ov) lab = 1.f;                         // :78
+    }
+    labels[i] = lab;
+    // selection keys: candidates get a uniform key in (0,1], everything else -1 so it sorts last
+    key_fg[i] = lab == 1.f ? (float)((rand_key(seed, 1, i) >> 8) + 1) * (1.0f / 16777216.0f) : -1.f;
+    key_bg[i] = lab == 0.f ? (float)((rand_key(seed, 2, i) >> 8) + 1) * (1.0f / 16777216.0f) : -1.f;
+    if (lab == 1.f) atomicAdd(counters + 0, 1);
+    if (lab == 0.f) atomicAdd(counters + 1, 1);
+  }
+}
+
+// keep[order[i]] = 1 for the first min(count, quota) entries that are real candidates (key > 0)
+__global__ __launch_bounds__(256) void atl_mark_keep_kernel(const int64_t* __restrict__ order,
+                                                           const float* __restrict__ sorted_keys, int top_n,
+                                                           const int* __restrict__ counters, int which, int quota_total,
+                                                           int num_fg_cap, uint8_t* __restrict__ keep) {
+  // which = 0: fg, quota = num_fg_cap.  which = 1: bg, quota = quota_total - min(fg_count, num_fg_cap)  (:96-99)
+  const int fg_kept = min(counters[0], num_fg_cap);
+  const int quota = which == 0 ? num_fg_cap : quota_total - fg_kept;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < top_n; i += gridDim.x * blockDim.x)
+    if (i < quota && sorted_keys[i] > 0.f) keep[order[i]] = 1;
+}
+
+__global__ __launch_bounds__(256) void atl_finalize_kernel(const float* __restrict__ anchors, int n,
+                                                          const float* __restrict__ gt,
+                                                          const int* __restrict__ argmax,
+                                                          const float* __restrict__ max_ov,
+                                                          const uint8_t* __restrict__ keep_fg,
+                                                          const uint8_t* __restrict__ keep_bg,
+                                                          const int* __restrict__ counters, int quota_total,
+                                                          int num_fg_cap, float* __restrict__ labels,
+                                                          float* __restrict__ targets, float* __restrict__ inside,
+                                                          float* __restrict__ outside) {
+  const int fg = counters[0], bg = counters[1];
+  const int fg_kept = min(fg, num_fg_cap);
+  const int bg_kept = min(bg, quota_total - fg_kept);
+  const float wgt = 1.0f / (float)(fg_kept + bg_kept);      // :118-124 uniform example weights
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float lab = labels[i];
+    if (lab == 1.f && fg > num_fg_cap && !keep_fg[i]) lab = -1.f;                   // :91-96
+    if (lab == 0.f && bg > quota_total - fg_kept && !keep_bg[i]) lab = -1.f;        // :99-105
+    labels[i] = lab;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (max_ov[i] >= 0.f) {                                  // every inside anchor gets targets (:110)
+      const float4 a4 = reinterpret_cast<const float4*>(anchors)[i];
+      const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+      float o[4];
+      encode_box(a, gt + (size_t)argmax[i] * 5, o);
+      t = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    const float iw = lab == 1.f ? 1.f : 0.f;                 // RPN_BBOX_INSIDE_WEIGHTS (1,1,1,1)
+    const float ow = lab >= 0.f ? wgt : 0.f;
+    reinterpret_cast<float4*>(targets)[i] = t;
+    reinterpret_cast<float4*>(inside)[i] = make_float4(iw, iw, iw, iw);
+    reinterpret_cast<float4*>(outside)[i] = make_float4(ow, ow, ow, ow);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// proposal_target_layer for the image detector: one workgroup, R <= 4096 candidate RoIs.
+// LDS: keys[2][npad] u64 (random key << 32 | roi index) for the fg and bg candidates.
+// ---------------------------------------------------------------------------------------------
+constexpr int PTL_THREADS = 1024;
+
+struct PtlNorm {
+  float means[4], stds[4];
+};
+
+__global__ __launch_bounds__(PTL_THREADS) void ptl_kernel(const float* __restrict__ rois, const float* __restrict__ scores,
+                                                         const int* __restrict__ roi_count, int num_rois,
+                                                         const float* __restrict__ gt, int g, int num_classes,
+                                                         int rois_per_frame, int fg_quota, float fg_thresh, float bg_hi,
+                                                         float bg_lo, PtlNorm norm, uint32_t seed, int npad,
+                                                         float* __restrict__ out_labels, float* __restrict__ out_rois,
+                                                         float* __restrict__ out_scores, float* __restrict__ out_targets,
+                                                         float* __restrict__ out_inside, float* __restrict__ out_outside,
+                                                         int* __restrict__ out_assign, int* __restrict__ out_counts) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ptl_smem[];
+  uint64_t* kfg = reinterpret_cast<uint64_t*>(ptl_smem);
+  uint64_t* kbg = kfg + npad;
+  int* assign = reinterpret_cast<int*>(kbg + npad);  // [num_rois]
+  __shared__ int s_fg, s_bg;
+  const int t = threadIdx.x;
+  const int R = roi_count ? min(*roi_count, num_rois) : num_rois;
+  if (t == 0) { s_fg = 0; s_bg = 0; }
+  for (int i = t; i < npad; i += PTL_THREADS) { kfg[i] = ~0ull; kbg[i] = ~0ull; }
+  __syncthreads();
+  for (int i = t; i < R; i += PTL_THREADS) {
+    const float* b = rois + (size_t)i * 5 + 1;
+    float best = -1.f;
+    int arg = 0;
+    for (int j = 0; j < g; ++j) {
+      const float ov = iou_plus1(b, gt + (size_t)j * 5);
+      if (ov > best) { best = ov; arg = j; }
+    }
+    assign[i] = arg;
+    if (best >= fg_thresh) {                                   // :200
+      kfg[i] = ((uint64_t)rand_key(seed, 3, i) << 32) | (uint32_t)i;
+      atomicAdd(&s_fg, 1);
+    } else if (best < bg_hi && best >= bg_lo) {               // :203-204
+      kbg[i] = ((uint64_t)rand_key(seed, 4, i) << 32) | (uint32_t)i;
+      atomicAdd(&s_bg, 1);
+    }
+  }
+  __syncthreads();
+  block_bitonic_sort(kfg, npad);   // candidates first, in random order
+  block_bitonic_sort(kbg, npad);
+  const int nfg_c = s_fg, nbg_c = s_bg;
+  // :206-231 quotas
+  int n_fg, n_bg;
+  if (nfg_c > 0 && nbg_c > 0) { n_fg = min(fg_quota, nfg_c); n_bg = rois_per_frame - n_fg; }
+  else if (nfg_c > 0) { n_fg = rois_per_frame; n_bg = 0; }
+  else { n_fg = 0; n_bg = nbg_c > 0 ? rois_per_frame : 0; }
+  if (t == 0) { out_counts[0] = n_fg; out_counts[1] = n_bg; out_counts[2] = nfg_c; out_counts[3] = nbg_c; }
+  const int cols = 4 * num_classes;
+  for (int j = t; j < rois_per_frame; j += PTL_THREADS) {
+    int src = -1;
+    bool is_fg = false;
+    if (j < n_fg) {
+      // mixed case: n_fg <= candidates, a random subset without replacement (:207-211); foreground-only case with
+      // fewer candidates than rows: every row drawn WITH replacement (:217-221, torch_choice_replace :273-275)
+      const int pick = n_fg <= nfg_c ? j : (int)(rand_key(seed, 5, j) % (uint32_t)nfg_c);
+      src = (int)(kfg[pick] & 0xFFFFFFFFu);
+      is_fg = true;
+    } else if (j - n_fg < n_bg) {
+      const int q = j - n_fg;
+      const int pick = (nbg_c >= n_bg) ? q : (int)(rand_key(seed, 6, q) % (uint32_t)nbg_c);  // to_replace (:212)
+      src = (int)(kbg[pick] & 0xFFFFFFFFu);
+    }
+    float lab = 0.f;
+    float* tr = out_targets + (size_t)j * cols;
+    float* ir = out_inside + (size_t)j * cols;
+    float* orow = out_outside + (size_t)j * cols;
+    for (int q = 0; q < cols; ++q) { tr[q] = 0.f; ir[q] = 0.f; orow[q] = 0.f; }
+    float r5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float sc = 0.f;
+    int as = 0;
+    if (src >= 0) {
+      for (int q = 0; q < 5; ++q) r5[q] = rois[(size_t)src * 5 + q];
+      sc = scores ? scores[src] : 0.f;
+      as = assign[src];
+      const float* gb = gt + (size_t)as * 5;
+      if (is_fg) lab = gb[4];                                  // :198,238: class of the assigned gt, bg rows -> 0
+      const int c = (int)lab;
+      if (c > 0 && c < num_classes) {
+        float o[4];
+        encode_box(r5 + 1, gb, o);
+        for (int q = 0; q < 4; ++q) {                          // :160-163 normalised targets, :64-103 class slot
+          tr[4 * c + q] = (o[q] - norm.means[q]) / norm.stds[q];
+          ir[4 * c + q] = 1.f;
+          orow[4 * c + q] = 1.f;
+        }
+      }
+    }
+    out_labels[j] = lab;
+    for (int q = 0; q < 5; ++q) out_rois[(size_t)j * 5 + q] = r5[q];
+    out_scores[j] = sc;
+    out_assign[j] = as;
+  }
+}
+
+int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+unsigned grid_for(size_t items, unsigned cap = 4096) { return (unsigned)std::min<size_t>((items + 255) / 256, cap); }
+
+struct AtlLayout {
+  size_t gt_max, counters, max_ov, argmax, key_fg, key_bg, keep_fg, keep_bg, order, sorted, sort_count, total;
+};
+AtlLayout atl_layout(int n, int g, int top_n) {
+  AtlLayout l;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o = align_up(o + bytes, 256); return at; };
+  l.gt_max = take((size_t)std::max(g, 1) * 4);
+  l.counters = take(16);
+  l.max_ov = take((size_t)n * 4);
+  l.argmax = take((size_t)n * 4);
+  l.key_fg = take((size_t)n * 4);
+  l.key_bg = take((size_t)n * 4);
+  l.keep_fg = take((size_t)n);
+  l.keep_bg = take((size_t)n);
+  l.order = take((size_t)top_n * 8);
+  l.sorted = take((size_t)top_n * 4);
+  l.sort_count = take(16);
+  l.total = o;
+  return l;
+}
+
+}  // namespace
+
+extern "C" int frcnn_bbox_overlaps(const float* boxes, int box_ld, int n, const float* query, int query_ld, int k,
+                                   float* overlaps, void* stream_) {
+  FRCNN_REQUIRE(boxes && query && overlaps && n > 0 && k > 0 && box_ld >= 4 && query_ld >= 4, "bbox_overlaps: bad arguments");
+  hipLaunchKernelGGL(overlaps_kernel, dim3(grid_for((size_t)n * k)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     boxes, box_ld, n, query, query_ld, k, overlaps);
+  return check_launch("overlaps_kernel");
+}
+
+extern "C" size_t frcnn_anchor_target_layer_ws_bytes(int num_anchors_total, int num_gt, int rpn_batchsize) {
+  if (num_anchors_total <= 0 || rpn_batchsize <= 0) return 0;
+  const int top_n = std::min(rpn_batchsize, 16384);
+  return atl_layout(num_anchors_total, num_gt, top_n).total;
+}
+
+extern "C" int frcnn_anchor_target_layer(const float* anchors, int n, const float* gt_boxes, int num_gt,
+                                         const float* info_host, int rpn_batchsize, float fg_fraction,
+                                         float negative_overlap, float positive_overlap, uint32_t seed, float* labels,
+                                         float* targets, float* inside, float* outside, int* counts, void* ws,
+                                         size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FRCNN_REQUIRE(anchors && gt_boxes && info_host && labels && targets && inside && outside && n > 0 && num_gt > 0 &&
+                    rpn_batchsize > 0,
+                "anchor_target_layer: bad arguments (needs at least one gt box)");
+  const int top_n = std::min(rpn_batchsize, 16384);
+  const AtlLayout l = atl_layout(n, num_gt, top_n);
+  if (!ws || ws_bytes < l.total) return fail(FRCNN_ERR_WS, "anchor_target_layer: workspace %zu < %zu bytes", ws_bytes, l.total);
+  char* base = static_cast<char*>(ws);
+  unsigned* gt_max = reinterpret_cast<unsigned*>(base + l.gt_max);
+  int* counters = reinterpret_cast<int*>(base + l.counters);
+  float* max_ov = reinterpret_cast<float*>(base + l.max_ov);
+  int* argmax = reinterpret_cast<int*>(base + l.argmax);
+  float* key_fg = reinterpret_cast<float*>(base + l.key_fg);
+  float* key_bg = reinterpret_cast<float*>(base + l.key_bg);
+  uint8_t* keep_fg = reinterpret_cast<uint8_t*>(base + l.keep_fg);
+  uint8_t* keep_bg = reinterpret_cast<uint8_t*>(base + l.keep_bg);
+  int64_t* order = reinterpret_cast<int64_t*>(base + l.order);
+  float* sorted = reinterpret_cast<float*>(base + l.sorted);
+  int* sort_count = reinterpret_cast<int*>(base + l.sort_count);
+  // gt_max, counters .. up to max_ov are contiguous at the start; keep flags are contiguous too
+  hipError_t e = hipMemsetAsync(base, 0, l.max_ov, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(keep_fg, 0, l.order - l.keep_fg, stream);
+  if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "anchor_target_layer: memset: %s", hipGetErrorString(e));
+  const AtlFrame fr{info_host[0], info_host[1], info_host[2], info_host[3]};
+  const unsigned grid = grid_for((size_t)n);
+  hipLaunchKernelGGL(atl_overlap_kernel, dim3(grid), dim3(256), 0, stream, anchors, n, gt_boxes, num_gt, fr, max_ov, argmax,
+                     gt_max);
+  int rc = check_launch("atl_overlap_kernel");
+  if (rc != FRCNN_OK) return rc;
+  hipLaunchKernelGGL(atl_label_kernel, dim3(grid), dim3(256), 0, stream, anchors, n, gt_boxes, num_gt, max_ov, gt_max,
+                     negative_overlap, positive_overlap, seed, labels, key_fg, key_bg, counters);
+  rc = check_launch("atl_label_kernel");
+  if (rc != FRCNN_OK) return rc;
+  const int num_fg_cap = (int)(fg_fraction * (float)rpn_batchsize);   // :91
+  if (rpn_batchsize <= 16384) {
+    // random sub-sampling: the `quota` candidates with the largest random keys survive
+    for (int which = 0; which < 2; ++which) {
+      rc = frcnn_sort_topk_desc(which == 0 ? key_fg : key_bg, n, top_n, order, sorted, sort_count, nullptr, 0, stream_);
+      if (rc != FRCNN_OK) return rc;
+      hipLaunchKernelGGL(atl_mark_keep_kernel, dim3(grid_for((size_t)top_n)), dim3(256), 0, stream, order, sorted, top_n,
+                         counters, which, rpn_batchsize, num_fg_cap, which == 0 ? keep_fg : keep_bg);
+      rc = check_launch("atl_mark_keep_kernel");
+      if (rc != FRCNN_OK) return rc;
+    }
+  }
+  // (rpn_batchsize > 16384 only makes sense as "no sub-sampling": the caps then exceed any candidate count)
+  hipLaunchKernelGGL(atl_finalize_kernel, dim3(grid), dim3(256), 0, stream, anchors, n, gt_boxes, argmax, max_ov, keep_fg,
+                     keep_bg, counters, rpn_batchsize, num_fg_cap, labels, targets, inside, outside);
+  rc = check_launch("atl_finalize_kernel");
+  if (rc != FRCNN_OK) return rc;
+  if (counts) {
+    e = hipMemcpyAsync(counts, counters, 2 * sizeof(int), hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "anchor_target_layer: copy counts: %s", hipGetErrorString(e));
+  }
+  return FRCNN_OK;
+}
+
+extern "C" int frcnn_proposal_target_layer(const float* rois, const float* roi_scores, const int* roi_count,
+                                           int num_rois, const float* gt_boxes, int num_gt, int num_classes,
+                                           int rois_per_frame, float fg_fraction, float fg_thresh, float bg_thresh_hi,
+                                           float bg_thresh_lo, const float* means_host, const float* stds_host,
+                                           uint32_t seed, float* labels, float* out_rois, float* out_scores,
+                                           float* targets, float* inside, float* outside, int* gt_assignment,
+                                           int* counts, void* stream_) {
+  FRCNN_REQUIRE(rois && gt_boxes && means_host && stds_host && labels && out_rois && out_scores && targets && inside &&
+                    outside && gt_assignment && counts && num_rois > 0 && num_rois <= 4096 && num_gt > 0 &&
+                    num_classes > 1 && rois_per_frame > 0,
+                "proposal_target_layer: bad arguments (num_rois <= 4096, at least one gt box)");
+  PtlNorm norm;
+  for (int q = 0; q < 4; ++q) { norm.means[q] = means_host[q]; norm.stds[q] = stds_host[q]; }
+  const int npad = next_pow2(std::max(num_rois, 2));
+  const size_t lds = (size_t)npad * 16 + (size_t)num_rois * 4;
+  static size_t configured = 0;
+  if (lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ptl_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "proposal_target_layer: set LDS size: %s", hipGetErrorString(e));
+    configured = lds;
+  }
+  const int fg_quota = (int)lrintf(fg_fraction * (float)rois_per_frame);   // int(round(...)) (:44-45)
+  hipLaunchKernelGGL(ptl_kernel, dim3(1), dim3(PTL_THREADS), lds, static_cast<hipStream_t>(stream_), rois, roi_scores,
+                     roi_count, num_rois, gt_boxes, num_gt, num_classes, rois_per_frame, fg_quota, fg_thresh, bg_thresh_hi,
+                     bg_thresh_lo, norm, seed, npad, labels, out_rois, out_scores, targets, inside, outside, gt_assignment,
+                     counts);
+  return check_launch("ptl_kernel");
+}

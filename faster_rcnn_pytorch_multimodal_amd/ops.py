@@ -473,3 +473,61 @@ def det_loss(cls_score, labels, bbox_pred, targets, inside, outside, bbox_elem=4
                                   _ptr(outside), int(bbox_elem), float(grad_ce), float(grad_box), _ptr(losses), _ptr(dcls),
                                   _ptr(dbox), _stream()), "frcnn_det_loss")
     return losses, dcls, dbox
+
+
+def bbox_overlaps(boxes, query_boxes):
+    """IoU (+1 convention) between boxes (N, >=4) and query_boxes (K, >=4) -> (N, K)."""
+    lib = _hip.load()
+    _dev_f32(boxes, "boxes"); _dev_f32(query_boxes, "query_boxes")
+    n, k = boxes.shape[0], query_boxes.shape[0]
+    out = torch.empty((n, k), dtype=torch.float32, device=boxes.device)
+    if n and k:
+        _hip.check(lib.frcnn_bbox_overlaps(_ptr(boxes), boxes.shape[1], n, _ptr(query_boxes), query_boxes.shape[1], k,
+                                           _ptr(out), _stream()), "frcnn_bbox_overlaps")
+    return out
+
+
+def anchor_target_layer(anchors, gt_boxes, info, rpn_batchsize, fg_fraction, neg_ov, pos_ov, seed):
+    """Returns labels (N,), targets/inside/outside (N,4) in anchor order and counts (2,) int32 [fg, bg candidates]."""
+    lib = _hip.load()
+    _dev_f32(anchors, "anchors"); _dev_f32(gt_boxes, "gt_boxes")
+    n, g = anchors.shape[0], gt_boxes.shape[0]
+    if gt_boxes.shape[1] != 5:
+        raise _hip.HipError("anchor_target_layer: gt_boxes must be (G,5)")
+    dev = anchors.device
+    labels = torch.empty((n,), dtype=torch.float32, device=dev)
+    targets, inside, outside = (torch.empty((n, 4), dtype=torch.float32, device=dev) for _ in range(3))
+    counts = torch.zeros((2,), dtype=torch.int32, device=dev)
+    ws_bytes = lib.frcnn_anchor_target_layer_ws_bytes(n, g, int(rpn_batchsize))
+    ws = _workspace(ws_bytes, dev)
+    _hip.check(lib.frcnn_anchor_target_layer(
+        _ptr(anchors), n, _ptr(gt_boxes), g, _hip.float_array([float(v) for v in list(info)[:4]]), int(rpn_batchsize),
+        float(fg_fraction), float(neg_ov), float(pos_ov), int(seed) & 0xFFFFFFFF, _ptr(labels), _ptr(targets),
+        _ptr(inside), _ptr(outside), _ptr(counts), _ptr(ws), ws_bytes, _stream()), "frcnn_anchor_target_layer")
+    return labels, targets, inside, outside, counts
+
+
+def proposal_target_layer(rois, roi_scores, gt_boxes, num_classes, rois_per_frame, fg_fraction, fg_thresh, bg_hi, bg_lo,
+                          means, stds, seed, roi_count=None):
+    """Returns dict(labels (R,), rois (R,5), scores (R,), targets/inside/outside (R,4K), assign int32 (R,), counts int32 (4,))."""
+    lib = _hip.load()
+    _dev_f32(rois, "rois"); _dev_f32(gt_boxes, "gt_boxes")
+    if roi_scores is not None:
+        _dev_f32(roi_scores, "roi_scores")
+    dev = rois.device
+    r = int(rois_per_frame)
+    out = {"labels": torch.empty((r,), dtype=torch.float32, device=dev),
+           "rois": torch.empty((r, 5), dtype=torch.float32, device=dev),
+           "scores": torch.empty((r,), dtype=torch.float32, device=dev),
+           "targets": torch.empty((r, 4 * num_classes), dtype=torch.float32, device=dev),
+           "inside": torch.empty((r, 4 * num_classes), dtype=torch.float32, device=dev),
+           "outside": torch.empty((r, 4 * num_classes), dtype=torch.float32, device=dev),
+           "assign": torch.empty((r,), dtype=torch.int32, device=dev),
+           "counts": torch.zeros((4,), dtype=torch.int32, device=dev)}
+    _hip.check(lib.frcnn_proposal_target_layer(
+        _ptr(rois), _ptr(roi_scores), _ptr(roi_count), rois.shape[0], _ptr(gt_boxes), gt_boxes.shape[0], int(num_classes),
+        r, float(fg_fraction), float(fg_thresh), float(bg_hi), float(bg_lo), _hip.float_array(means),
+        _hip.float_array(stds), int(seed) & 0xFFFFFFFF, _ptr(out["labels"]), _ptr(out["rois"]), _ptr(out["scores"]),
+        _ptr(out["targets"]), _ptr(out["inside"]), _ptr(out["outside"]), _ptr(out["assign"]), _ptr(out["counts"]),
+        _stream()), "frcnn_proposal_target_layer")
+    return out

@@ -235,6 +235,34 @@ int frcnn_det_loss(const float* cls_score, const float* labels, int num_rois, in
                    int bbox_elem, float grad_ce, float grad_box, float* losses, float* dcls, float* dbox,
                    void* stream);
 
+/* bbox_overlaps (lib/utils/bbox.py:5-33): IoU with the +1 area convention; boxes (n rows of box_ld floats, first
+ * 4 = [x1,y1,x2,y2]) x query (k rows of query_ld floats) -> overlaps (n,k). */
+int frcnn_bbox_overlaps(const float* boxes, int box_ld, int n, const float* query, int query_ld, int k,
+                        float* overlaps, void* stream);
+
+/* anchor_target_layer_torch (lib/layer_utils/anchor_target_layer.py:22-165; IGNORE_DC off, CLOBBER_POSITIVES off,
+ * uniform example weights): anchors (n,4) in (H,W,A) order, gt_boxes (num_gt,5) [x1,y1,x2,y2,cls], info HOST
+ * [x_min,x_max,y_min,y_max].  Outputs in anchor order: labels (n) in {-1,0,1}, targets/inside/outside (n,4);
+ * counts (2 ints, may be NULL) = fg / bg candidates before sub-sampling.  Sub-sampling to
+ * fg_fraction*rpn_batchsize foreground and rpn_batchsize total draws hash keys from `seed`. */
+size_t frcnn_anchor_target_layer_ws_bytes(int num_anchors_total, int num_gt, int rpn_batchsize);
+int frcnn_anchor_target_layer(const float* anchors, int n, const float* gt_boxes, int num_gt,
+                              const float* info_host, int rpn_batchsize, float fg_fraction, float negative_overlap,
+                              float positive_overlap, uint32_t seed, float* labels, float* targets, float* inside,
+                              float* outside, int* counts, void* ws, size_t ws_bytes, void* stream);
+
+/* proposal_target_layer (lib/layer_utils/proposal_target_layer.py:22-262, image detector, USE_GT / IGNORE_DC off):
+ * rois (num_rois,5), roi_scores (num_rois) or NULL, roi_count device int or NULL, gt_boxes (num_gt,5).
+ * Outputs with rois_per_frame rows (foreground rows first): labels, out_rois (.,5), out_scores, targets / inside /
+ * outside (., 4*num_classes; targets normalised with means/stds, HOST 4 floats each), gt_assignment (.) ints,
+ * counts[4] = {fg rows, bg rows, fg candidates, bg candidates}.  num_rois <= 4096. */
+int frcnn_proposal_target_layer(const float* rois, const float* roi_scores, const int* roi_count, int num_rois,
+                                const float* gt_boxes, int num_gt, int num_classes, int rois_per_frame,
+                                float fg_fraction, float fg_thresh, float bg_thresh_hi, float bg_thresh_lo,
+                                const float* means_host, const float* stds_host, uint32_t seed, float* labels,
+                                float* out_rois, float* out_scores, float* targets, float* inside, float* outside,
+                                int* gt_assignment, int* counts, void* stream);
+
 /* LiDAR form (filter_predictions.py:55-62,67, db_type 'lidar'): no clamp, NMS on the yaw-less BEV rectangle
  * xc -+ l/2, yc -+ w/2 of the 7-DoF boxes, dets (K, max_out, 8) [xc,yc,zc,l,w,h,ry,score].
  * Workspace: frcnn_filter_per_class_ws_bytes. */

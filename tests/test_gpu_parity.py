@@ -785,3 +785,111 @@ def test_rpn_and_det_losses_match_oracle_and_autograd(hip):
     assert abs(lo[0] - ce.item()) <= 1e-5 and abs(lo[1] - bl.item()) <= 1e-5
     np.testing.assert_allclose(dcls.cpu().numpy(), csd.grad.float().numpy(), rtol=0, atol=1e-7)
     np.testing.assert_allclose(dbox.cpu().numpy(), bpd.grad.float().numpy(), rtol=0, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------
+# training-target layers on the device
+# ------------------------------------------------------------------------------------------------
+def test_bbox_overlaps_against_reference_golden(hip, golden_dir):
+    ops = _ops()
+    g = np.load(os.path.join(golden_dir, "box_codec.npz"))
+    got = ops.bbox_overlaps(torch.from_numpy(g["boxes"][:64]).to(DEV), torch.from_numpy(g["gt"][:48]).to(DEV))
+    np.testing.assert_allclose(got.cpu().numpy(), g["overlaps"], rtol=0, atol=1e-6)
+
+
+def test_anchor_target_layer_against_reference_golden(hip, golden_dir):
+    """Sub-sampling inactive (RPN_BATCHSIZE above every count): labels / weights bit-exact, targets to fp32 log()."""
+    from faster_rcnn_pytorch_multimodal_amd.layer_utils.anchor_target_layer import anchor_target_layer_torch
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    C.reset_cfg()
+    C.cfg.TRAIN.RPN_BATCHSIZE = 10 ** 7
+    z = np.load(os.path.join(golden_dir, "lidar_train.npz"))
+    h, w = (int(v) for v in z["atl_hw"])
+    lab, tgt, inw, outw = anchor_target_layer_torch(torch.from_numpy(z["atl_gt"]).to(DEV), None, z["atl_info"],
+                                                    torch.from_numpy(z["atl_anchors"]).to(DEV), 25, h, w)
+    np.testing.assert_array_equal(lab.cpu().numpy(), z["atl_labels"])
+    np.testing.assert_array_equal(inw.cpu().numpy(), z["atl_inside"])
+    np.testing.assert_array_equal(outw.cpu().numpy(), z["atl_outside"])
+    np.testing.assert_allclose(tgt.cpu().numpy(), z["atl_targets"], rtol=0, atol=2e-6)
+    C.reset_cfg()
+
+
+def test_anchor_target_layer_subsampling_properties(hip, golden_dir):
+    """Default caps (256 examples, <= 128 fg): the sampled labels are a subset of the unsampled ones, the counts hit
+    the quotas exactly, the weights are 1/num_examples, and the draw is repeatable for a given seed."""
+    from faster_rcnn_pytorch_multimodal_amd.layer_utils.anchor_target_layer import anchor_target_layer_device
+    from faster_rcnn_pytorch_multimodal_amd.layer_utils.snippets import generate_anchors_pre
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    C.reset_cfg()
+    anchors, _ = generate_anchors_pre(38, 63, 16, C.cfg.ANCHOR_SCALES, C.cfg.ANCHOR_RATIOS, 1.0, device=DEV)
+    info = np.array([0, 1000, 0, 600, 0, 0, 1.0], np.float32)
+    g = torch.Generator().manual_seed(3)
+    gt = torch.cat((_rand_boxes(12, g, max_wh=250), torch.ones(12, 1)), 1).to(DEV)
+    C.cfg.TRAIN.RPN_BATCHSIZE = 10 ** 7
+    full, _, _, _, counts = anchor_target_layer_device(gt, info, anchors, seed=1)
+    full = full.cpu()
+    ref = O.anchor_target_layer(gt.cpu(), info, anchors.cpu(), 25, 38, 63, rpn_batchsize=10 ** 7)[0]
+    assert torch.equal(full.view(1, 38, 63, 25).permute(0, 3, 1, 2), ref)
+    n_fg_all, n_bg_all = int((full == 1).sum()), int((full == 0).sum())
+    assert counts.cpu().tolist() == [n_fg_all, n_bg_all] and n_bg_all > 256
+    C.reset_cfg()
+    for fg_frac in (0.5, 0.02):                     # 0.02 -> cap of 5 foreground anchors: exercises the fg branch too
+        C.cfg.TRAIN.RPN_FG_FRACTION = fg_frac
+        lab, tgt, inw, outw, _ = anchor_target_layer_device(gt, info, anchors, seed=11)
+        lab2 = anchor_target_layer_device(gt, info, anchors, seed=11)[0]
+        lab3 = anchor_target_layer_device(gt, info, anchors, seed=12)[0]
+        assert torch.equal(lab, lab2) and not torch.equal(lab, lab3)
+        lab = lab.cpu()
+        cap = int(fg_frac * 256)
+        n_fg, n_bg = int((lab == 1).sum()), int((lab == 0).sum())
+        assert n_fg == min(n_fg_all, cap) and n_bg == 256 - n_fg
+        assert ((lab == 1) <= (full == 1)).all() and ((lab == 0) <= (full == 0)).all()
+        ow = outw.cpu()
+        assert torch.equal(ow[:, 0] > 0, lab >= 0) and np.allclose(ow[lab >= 0].numpy(), 1.0 / 256)
+        assert torch.equal(inw.cpu()[:, 0] == 1, lab == 1)
+    C.reset_cfg()
+
+
+def test_proposal_target_layer_against_reference_golden(hip, golden_dir):
+    """40 fg == the fg share, 216 bg == the rest: every candidate is taken, so the row SET must equal the reference's."""
+    from faster_rcnn_pytorch_multimodal_amd.layer_utils.proposal_target_layer import proposal_target_layer
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    C.reset_cfg()
+    C.cfg.NET_TYPE = "image"
+    z = np.load(os.path.join(golden_dir, "lidar_train.npz"))
+    rois, sc, gt = (torch.from_numpy(z[k]).to(DEV) for k in ("ptl_rois", "ptl_scores", "ptl_gt"))
+    lab, r, _, s, bt, biw, bow = proposal_target_layer(rois, sc, None, gt, None, None, 2, 4)
+    assert (lab[:40] == 1).all() and (lab[40:] == 0).all()                   # foreground rows first
+    packed = torch.cat((r, lab, s.view(-1, 1), bt, biw, bow), 1).cpu().numpy()
+    packed = packed[np.lexsort(packed.T[::-1])]
+    want = z["ptl_packed_sorted"]
+    np.testing.assert_array_equal(packed[:, :7], want[:, :7])               # rois, labels, scores: exact
+    np.testing.assert_allclose(packed[:, 7:15], want[:, 7:15], rtol=0, atol=2e-5)   # targets / 0.1 stds: log(), sqrt()
+    np.testing.assert_array_equal(packed[:, 15:], want[:, 15:])             # weights: exact
+    C.reset_cfg()
+
+
+def test_proposal_target_layer_sampling_properties(hip):
+    ops = _ops()
+    g = torch.Generator().manual_seed(8)
+    gt = torch.tensor([[100., 100, 299, 259, 1], [500, 300, 699, 499, 1]])
+    fg = gt[torch.arange(150) % 2, :4] + (torch.rand(150, 4, generator=g) - 0.5) * 8
+    bg = _rand_boxes(100, g, max_wh=50)
+    bg = bg[O.bbox_overlaps(bg, gt[:, :4]).max(1)[0] < 0.4]
+    rois = torch.cat((torch.zeros(len(fg) + len(bg), 1), torch.cat((fg, bg), 0)), 1)
+    args = (2, 256, 0.25, 0.6, 0.5, 0.0, (0.0,) * 4, (0.1, 0.1, 0.2, 0.2))
+    out = ops.proposal_target_layer(rois.to(DEV), None, gt.to(DEV), *args, seed=5)
+    cnt = out["counts"].cpu().tolist()
+    assert cnt == [64, 192, 150, len(bg)]                                    # 150 fg candidates -> 64 rows, bg with replacement
+    sel = out["rois"].cpu()
+    fg_rows = {tuple(r.tolist()) for r in sel[:64]}
+    assert len(fg_rows) == 64 and fg_rows <= {tuple(r.tolist()) for r in rois[:150]}      # no repeats, all foreground
+    assert {tuple(r.tolist()) for r in sel[64:]} <= {tuple(r.tolist()) for r in rois[150:]}
+    lab = out["labels"].cpu()
+    assert (lab[:64] == 1).all() and (lab[64:] == 0).all()
+    out2 = ops.proposal_target_layer(rois.to(DEV), None, gt.to(DEV), *args, seed=5)
+    assert all(torch.equal(out[k], out2[k]) for k in out)
+    # device-side roi count: candidates past the count are ignored
+    cnt_dev = torch.tensor([150], dtype=torch.int32, device=DEV)
+    out3 = ops.proposal_target_layer(rois.to(DEV), None, gt.to(DEV), *args, seed=5, roi_count=cnt_dev)
+    assert out3["counts"].cpu().tolist() == [256, 0, 150, 0]
