@@ -426,6 +426,21 @@ __global__ __launch_bounds__(256) void clip_boxes_kernel(const float* __restrict
   }
 }
 
+// LevelMapper.__call__ (lib/utils/torchpoolers.py:39-51): FPN level of each RoI from its area (no +1):
+// floor(lvl0 + log2(sqrt(area) / s0) + eps) clamped to [k_min, k_max], returned relative to k_min.
+__global__ __launch_bounds__(256) void fpn_level_map_kernel(const float* __restrict__ rois, int n, int k_min, int k_max,
+                                                           float s0, float lvl0, float eps, int* __restrict__ levels) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float* b = rois + (size_t)i * 5 + 1;
+    const float area = (b[2] - b[0]) * (b[3] - b[1]);
+    const float s = sqrtf(area);
+    float lvl = floorf(lvl0 + (float)log2((double)(s / s0)) + eps);
+    lvl = fminf(fmaxf(lvl, (float)k_min), (float)k_max);   // NaN (negative area) falls to k_min like clamp(min=...)
+    if (!(lvl >= (float)k_min)) lvl = (float)k_min;
+    levels[i] = (int)lvl - k_min;
+  }
+}
+
 int next_pow2(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -625,6 +640,15 @@ extern "C" int frcnn_lidar_bbox_transform_inv(const float* rois, int roi_ld, con
                      static_cast<hipStream_t>(stream_), rois, roi_ld, anchors_3d, deltas, n, num_classes, scale,
                      scale > 0.f ? 1 : 0, out);
   return check_launch("lidar_bbox_transform_inv_kernel");
+}
+
+extern "C" int frcnn_fpn_level_map(const float* rois, int num_rois, int k_min, int k_max, float canonical_scale,
+                                   float canonical_level, float eps, int* levels, void* stream_) {
+  FRCNN_REQUIRE(rois && levels && num_rois > 0 && k_min <= k_max && canonical_scale > 0.f, "fpn_level_map: bad arguments");
+  hipLaunchKernelGGL(fpn_level_map_kernel, dim3(std::min((num_rois + 255) / 256, 1024)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), rois, num_rois, k_min, k_max, canonical_scale, canonical_level, eps,
+                     levels);
+  return check_launch("fpn_level_map_kernel");
 }
 
 extern "C" int frcnn_clip_boxes(const float* boxes, int num_boxes, const float* info_host, float* out, void* stream_) {

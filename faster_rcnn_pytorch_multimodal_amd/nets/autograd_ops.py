@@ -1,0 +1,366 @@
+"""Autograd nodes of the training path (``Network.train_step`` -> ``loss.backward()``,
+lib/model/train_val.py:458): each node's forward AND backward are libfrcnn_hip.so launches
+(``frcnn_conv2d_fwd / _bwd_data / _bwd_weight``, ``frcnn_act_bwd``, ``frcnn_upsample_bilinear_*``,
+``frcnn_roi_align_fwd / _bwd``, ``frcnn_rpn_loss``, ``frcnn_det_loss``).  torch.autograd only orders the nodes
+and owns the ``.grad`` buffers; gradient accumulation inside a residual block is fused into the data-gradient
+kernel's epilogue (``add=``), so a Bottleneck is ONE node.
+
+BatchNorm is frozen on this path (lib/nets/imagenet.py:110-116): it is a per-channel scale/shift of the
+convolution output and receives no gradient.  Activations are NHWC; parameters keep the reference's layouts
+(Conv2d (K,C,R,S), Linear (out,in)) and are re-laid out as KRSC through ``hip_modules.prepared_conv`` caches.
+"""
+import torch
+
+from .. import ops
+from .hip_modules import pad4, prepared_conv
+
+
+def _transposed_filter(conv_like, w_krsc):
+    """Cached (C,R,S,K) flipped filter of the data-gradient convolution, keyed like the forward filter."""
+    cache = conv_like.__dict__.get('_frcnn_wt')
+    key = (w_krsc.data_ptr(), w_krsc._version, tuple(w_krsc.shape))
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    w_t = ops.conv2d_transpose_filter(w_krsc)
+    conv_like.__dict__['_frcnn_wt'] = (key, w_t)
+    return w_t
+
+
+def _param_grad_from_krsc(dw_krsc, param):
+    """(K,R,S,Cpad) -> the parameter's own layout ((K,C,R,S) conv, (out,in) linear)."""
+    k, r, s, _ = dw_krsc.shape
+    if param.dim() == 2:
+        return dw_krsc.view(k, -1)[:, :param.shape[1]].contiguous()
+    return dw_krsc[..., :param.shape[1]].permute(0, 3, 1, 2).contiguous()
+
+
+def _stride_pad(conv):
+    st = conv.stride[0] if isinstance(conv.stride, (tuple, list)) else conv.stride
+    pd = conv.padding[0] if isinstance(conv.padding, (tuple, list)) else conv.padding
+    return st, pd
+
+
+class _ConvFn(torch.autograd.Function):
+    """y = act(conv(x, w) * scale + shift [+ residual]) for ONE parameter set (weight [, bias])."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, pack):
+        w_krsc, scale, shift, stride, pad, relu, owner = pack
+        y = ops.conv2d_nhwc(x, w_krsc, scale, shift, residual, stride=stride, pad=pad, relu=relu)
+        ctx.pack = pack
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, y if relu else None, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, bias = ctx.saved_tensors
+        w_krsc, scale, _, stride, pad, relu, owner = ctx.pack
+        dy = dy.contiguous()
+        need_x, need_res, need_w, need_b = ctx.needs_input_grad[:4]
+        if relu or scale is not None or (ctx.has_res and need_res):
+            d_conv, d_res = ops.act_bwd(dy, y, scale, relu=relu, want_res=ctx.has_res and need_res)
+        else:
+            d_conv, d_res = dy, None
+        dx = dw = db = None
+        r, s = w_krsc.shape[1], w_krsc.shape[2]
+        if need_w or (bias is not None and need_b):
+            dw_krsc, db = ops.conv2d_bwd_weight(x, d_conv, r, s, stride=stride, pad=pad, want_bias=bias is not None)
+            if need_w:
+                dw = _param_grad_from_krsc(dw_krsc, weight)
+            if not need_b:
+                db = None
+        if need_x:
+            dx = ops.conv2d_bwd_data(d_conv, _transposed_filter(owner, w_krsc), tuple(x.shape), stride=stride, pad=pad)
+        return dx, d_res, dw, db, None
+
+
+def conv_bn_act_train(x, conv, bn=None, relu=False, residual=None, use_bn=True):
+    """Differentiable counterpart of hip_modules.conv_bn_act (frozen / eval-mode BatchNorm only)."""
+    if bn is not None and use_bn and bn.training:
+        raise NotImplementedError("BatchNorm with batch statistics is not on the HIP path (the image detector freezes BN)")
+    w_krsc, scale, shift = prepared_conv(conv, bn, use_bn)
+    if x.shape[-1] != w_krsc.shape[-1]:
+        raise NotImplementedError("differentiable conv needs C % 4 == 0 inputs (only the frozen stem pads its input)")
+    stride, pad = _stride_pad(conv)
+    # with a folded BN the effective bias is shift = bn.bias - mean*scale (+ conv.bias*scale); conv.bias itself only
+    # exists on the BN-free convolutions (RPN, FPN), where shift == conv.bias and d(bias) = sum(d_conv)
+    return _ConvFn.apply(x, residual, conv.weight, conv.bias, (w_krsc, scale, shift, stride, pad, relu, conv))
+
+
+def linear_train(x2d, lin, relu=False, weight_nhwc_from=None):
+    """act(x W^T + b) as a 1x1 convolution over R "pixels".  ``weight_nhwc_from=(C,P)`` says the Linear consumes an
+    NCHW-flattened (C,P,P) map while ``x2d`` is the NHWC flattening: the filter columns are permuted once (cached)."""
+    r, cin = x2d.shape
+    if weight_nhwc_from is None:
+        w_krsc = lin.weight.detach().view(lin.out_features, 1, 1, cin)
+        return _ConvFn.apply(x2d.view(r, 1, 1, cin), None, lin.weight, lin.bias,
+                             (w_krsc, None, lin.bias.detach(), 1, 0, relu, lin)).view(r, -1)
+    return _PermutedLinearFn.apply(x2d, lin.weight, lin.bias, lin, weight_nhwc_from, relu)
+
+
+class _PermutedLinearFn(torch.autograd.Function):
+    @staticmethod
+    def _prepared(lin, c, p):
+        key = (lin.weight._version, lin.weight.data_ptr())
+        cache = lin.__dict__.get('_frcnn_perm')
+        if cache is None or cache[0] != key:
+            w = lin.weight.detach().view(lin.out_features, c, p, p).permute(0, 2, 3, 1).reshape(lin.out_features, 1, 1, -1)
+            cache = (key, w.contiguous())
+            lin.__dict__['_frcnn_perm'] = cache
+        return cache[1]
+
+    @staticmethod
+    def forward(ctx, x2d, weight, bias, lin, cp, relu):
+        c, p = cp
+        w_krsc = _PermutedLinearFn._prepared(lin, c, p)
+        r = x2d.shape[0]
+        y = ops.conv2d_nhwc(x2d.view(r, 1, 1, -1), w_krsc, None, bias.detach(), None, relu=relu)
+        ctx.meta = (lin, cp, relu, w_krsc)
+        ctx.save_for_backward(x2d, y if relu else None)
+        return y.view(r, -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, y = ctx.saved_tensors
+        lin, (c, p), relu, w_krsc = ctx.meta
+        r = x2d.shape[0]
+        dy4 = dy.contiguous().view(r, 1, 1, -1)
+        d_conv = ops.act_bwd(dy4, y, None, relu=True)[0] if relu else dy4
+        x4 = x2d.view(r, 1, 1, -1)
+        dw_krsc, db = ops.conv2d_bwd_weight(x4, d_conv, 1, 1, want_bias=True)
+        dw = dw_krsc.view(lin.out_features, p, p, c).permute(0, 3, 1, 2).reshape(lin.out_features, -1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_bwd_data(d_conv, _transposed_filter(lin, w_krsc), tuple(x4.shape)).view(r, -1)
+        return dx, dw, db, None, None, None
+
+
+class _FusedHeadFn(torch.autograd.Function):
+    """Two sibling layers that share their input (rpn_cls_score_net + rpn_bbox_pred_net, cls_score_net +
+    bbox_pred_net) as ONE convolution with the filters concatenated along K and zero-padded to a multiple of 4."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, pack):
+        w_krsc, bias_cat, owner = pack
+        y = ops.conv2d_nhwc(x, w_krsc, None, bias_cat, None)
+        ctx.pack = pack
+        ctx.save_for_backward(x, w1, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2 = ctx.saved_tensors
+        w_krsc, _, owner = ctx.pack
+        dy = dy.contiguous()
+        dw_krsc, db = ops.conv2d_bwd_weight(x, dy, w_krsc.shape[1], w_krsc.shape[2], want_bias=True)
+        k1, k2 = w1.shape[0], w2.shape[0]
+        dw1 = _param_grad_from_krsc(dw_krsc[:k1], w1)
+        dw2 = _param_grad_from_krsc(dw_krsc[k1:k1 + k2], w2)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_bwd_data(dy, _transposed_filter(owner, w_krsc), tuple(x.shape))
+        return dx, dw1, db[:k1].contiguous(), dw2, db[k1:k1 + k2].contiguous(), None
+
+
+def fused_head_weights(owner, m1, m2, cache_name):
+    """(w_krsc (K1+K2 padded to %4, 1, 1, C), bias) of two 1x1-conv / Linear siblings, cached on ``owner``."""
+    tensors = (m1.weight, m1.bias, m2.weight, m2.bias)
+    key = tuple((t._version, t.data_ptr()) for t in tensors)
+    cache = owner.__dict__.get(cache_name)
+    if cache is not None and cache[0] == key:
+        return cache[1], cache[2]
+    with torch.no_grad():
+        w1 = m1.weight.detach().reshape(m1.weight.shape[0], -1)
+        w2 = m2.weight.detach().reshape(m2.weight.shape[0], -1)
+        k = w1.shape[0] + w2.shape[0]
+        kp = pad4(k)
+        w = torch.zeros((kp, w1.shape[1]), dtype=torch.float32, device=w1.device)
+        w[:w1.shape[0]] = w1
+        w[w1.shape[0]:k] = w2
+        b = torch.zeros((kp,), dtype=torch.float32, device=w1.device)
+        b[:w1.shape[0]] = m1.bias.detach()
+        b[w1.shape[0]:k] = m2.bias.detach()
+        w = w.view(kp, 1, 1, -1).contiguous()
+    owner.__dict__[cache_name] = (key, w, b)
+    return w, b
+
+
+def fused_head_train(x, owner, m1, m2, cache_name):
+    w, b = fused_head_weights(owner, m1, m2, cache_name)
+    return _FusedHeadFn.apply(x, m1.weight, m1.bias, m2.weight, m2.bias, (w, b, _Holder.of(owner, cache_name)))
+
+
+class _Holder(object):
+    """Small attribute bag that owns the transposed-filter cache of a fused head."""
+    @staticmethod
+    def of(owner, name):
+        h = owner.__dict__.get(name + '_holder')
+        if h is None:
+            h = _Holder()
+            owner.__dict__[name + '_holder'] = h
+        return h
+
+
+class _BottleneckFn(torch.autograd.Function):
+    """lib/nets/resnet.py:98-127 as one node: three (four with the projection shortcut) fused conv launches forward;
+    backward walks them in reverse and accumulates the two gradients of the block input inside the last
+    data-gradient launch."""
+
+    @staticmethod
+    def forward(ctx, x, block, use_bn, *weights):
+        p1 = prepared_conv(block.conv1, block.bn1, use_bn)
+        p2 = prepared_conv(block.conv2, block.bn2, use_bn)
+        p3 = prepared_conv(block.conv3, block.bn3, use_bn)
+        s1, _ = _stride_pad(block.conv1)
+        s2, _ = _stride_pad(block.conv2)
+        if block.downsample is not None:
+            pd = prepared_conv(block.downsample[0], block.downsample[1], True)
+            sd, _ = _stride_pad(block.downsample[0])
+            identity = ops.conv2d_nhwc(x, pd[0], pd[1], pd[2], None, stride=sd, pad=0, relu=False)
+        else:
+            pd, sd, identity = None, 1, x
+        o1 = ops.conv2d_nhwc(x, p1[0], p1[1], p1[2], None, stride=s1, pad=0, relu=True)
+        o2 = ops.conv2d_nhwc(o1, p2[0], p2[1], p2[2], None, stride=s2, pad=1, relu=True)
+        out = ops.conv2d_nhwc(o2, p3[0], p3[1], p3[2], identity, stride=1, pad=0, relu=True)
+        ctx.block = block
+        ctx.meta = (p1, p2, p3, pd, s1, s2, sd)
+        ctx.save_for_backward(x, o1, o2, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, o1, o2, out = ctx.saved_tensors
+        blk = ctx.block
+        p1, p2, p3, pd, s1, s2, sd = ctx.meta
+        need_w = [w.requires_grad for w in (blk.conv1.weight, blk.conv2.weight, blk.conv3.weight)]
+        dz3, d_id = ops.act_bwd(dy.contiguous(), out, p3[1], relu=True, want_res=True)
+        dw3 = ops.conv2d_bwd_weight(o2, dz3, 1, 1)[0] if need_w[2] else None
+        d_o2 = ops.conv2d_bwd_data(dz3, _transposed_filter(blk.conv3, p3[0]), tuple(o2.shape))
+        dz2, _ = ops.act_bwd(d_o2, o2, p2[1], relu=True)
+        dw2 = ops.conv2d_bwd_weight(o1, dz2, 3, 3, stride=s2, pad=1)[0] if need_w[1] else None
+        d_o1 = ops.conv2d_bwd_data(dz2, _transposed_filter(blk.conv2, p2[0]), tuple(o1.shape), stride=s2, pad=1)
+        dz1, _ = ops.act_bwd(d_o1, o1, p1[1], relu=True)
+        dw1 = ops.conv2d_bwd_weight(x, dz1, 1, 1, stride=s1)[0] if need_w[0] else None
+        dwd = None
+        dx = None
+        if pd is not None:
+            dzd, _ = ops.act_bwd(d_id, None, pd[1], relu=False)
+            if blk.downsample[0].weight.requires_grad:
+                dwd = ops.conv2d_bwd_weight(x, dzd, 1, 1, stride=sd)[0]
+            if ctx.needs_input_grad[0]:
+                dx = ops.conv2d_bwd_data(dzd, _transposed_filter(blk.downsample[0], pd[0]), tuple(x.shape), stride=sd)
+                dx = ops.conv2d_bwd_data(dz1, _transposed_filter(blk.conv1, p1[0]), tuple(x.shape), stride=s1, add=dx)
+        elif ctx.needs_input_grad[0]:
+            dx = ops.conv2d_bwd_data(dz1, _transposed_filter(blk.conv1, p1[0]), tuple(x.shape), stride=s1, add=d_id)
+        grads = [None if g is None else _param_grad_from_krsc(g, w) for g, w in
+                 ((dw1, blk.conv1.weight), (dw2, blk.conv2.weight), (dw3, blk.conv3.weight))]
+        if pd is not None:
+            grads.append(None if dwd is None else _param_grad_from_krsc(dwd, blk.downsample[0].weight))
+        return (dx, None, None) + tuple(grads)
+
+
+def bottleneck_train(x, block):
+    """Differentiable Bottleneck (frozen BN).  Falls back to the plain inference launches when nothing in or below
+    the block needs a gradient."""
+    for bn in (block.bn1, block.bn2, block.bn3):
+        if block.batchnorm_en and bn.training:
+            raise NotImplementedError("BatchNorm with batch statistics is not on the HIP path")
+    weights = [block.conv1.weight, block.conv2.weight, block.conv3.weight]
+    if block.downsample is not None:
+        weights.append(block.downsample[0].weight)
+    return _BottleneckFn.apply(x, block, block.batchnorm_en, *weights)
+
+
+class _UpsampleAddFn(torch.autograd.Function):
+    """lib/nets/fpn.py:42-45."""
+
+    @staticmethod
+    def forward(ctx, x, lateral):
+        ctx.in_hw = (x.shape[1], x.shape[2])
+        return ops.upsample_bilinear_add(x, lateral)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        dx = ops.upsample_bilinear_bwd(dout, ctx.in_hw) if ctx.needs_input_grad[0] else None
+        return dx, (dout if ctx.needs_input_grad[1] else None)
+
+
+def upsample_add_train(x, lateral):
+    return _UpsampleAddFn.apply(x, lateral)
+
+
+class _MultiLevelRoIAlignFn(torch.autograd.Function):
+    """MultiScaleRoIAlign.forward (lib/utils/torchpoolers.py:137-200): every level writes the RoIs mapped to it."""
+
+    @staticmethod
+    def forward(ctx, rois, levels, meta, *feats):
+        pooled, scales, sampling = meta
+        out = torch.zeros((rois.shape[0], pooled, pooled, feats[0].shape[-1]), dtype=torch.float32, device=rois.device)
+        for lvl, (f, sc) in enumerate(zip(feats, scales)):
+            ops.roi_align_nhwc(f, rois, pooled, sc, sampling, level_of_roi=levels, level=lvl if levels is not None else -1,
+                               out=out)
+        ctx.meta = meta
+        ctx.shapes = [tuple(f.shape) for f in feats]
+        ctx.save_for_backward(rois, levels)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        rois, levels = ctx.saved_tensors
+        pooled, scales, sampling = ctx.meta
+        dout = dout.contiguous()
+        grads = []
+        for lvl, (shape, sc) in enumerate(zip(ctx.shapes, scales)):
+            if not ctx.needs_input_grad[3 + lvl]:
+                grads.append(None)
+                continue
+            grads.append(ops.roi_align_bwd(dout, shape, rois, sc, sampling, level_of_roi=levels,
+                                           level=lvl if levels is not None else -1))
+        return (None, None, None) + tuple(grads)
+
+
+def roi_align_train(feats, rois, levels, pooled, scales, sampling):
+    return _MultiLevelRoIAlignFn.apply(rois, levels, (pooled, tuple(scales), sampling), *feats)
+
+
+class _RpnLossFn(torch.autograd.Function):
+    """cross_entropy over labelled anchors + smooth_l1_loss('RPN', ...) on the fused RPN head output."""
+
+    @staticmethod
+    def forward(ctx, rpn2d, labels, targets, inside, outside, num_anchors):
+        losses, drpn = ops.rpn_loss(rpn2d, num_anchors, labels, targets, inside, outside, 1.0, 1.0, want_grad=True)
+        ctx.a = num_anchors
+        ctx.save_for_backward(drpn)
+        return losses[:2].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (drpn,) = ctx.saved_tensors
+        a = ctx.a
+        d = drpn.clone()
+        d[:, :2 * a] *= g[0]          # cross-entropy gradient lives in the logit columns,
+        d[:, 2 * a:6 * a] *= g[1]     # the box-loss gradient in the delta columns
+        return d, None, None, None, None, None
+
+
+def rpn_loss_train(rpn2d, labels, targets, inside, outside, num_anchors):
+    return _RpnLossFn.apply(rpn2d, labels, targets, inside, outside, num_anchors)
+
+
+class _DetLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cls_score, bbox_pred, labels, targets, inside, outside):
+        losses, dcls, dbox = ops.det_loss(cls_score, labels, bbox_pred, targets, inside, outside, 4, 1.0, 1.0)
+        ctx.save_for_backward(dcls, dbox)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        dcls, dbox = ctx.saved_tensors
+        return dcls * g[0], dbox * g[1], None, None, None, None
+
+
+def det_loss_train(cls_score, bbox_pred, labels, targets, inside, outside):
+    return _DetLossFn.apply(cls_score.contiguous(), bbox_pred.contiguous(), labels, targets, inside, outside)

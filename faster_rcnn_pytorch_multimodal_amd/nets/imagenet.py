@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from ..model.config import cfg
 from ..utils.init_utils import normal_init, set_bn_eval, set_bn_fix, set_bn_train, set_bn_var
+from .fpn import fpn
 from .network import Network
 
 
@@ -62,6 +63,9 @@ class imagenet(Network):
         normal_init(self.rpn_net, 0, 0.01, cfg.TRAIN.TRUNCATED)
         if cfg.USE_FPN:
             self._fpn.init()
+        if cfg.ENABLE_CUSTOM_TAIL:
+            for m in (self.t_fc1, self.t_fc2, self.t_fc3):
+                normal_init(m, 0, 0.01, cfg.TRAIN.TRUNCATED)
         normal_init(self.rpn_cls_score_net, 0, 0.01, cfg.TRAIN.TRUNCATED)
         normal_init(self.rpn_bbox_pred_net, 0, 0.01, cfg.TRAIN.TRUNCATED)
         normal_init(self.cls_score_net, 0, 0.01, cfg.TRAIN.TRUNCATED)
@@ -79,8 +83,15 @@ class imagenet(Network):
                 p.requires_grad = False
         self.resnet.apply(set_bn_var if cfg.RESNET.FIXED_BLOCKS == -1 else set_bn_fix)
         if cfg.USE_FPN:
-            raise NotImplementedError("FPN image detector: see nets/fpn.py (not wired into Network yet)")
-        self._layers['head'] = _Head(self.resnet)
+            # imagenet.py:119-129: the pyramid is built from c2..c5, so layer4 belongs to the backbone here
+            self._fpn = fpn(planes=self._net_conv_channels)
+            self._layers['fpn'] = self._fpn
+            self._layers['fpn_downsample'] = nn.MaxPool2d(2)      # present upstream; unused on this path
+            self._layers['head'] = self.resnet.stem()
+            for i in (1, 2, 3, 4):
+                self._layers['layer%d' % i] = getattr(self.resnet, 'layer%d' % i)
+        else:
+            self._layers['head'] = _Head(self.resnet)
 
     def train(self, mode=True):
         nn.Module.train(self, mode)

@@ -25,14 +25,22 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..layer_utils.proposal_layer import proposal_layer_device
+from ..layer_utils.anchor_target_layer import anchor_target_layer_device
 from ..layer_utils.generate_3d_anchors import generate_anchors_3d
+from ..layer_utils.proposal_layer import proposal_layer_device
+from ..layer_utils.proposal_target_layer import proposal_target_layer_device
 from ..layer_utils.snippets import generate_anchors_pre
 from ..model.config import cfg
 from . import resnet as custom_resnet
+from .autograd_ops import (conv_bn_act_train, det_loss_train, fused_head_train, fused_head_weights, linear_train,
+                           roi_align_train, rpn_loss_train)
 from .hip_modules import conv_bn_act, pad4, to_nchw_view, to_nhwc
 
 ROI_ALIGN_SAMPLING_RATIO = 0
+# FPN choices the missing network.py leaves open (DESIGN.md "reconstructed contract"):
+FPN_RPN_LEVEL = 0                 # the RPN runs on p2 only (_feat_stride = 4, lib/nets/imagenet.py:34)
+FPN_POOL_LEVELS = (2, 5)          # MultiScaleRoIAlign over p2..p5 (k_min, k_max of LevelMapper)
+CUSTOM_TAIL_WIDTH = None          # t_fc1: P*P*C -> _fc7_channels, t_fc2 / t_fc3: _fc7_channels -> _fc7_channels
 
 
 class Network(nn.Module):
@@ -80,6 +88,15 @@ class Network(nn.Module):
         # detection heads: lib/nets/imagenet.py:85-86
         self.cls_score_net = nn.Linear(self._det_net_channels, self._num_classes)
         self.bbox_pred_net = nn.Linear(self._det_net_channels, self._num_classes * self._bbox_elem())
+        if cfg.ENABLE_CUSTOM_TAIL:
+            # names from lib/nets/imagenet.py:70-73; ReLU MLP P*P*C -> fc7 -> fc7 -> fc7 (sizes: see module docstring)
+            width = CUSTOM_TAIL_WIDTH or self._fc7_channels
+            self.t_fc1 = nn.Linear(self._roi_pooling_channels, width)
+            self.t_fc2 = nn.Linear(width, width)
+            self.t_fc3 = nn.Linear(width, self._fc7_channels)
+        elif getattr(self, '_fpn_en', False):
+            raise NotImplementedError("the FPN detector needs cfg.ENABLE_CUSTOM_TAIL (layer4 is part of its backbone); "
+                                      "tools/trainval_net.py:326-330 sets both")
         self.init_weights()
 
     def _build_resnet(self):
@@ -102,7 +119,18 @@ class Network(nn.Module):
     # forward pieces (reference names).  Public tensors are NCHW-shaped views of NHWC storage.
     # ------------------------------------------------------------------------------------------
     def _image_to_head(self):
-        net_conv = self._layers['head'](to_nhwc(self._image))
+        x = to_nhwc(self._image)
+        if getattr(self, '_fpn_en', False):
+            c1 = self._layers['head'](x)
+            c2 = self._layers['layer1'](c1)
+            c3 = self._layers['layer2'](c2)
+            c4 = self._layers['layer3'](c3)
+            c5 = self._layers['layer4'](c4)
+            self._pyramid = list(self._layers['fpn'](c2, c3, c4, c5))          # p2, p3, p4, p5 (NHWC)
+            net_conv = self._pyramid[FPN_RPN_LEVEL]
+        else:
+            self._pyramid = None
+            net_conv = self._layers['head'](x)
         self._act_summaries['conv'] = net_conv
         return to_nchw_view(net_conv)
 
@@ -127,20 +155,17 @@ class Network(nn.Module):
         return anchors
 
     def _fused_rpn_head(self):
-        """rpn_cls_score_net and rpn_bbox_pred_net share their input, so they run as ONE 1x1 conv with
-        the filters concatenated: output channels [0,2A) = class logits, [2A,6A) = box deltas."""
-        cls_net, box_net = self.rpn_cls_score_net, self.rpn_bbox_pred_net
-        key = tuple((t._version, t.data_ptr()) for t in (cls_net.weight, cls_net.bias, box_net.weight, box_net.bias))
-        if self._rpn_fused is None or self._rpn_fused[0] != key:
-            with torch.no_grad():
-                w = torch.cat((cls_net.weight.detach(), box_net.weight.detach()), 0)       # (6A, C, 1, 1)
-                w_krsc = w.permute(0, 2, 3, 1).contiguous()
-                b = torch.cat((cls_net.bias.detach(), box_net.bias.detach()), 0).contiguous()
-            self._rpn_fused = (key, w_krsc, b)
-        return self._rpn_fused[1], self._rpn_fused[2]
+        """rpn_cls_score_net and rpn_bbox_pred_net share their input, so they run as ONE 1x1 conv with the filters
+        concatenated and zero-padded to a multiple of 4 outputs: channels [0,2A) = class logits, [2A,6A) = box
+        deltas, [6A, ld) = padding (never read)."""
+        return fused_head_weights(self, self.rpn_cls_score_net, self.rpn_bbox_pred_net, '_rpn_fused_cache')
 
     def _rpn_head(self, net_conv_nhwc):
-        """relu(rpn_net) then the fused cls+bbox 1x1.  Returns (H, W, 6A) NHWC logits|deltas."""
+        """relu(rpn_net) then the fused cls+bbox 1x1.  Returns (1, H, W, ld >= 6A) NHWC logits|deltas."""
+        if torch.is_grad_enabled():
+            rpn = conv_bn_act_train(net_conv_nhwc, self.rpn_net, None, relu=True)
+            self._act_summaries['rpn'] = rpn
+            return fused_head_train(rpn, self, self.rpn_cls_score_net, self.rpn_bbox_pred_net, '_rpn_fused_cache')
         rpn = conv_bn_act(net_conv_nhwc, self.rpn_net, None, relu=True)
         self._act_summaries['rpn'] = rpn
         w, b = self._fused_rpn_head()
@@ -156,9 +181,10 @@ class Network(nn.Module):
         key = 'TRAIN' if self._mode == 'TRAIN' else 'TEST'
         if cfg[key].get('MODE', 'nms') != 'nms' and key == 'TEST':
             raise NotImplementedError("TEST.MODE='top' (proposal_top_layer) is not on the HIP path")
-        res = proposal_layer_device(self._anchors, self._info, self._num_anchors, cfg[key].RPN_PRE_NMS_TOP_N,
-                                    cfg[key].RPN_POST_NMS_TOP_N, cfg[key].RPN_NMS_THRESH,
-                                    rpn=rpn_out.view(h * w, rpn_out.shape[-1]))
+        with torch.no_grad():   # proposals carry no gradient (proposal_layer.py works on detached scores/deltas)
+            res = proposal_layer_device(self._anchors, self._info, self._num_anchors, cfg[key].RPN_PRE_NMS_TOP_N,
+                                        cfg[key].RPN_POST_NMS_TOP_N, cfg[key].RPN_NMS_THRESH,
+                                        rpn=rpn_out.detach().view(h * w, rpn_out.shape[-1]))
         self._predictions['rpn_out'] = rpn_out
         self._predictions['rpn_scores'] = res.scores
         self._predictions['rpn_proposals'] = res.proposals
@@ -173,10 +199,26 @@ class Network(nn.Module):
             self._predictions['roi_anchors_3d'] = ops.gather_rows(a3_sorted, res.keep_idx, res.count)
         return res.rois
 
+    def _pyramid_scales(self):
+        """MultiScaleRoIAlign.infer_scale (lib/utils/torchpoolers.py:107-117): 2 ** round(log2(feat / image))."""
+        img_h = float(self._image.shape[2])
+        return [2.0 ** float(np.round(np.log2(float(f.shape[1]) / img_h))) for f in self._pyramid]
+
     def _crop_pool_layer(self, bottom, rois):
-        """RoIAlign 7x7 (POOLING_MODE 'align', lib/model/config.py:364).  (R, C, 7, 7) NCHW-shaped."""
-        pooled = ops.roi_align_nhwc(to_nhwc(bottom), rois.contiguous(), cfg.POOLING_SIZE, 1.0 / self._feat_stride,
-                                    ROI_ALIGN_SAMPLING_RATIO, roi_count=self._predictions.get('rois_count'))
+        """RoIAlign 7x7: single level for POOLING_MODE 'align' (lib/model/config.py:364); over p2..p5 with the FPN
+        level heuristic for 'multiscale' (lib/utils/torchpoolers.py:137-200).  (R, C, 7, 7) NCHW-shaped."""
+        rois = rois.contiguous()
+        if self._pyramid is not None and cfg.POOLING_MODE == 'multiscale':
+            levels = ops.fpn_level_map(rois, FPN_POOL_LEVELS[0], FPN_POOL_LEVELS[1])
+            self._predictions['roi_levels'] = levels
+            pooled = roi_align_train(self._pyramid, rois, levels, cfg.POOLING_SIZE, self._pyramid_scales(),
+                                     ROI_ALIGN_SAMPLING_RATIO)
+        elif torch.is_grad_enabled() and bottom.requires_grad:
+            pooled = roi_align_train([to_nhwc(bottom)], rois, None, cfg.POOLING_SIZE, [1.0 / self._feat_stride],
+                                     ROI_ALIGN_SAMPLING_RATIO)
+        else:
+            pooled = ops.roi_align_nhwc(to_nhwc(bottom), rois, cfg.POOLING_SIZE, 1.0 / self._feat_stride,
+                                        ROI_ALIGN_SAMPLING_RATIO, roi_count=self._predictions.get('rois_count'))
         return to_nchw_view(pooled)
 
     def _layer4(self, pool5_nhwc):
@@ -191,7 +233,18 @@ class Network(nn.Module):
             roi_anchors_3d=self._predictions.get('roi_anchors_3d') if key == 'LIDAR' else None)
 
     def _head_to_tail(self, pool5):
-        """layer4 on the pooled RoIs then ``.mean(3).mean(2)`` -> fc7 (R, 2048)."""
+        """Without FPN: layer4 on the pooled RoIs then ``.mean(3).mean(2)`` -> fc7 (R, 2048).
+        With the custom tail (FPN): relu(t_fc1) -> relu(t_fc2) -> relu(t_fc3) on the flattened (C,7,7) RoI features;
+        the NHWC flattening is absorbed into a column permutation of t_fc1's weight."""
+        if cfg.ENABLE_CUSTOM_TAIL:
+            x = to_nhwc(pool5)
+            r, p, _, c = x.shape
+            h = linear_train(x.reshape(r, p * p * c), self.t_fc1, relu=True, weight_nhwc_from=(c, p))
+            h = linear_train(h, self.t_fc2, relu=True)
+            return linear_train(h, self.t_fc3, relu=True)
+        if torch.is_grad_enabled():
+            raise NotImplementedError("training the layer4 tail (non-FPN detector) is not on the HIP path yet; "
+                                      "use USE_FPN + ENABLE_CUSTOM_TAIL (tools/trainval_net.py:326-330)")
         y = self._layer4(to_nhwc(pool5))
         out = self._tail_kernel(y, self._predictions['rois'])
         self._predictions['_tail'] = out
@@ -199,6 +252,14 @@ class Network(nn.Module):
 
     def _region_classification(self, fc7):
         """cls_score_net + softmax, bbox_pred_net.  Returns (cls_prob, bbox_pred) like the ancestor."""
+        if torch.is_grad_enabled() and self._mode == 'TRAIN':
+            r, c = fc7.shape
+            k, e = self._num_classes, self._bbox_elem()
+            out = fused_head_train(fc7.view(r, 1, 1, c), self, self.cls_score_net, self.bbox_pred_net,
+                                   '_det_fused_cache').view(r, -1)
+            self._predictions['cls_score'] = out[:, :k]
+            self._predictions['bbox_pred'] = out[:, k:k + k * e]
+            return None, self._predictions['bbox_pred']
         tail = self._predictions.get('_tail')
         if tail is None or tail['fc7'] is not fc7:
             r, c = fc7.shape
@@ -212,16 +273,52 @@ class Network(nn.Module):
     def _predict(self):
         net_conv = self._image_to_head()
         rois = self._region_proposal(net_conv)
+        if self._mode == 'TRAIN':
+            rois = self._training_targets(rois)
         pool5 = self._crop_pool_layer(net_conv, rois)
         fc7 = self._head_to_tail(pool5)
         cls_prob, bbox_pred = self._region_classification(fc7)
         return rois, cls_prob, bbox_pred
 
+    # ------------------------------------------------------------------------------------------
+    # training: targets and losses (anchor_target_layer.py, proposal_target_layer.py, loss_utils.py; _add_losses of
+    # the missing network.py restated from the ancestor: the four terms are summed with unit weights)
+    # ------------------------------------------------------------------------------------------
+    def _training_targets(self, rois):
+        """RPN anchor targets + second-stage RoI sampling.  ``self._target_override`` (tests) injects precomputed
+        targets: dict(anchor=(labels, targets, inside, outside), proposal=dict(rois, labels, targets, inside, outside))."""
+        ov = getattr(self, '_target_override', None) or {}
+        with torch.no_grad():
+            if 'anchor' in ov:
+                self._anchor_targets = dict(zip(('labels', 'targets', 'inside', 'outside'), ov['anchor']))
+            else:
+                lab, tgt, inw, outw, counts = anchor_target_layer_device(self._gt_boxes, self._info, self._anchors)
+                self._anchor_targets = {'labels': lab, 'targets': tgt, 'inside': inw, 'outside': outw, 'counts': counts}
+            if 'proposal' in ov:
+                self._proposal_targets = dict(ov['proposal'])
+            else:
+                p = self._predictions
+                self._proposal_targets = proposal_target_layer_device(p['rois'], p['roi_scores'], self._gt_boxes,
+                                                                      self._num_classes, roi_count=p['rois_count'])
+        self._predictions['rois_sampled'] = self._proposal_targets['rois']
+        self._predictions['rois_count'] = None            # every sampled row is live
+        return self._proposal_targets['rois']
+
+    def _add_losses(self):
+        p, at, pt = self._predictions, self._anchor_targets, self._proposal_targets
+        rpn_out = p['rpn_out']
+        hw, ld = rpn_out.shape[1] * rpn_out.shape[2], rpn_out.shape[3]
+        rpn_l = rpn_loss_train(rpn_out.view(hw, ld), at['labels'], at['targets'], at['inside'], at['outside'],
+                               self._num_anchors)
+        det_l = det_loss_train(p['cls_score'], p['bbox_pred'], pt['labels'], pt['targets'], pt['inside'], pt['outside'])
+        self._losses = {'rpn_cross_entropy': rpn_l[0], 'rpn_loss_box': rpn_l[1], 'cross_entropy': det_l[0],
+                        'loss_box': det_l[1]}
+        self._losses['total_loss'] = rpn_l[0] + rpn_l[1] + det_l[0] + det_l[1]
+        return self._losses['total_loss']
+
     def forward(self, image, info, gt_boxes=None, gt_boxes_dc=None, mode='TRAIN'):
         """image: (1,H,W,C) float32 numpy blob (lib/roi_data_layer/minibatch.py:670) or device tensor of
         that layout; info: 7-vector [x_min,x_max,y_min,y_max,z_min,z_max,scale]."""
-        if mode != 'TEST':
-            raise NotImplementedError("training forward/backward is not on the HIP path yet")
         dev = torch.device(self._device)
         if dev.type != 'cuda':
             raise RuntimeError("faster_rcnn_pytorch_multimodal_amd runs on the MI355X only (net._device=%r); "
@@ -235,7 +332,17 @@ class Network(nn.Module):
         self._image = to_nchw_view(ops.pad_channels(image.contiguous(), pad4(image.shape[-1])))
         self._mode = mode
         self._predictions = {}
-        return self._predict()
+        if mode == 'TEST':
+            with torch.no_grad():
+                return self._predict()
+        if cfg.NET_TYPE != 'image':
+            raise NotImplementedError("training the LiDAR detector is not on the HIP path yet")
+        gt = np.asarray(gt_boxes, dtype=np.float32) if not isinstance(gt_boxes, torch.Tensor) else gt_boxes
+        self._gt_boxes = (torch.from_numpy(np.ascontiguousarray(gt)) if isinstance(gt, np.ndarray) else gt).to(
+            dev, dtype=torch.float32)
+        out = self._predict()
+        self._add_losses()
+        return out
 
     # ------------------------------------------------------------------------------------------
     # inference entry point used by lib/model/test.py:75
@@ -243,17 +350,36 @@ class Network(nn.Module):
     def test_frame(self, data, info):
         """Returns (cls_score, cls_prob, pred_boxes, rois, uncertainties) as device tensors with exactly
         ``n`` = number of proposals rows (one host sync to read n), like the reference."""
-        with torch.no_grad():
-            self.forward(data, info, None, None, mode='TEST')
+        self.forward(data, info, None, None, mode='TEST')
         p = self._predictions
         n = int(p['rois_count'].item())
         return p['cls_score'][:n], p['cls_prob'][:n], p['pred_boxes'][:n], p['rois'][:n], {}
 
+    def _clip_gradients(self):
+        """Per-element clamp to +-cfg.GRAD_MAX_CLIP (lib/model/config.py:338; the ancestor clips by value)."""
+        clip = float(cfg.GRAD_MAX_CLIP)
+        for prm in self.parameters():
+            if prm.grad is not None:
+                prm.grad.clamp_(-clip, clip)
+
     def train_step(self, blobs, optimizer, update_weights=False):
-        raise NotImplementedError("training step is not on the HIP path yet")
+        """One forward/backward on a frame (lib/model/train_val.py:458).  Gradients accumulate over calls and the
+        optimizer steps only when ``update_weights`` (pseudo-batching, train_val.py:379-382).  Returns the loss."""
+        self.forward(blobs['data'], blobs['info'], blobs['gt_boxes'], blobs.get('gt_boxes_dc'), mode='TRAIN')
+        loss = self._losses['total_loss']
+        loss.backward()
+        if update_weights:
+            self._clip_gradients()
+            optimizer.step()
+            optimizer.zero_grad()
+        value = float(loss.item())
+        self._predictions = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in self._predictions.items()}
+        return value
 
     def train_step_with_summary(self, blobs, optimizer, sum_size, update_weights=False):
-        raise NotImplementedError("training step is not on the HIP path yet")
+        """Same step; the summary list carries the four loss terms instead of tensorboard protobufs."""
+        loss = self.train_step(blobs, optimizer, update_weights)
+        return loss, [(k, float(v.item())) for k, v in self._losses.items()]
 
     def run_eval(self, blobs, batch_size, update_summaries=False):
         raise NotImplementedError("validation step is not on the HIP path yet")

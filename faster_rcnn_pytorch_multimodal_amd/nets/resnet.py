@@ -9,6 +9,7 @@ layer4 runs at stride 1 (resnet.py:236-238); with FPN layer4[0] keeps stride 2 o
 Every conv is fused with its folded BatchNorm, the residual add and the ReLU in one kernel launch.
 Tensors between modules are NHWC.
 """
+import torch
 import torch.nn as nn
 
 from ..model.config import cfg
@@ -29,7 +30,13 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.batchnorm_en = batchnorm_en
 
+    def _needs_grad(self, x):
+        return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+
     def forward(self, x):
+        if self._needs_grad(x):
+            from .autograd_ops import bottleneck_train     # one autograd node per block, HIP kernels both ways
+            return bottleneck_train(x, self)
         bn = self.batchnorm_en
         if self.downsample is not None:
             identity = conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)

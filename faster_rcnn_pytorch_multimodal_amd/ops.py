@@ -531,3 +531,13 @@ def proposal_target_layer(rois, roi_scores, gt_boxes, num_classes, rois_per_fram
         _ptr(out["targets"]), _ptr(out["inside"]), _ptr(out["outside"]), _ptr(out["assign"]), _ptr(out["counts"]),
         _stream()), "frcnn_proposal_target_layer")
     return out
+
+
+def fpn_level_map(rois, k_min, k_max, canonical_scale=224.0, canonical_level=4.0, eps=1e-6):
+    """rois (R,5) -> int32 (R,) pyramid level relative to k_min (LevelMapper, torchpoolers.py:39-51)."""
+    lib = _hip.load()
+    _dev_f32(rois, "rois")
+    levels = torch.empty((rois.shape[0],), dtype=torch.int32, device=rois.device)
+    _hip.check(lib.frcnn_fpn_level_map(_ptr(rois), rois.shape[0], int(k_min), int(k_max), float(canonical_scale),
+                                       float(canonical_level), float(eps), _ptr(levels), _stream()), "frcnn_fpn_level_map")
+    return levels

@@ -159,6 +159,11 @@ int frcnn_roi_align_fwd(const float* feat, int h, int w, int c, const float* roi
                         int num_rois, int pooled, float spatial_scale, int sampling_ratio,
                         const int* level_of_roi, int level, float* out, void* stream);
 
+/* LevelMapper (lib/utils/torchpoolers.py:20-51) of MultiScaleRoIAlign: levels[i] = clamp(floor(canonical_level +
+ * log2(sqrt(area_i) / canonical_scale) + eps), k_min, k_max) - k_min for rois (n,5); area without +1. */
+int frcnn_fpn_level_map(const float* rois, int num_rois, int k_min, int k_max, float canonical_scale,
+                        float canonical_level, float eps, int* levels, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Detection tail (_head_to_tail mean + _region_classification + test-time decode of network.py;
  * evidence lib/model/test.py:75-79, lib/model/config.py:219-223):

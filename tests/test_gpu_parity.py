@@ -438,7 +438,8 @@ def test_detector_stagewise_against_oracle(hip):
     a = 25
     rpn_out = p["rpn_out"].cpu()
     _close_feat(rpn_out[..., :2 * a].permute(0, 3, 1, 2).numpy(), d["rpn_cls_score"].numpy(), "rpn_cls_score", 1e-4)
-    _close_feat(rpn_out[..., 2 * a:].numpy(), d["rpn_bbox_pred"].numpy(), "rpn_bbox_pred", 1e-4)
+    _close_feat(rpn_out[..., 2 * a:6 * a].numpy(), d["rpn_bbox_pred"].numpy(), "rpn_bbox_pred", 1e-4)
+    assert rpn_out.shape[-1] == 152 and (rpn_out[..., 6 * a:] == 0).all()      # padded to a multiple of 4 outputs
     # proposal stage on the oracle's probabilities/deltas: bit-exact choice, boxes within 1e-4
     fg = d["rpn_cls_prob"][..., a:].contiguous().view(-1).to(DEV)
     res = proposal_layer_device(d["anchors"].to(DEV), info, a, 6000, 300, 0.7, rpn_cls_prob_fg=fg,
@@ -893,3 +894,121 @@ def test_proposal_target_layer_sampling_properties(hip):
     cnt_dev = torch.tensor([150], dtype=torch.int32, device=DEV)
     out3 = ops.proposal_target_layer(rois.to(DEV), None, gt.to(DEV), *args, seed=5, roi_count=cnt_dev)
     assert out3["counts"].cpu().tolist() == [256, 0, 150, 0]
+
+
+# ------------------------------------------------------------------------------------------------
+# FPN detector: forward + backward of one training step (BASELINE config 4)
+# ------------------------------------------------------------------------------------------------
+def _build_fpn_pair(seed=21):
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.nets.imagenet import imagenet
+    C.reset_cfg()
+    C.cfg.NET_TYPE = "image"
+    C.cfg.USE_FPN = True
+    C.cfg.POOLING_MODE = "multiscale"
+    C.cfg.ENABLE_CUSTOM_TAIL = True                     # tools/trainval_net.py:326-330
+    oracle = O.FpnNetOracle(num_classes=2)
+    sd = O.seeded_state_dict(oracle, seed, bn_mode="tame")
+    oracle.load_state_dict(sd, strict=True)
+    oracle.set_trainable(1)
+    net = imagenet(num_layers=101)
+    net.create_architecture(2, tag="default", anchor_scales=C.cfg.ANCHOR_SCALES, anchor_ratios=C.cfg.ANCHOR_RATIOS)
+    assert set(net.state_dict().keys()) == set(sd.keys())
+    net.load_state_dict(sd, strict=True)
+    net._device = DEV
+    net.to(DEV)
+    return net, oracle
+
+
+def _fpn_case():
+    rng = np.random.default_rng(5)
+    data = (rng.standard_normal((1, 256, 320, 3)) * 50).astype(np.float32)
+    info = np.array([0, 320, 0, 256, 0, 0, 1.0], np.float32)
+    gt = np.array([[20, 30, 69, 79, 1], [100, 20, 219, 139, 1], [60, 10, 299, 249, 1], [200, 150, 260, 230, 1]], np.float32)
+    g = torch.Generator().manual_seed(2)
+    jit = torch.from_numpy(gt[:, :4])[torch.arange(120) % 4] + (torch.rand(120, 4, generator=g) - 0.5) * 12
+    rnd = _rand_boxes(380, g, extent=(320, 256), max_wh=200)
+    boxes = torch.cat((jit, rnd), 0)
+    boxes[:, 0::2] = boxes[:, 0::2].clamp(0, 319)
+    boxes[:, 1::2] = boxes[:, 1::2].clamp(0, 255)
+    rois = torch.cat((torch.zeros(len(boxes), 1), boxes), 1)
+    return data, info, gt, rois, torch.rand(len(boxes), 1, generator=g)
+
+
+def test_fpn_train_step_matches_oracle_autograd(hip):
+    """Same weights, same frame, same sampled targets (injected from the oracle so the RNG streams do not matter):
+    pyramid, RoI features, the four losses and the parameter gradients must agree with torch-CPU autograd."""
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    net, oracle = _build_fpn_pair()
+    data, info, gt, rois, scores = _fpn_case()
+    losses, d = oracle.train_forward(data, info, gt, generator=torch.Generator().manual_seed(3), proposals=(rois, scores))
+    losses["total_loss"].backward()
+    assert int((d["labels"] > 0).sum()) >= 20 and len(torch.unique(d["levels"])) >= 3     # fg rows, several levels
+    net.train()
+    net._target_override = {
+        "anchor": tuple(d[k].contiguous().to(DEV) for k in ("anchor_labels", "anchor_targets", "anchor_inside", "anchor_outside")),
+        "proposal": {k: d[k].contiguous().to(DEV) for k in ("rois", "labels", "targets", "inside", "outside")}}
+    net.zero_grad()
+    net.forward(data, info, gt, None, mode="TRAIN")
+    for lvl in range(4):
+        _close_feat(net._pyramid[lvl].detach().cpu().permute(0, 3, 1, 2).numpy(), d["pyramid"][lvl].detach().numpy(),
+                    "p%d" % (lvl + 2), 5e-5)
+    np.testing.assert_array_equal(net._predictions["roi_levels"].cpu().numpy(), d["levels"].numpy())
+    _close_feat(net._predictions["cls_score"].detach().cpu().numpy(), d["cls_score"].detach().numpy(), "cls_score", 2e-4)
+    got = {k: float(v.item()) for k, v in net._losses.items()}
+    for k, v in losses.items():
+        assert abs(got[k] - float(v.item())) <= 2e-4 * max(1.0, abs(float(v.item()))), (k, got[k], float(v.item()))
+    net._losses["total_loss"].backward()
+    own = dict(net.named_parameters())
+    checked, worst = 0, 0.0
+    for name, p_ref in oracle.named_parameters():
+        p = own[name]
+        if not p_ref.requires_grad:
+            assert p.grad is None, name                                # frozen stem / layer1 / BatchNorm
+            continue
+        if name in ("_fpn.aalayer4.weight", "_fpn.aalayer4.bias"):     # defined but unused (fpn.py:39)
+            assert p.grad is None and p_ref.grad is None
+            continue
+        assert p.grad is not None and p_ref.grad is not None, name
+        # fp32 on both sides; a ReLU input within rounding noise of zero can flip its mask between the two paths
+        # and move a single filter's gradient by a visible amount, so the bar is on the L2 norm of the difference
+        ref = p_ref.grad.numpy().astype(np.float64)
+        diff = p.grad.cpu().numpy().astype(np.float64) - ref
+        rel = np.sqrt((diff ** 2).sum()) / (np.sqrt((ref ** 2).sum()) + 1e-30)
+        worst = max(worst, rel)
+        assert rel <= 5e-3, "grad %s: relative L2 error %.3e" % (name, rel)
+        assert np.abs(diff).max() <= 5e-2 * np.abs(ref).max() + 1e-8, "grad %s: max err %.3e" % (name, np.abs(diff).max())
+        checked += 1
+    assert checked == 121          # layer2..4 convs (93) + FPN (12) + RPN (6) + heads (4) + tail (6)
+    print("fpn train step: %d parameter gradients checked, worst relative L2 error %.2e" % (checked, worst))
+    C.reset_cfg()
+
+
+def test_fpn_train_step_end_to_end(hip):
+    """net.train_step with the device-side target layers and a torch SGD optimizer (lib/model/train_val.py:188-208,
+    379-382,458): gradients accumulate while update_weights is False, the optimizer steps and clears them when True."""
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    net, _ = _build_fpn_pair(seed=22)
+    data, info, gt, _, _ = _fpn_case()
+    net.train()
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=1e-3, momentum=C.cfg.TRAIN.MOMENTUM)
+    blobs = {"data": data, "info": info, "gt_boxes": gt, "gt_boxes_dc": np.zeros((0, 4), np.float32)}
+    torch.manual_seed(0)
+    w0 = net.rpn_net.weight.detach().clone()
+    l1 = net.train_step(blobs, opt, update_weights=False)
+    g1 = net.rpn_net.weight.grad.detach().clone()
+    assert np.isfinite(l1) and torch.equal(net.rpn_net.weight.detach(), w0) and g1.abs().max() > 0
+    at = net._anchor_targets
+    assert int((at["labels"] == 1).sum()) >= 4 and int((at["labels"] >= 0).sum()) == 256
+    assert net._proposal_targets["rois"].shape == (256, 5)
+    l2, summary = net.train_step_with_summary(blobs, opt, 1, update_weights=True)
+    assert np.isfinite(l2) and {k for k, _ in summary} >= {"rpn_cross_entropy", "rpn_loss_box", "cross_entropy", "loss_box"}
+    assert not torch.equal(net.rpn_net.weight.detach(), w0)            # stepped ...
+    assert net.rpn_net.weight.grad is None or float(net.rpn_net.weight.grad.abs().max()) == 0.0   # ... and cleared
+    assert net.resnet.conv1.weight.grad is None and net.resnet.layer1[0].conv1.weight.grad is None
+    # inference still works on the same module afterwards
+    net.eval()
+    _, cp, pb, rois, _ = net.test_frame(data, info)
+    assert cp.shape[1] == 2 and pb.shape == (rois.shape[0], 8)
+    C.reset_cfg()
