@@ -199,6 +199,183 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_topk_desc_kernel(const floa
   if (t == 0) count_out[0] = take;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Multi-workgroup form of the same top-k for large n (10^5 .. 10^6 scores: FPN / training RPN).  Same total
+// order and the same result as the single-workgroup kernel:
+//   3 x { topk_hist_kernel (all CUs: 11/11/10-bit digit histogram of the keys that still match the prefix)
+//         topk_pick_kernel (one wave: bucket holding the top_n-th key -> extends the prefix) }
+//   topk_count_eq_kernel  per-workgroup count of keys == kth over a contiguous index range
+//   topk_scan_eq_kernel   exclusive scan of those counts (ties are taken lowest index first)
+//   topk_compact_kernel   keys < kth (any slot) and the first need_eq ties (ordered slots) -> u64 candidates
+//   topk_final_sort_kernel  bitonic sort of the <= 16384 candidates in LDS, outputs in the canonical order
+// ------------------------------------------------------------------------------------------------
+constexpr int TOPK_BINS = 2048;
+constexpr int TOPK_BLOCK_ITEMS = 4096;  // scores per workgroup (256 threads x 16)
+
+struct TopkState {   // lives at the start of the workspace
+  uint32_t prefix;   // digits of the kth key decided so far (high bits)
+  uint32_t need;     // rank still to resolve inside the current prefix
+  uint32_t fill;     // slots handed out to keys < kth
+  uint32_t pad;
+  uint32_t hist[TOPK_BINS];
+};
+
+__device__ __forceinline__ void topk_pass_bits(int pass, int& shift, int& bits) {
+  shift = pass == 0 ? 21 : pass == 1 ? 10 : 0;
+  bits = pass == 2 ? 10 : 11;
+}
+
+__global__ __launch_bounds__(256) void topk_init_kernel(TopkState* st, int take) {
+  for (int i = threadIdx.x; i < TOPK_BINS; i += 256) st->hist[i] = 0;
+  if (threadIdx.x == 0) { st->prefix = 0; st->need = (uint32_t)take; st->fill = 0; st->pad = 0; }
+}
+
+__global__ __launch_bounds__(256) void topk_hist_kernel(const float* __restrict__ scores, int n, int pass,
+                                                       TopkState* __restrict__ st) {
+  __shared__ uint32_t h[TOPK_BINS];
+  for (int i = threadIdx.x; i < TOPK_BINS; i += 256) h[i] = 0;
+  __syncthreads();
+  int shift, bits;
+  topk_pass_bits(pass, shift, bits);
+  const uint32_t prefix = st->prefix;
+  const uint32_t himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + bits));
+  const int lo = blockIdx.x * TOPK_BLOCK_ITEMS, hi = min(lo + TOPK_BLOCK_ITEMS, n);
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+    const uint32_t k = desc_key(scores[i]);
+    if ((k & himask) == prefix) atomicAdd(&h[(k >> shift) & ((1u << bits) - 1u)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TOPK_BINS; i += 256)
+    if (h[i]) atomicAdd(&st->hist[i], h[i]);
+}
+
+__global__ __launch_bounds__(64) void topk_pick_kernel(TopkState* __restrict__ st, int pass) {
+  // one wave: lane l owns bins [32l, 32l+32); exclusive prefix over the lanes via shuffles, then the lane that
+  // contains the target rank walks its 32 bins
+  int shift, bits;
+  topk_pass_bits(pass, shift, bits);
+  const int lane = threadIdx.x;
+  uint32_t mine = 0;
+  for (int b = 0; b < 32; ++b) mine += st->hist[lane * 32 + b];
+  uint32_t incl = mine;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  const uint32_t excl = incl - mine, need = st->need;
+  uint32_t new_prefix = 0, new_need = 0;
+  const bool owner = need > excl && need <= incl;
+  if (owner) {
+    uint32_t acc = excl;
+    int b = 0;
+    for (; b < 32; ++b) {
+      const uint32_t c = st->hist[lane * 32 + b];
+      if (acc + c >= need) break;
+      acc += c;
+    }
+    new_prefix = st->prefix | ((uint32_t)(lane * 32 + b) << shift);
+    new_need = need - acc;
+  }
+  __syncthreads();   // single wave: orders the reads of hist above against the clears below
+  for (int b = 0; b < 32; ++b) st->hist[lane * 32 + b] = 0;
+  if (owner) { st->prefix = new_prefix; st->need = new_need; }
+}
+
+__global__ __launch_bounds__(256) void topk_count_eq_kernel(const float* __restrict__ scores, int n,
+                                                           const TopkState* __restrict__ st,
+                                                           uint32_t* __restrict__ block_eq) {
+  __shared__ uint32_t s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const uint32_t kth = st->prefix;
+  const int lo = blockIdx.x * TOPK_BLOCK_ITEMS, hi = min(lo + TOPK_BLOCK_ITEMS, n);
+  uint32_t c = 0;
+  for (int i = lo + threadIdx.x; i < hi; i += 256) c += desc_key(scores[i]) == kth ? 1u : 0u;
+  if (c) atomicAdd(&s_cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0) block_eq[blockIdx.x] = s_cnt;
+}
+
+__global__ __launch_bounds__(1024) void topk_scan_eq_kernel(uint32_t* __restrict__ block_eq, int nblocks) {
+  // exclusive scan in place (nblocks <= 16384 handled in chunks of 1024 with a running carry)
+  __shared__ uint32_t buf[1024];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += 1024) {
+    const int i = base + threadIdx.x;
+    const uint32_t v = i < nblocks ? block_eq[i] : 0u;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const uint32_t u = threadIdx.x >= off ? buf[threadIdx.x - off] : 0u;
+      __syncthreads();
+      buf[threadIdx.x] += u;
+      __syncthreads();
+    }
+    if (i < nblocks) block_eq[i] = carry + buf[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += buf[1023];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void topk_compact_kernel(const float* __restrict__ scores, int n, int take,
+                                                          TopkState* __restrict__ st,
+                                                          const uint32_t* __restrict__ block_eq_excl,
+                                                          uint64_t* __restrict__ cand) {
+  // thread t owns the contiguous range [lo + 16t, lo + 16t + 16): ties stay in index order
+  __shared__ uint32_t scan[256];
+  const uint32_t kth = st->prefix, need_eq = st->need;
+  const uint32_t base_eq = (uint32_t)take - need_eq;   // number of keys < kth
+  const int lo = blockIdx.x * TOPK_BLOCK_ITEMS + threadIdx.x * 16;
+  const int hi = min(lo + 16, min((blockIdx.x + 1) * TOPK_BLOCK_ITEMS, n));
+  uint32_t my_eq = 0;
+  for (int i = lo; i < hi; ++i) {
+    const uint32_t k = desc_key(scores[i]);
+    if (k < kth) {
+      const uint32_t pos = atomicAdd(&st->fill, 1u);
+      cand[pos] = ((uint64_t)k << 32) | (uint32_t)i;
+    } else if (k == kth) {
+      ++my_eq;
+    }
+  }
+  scan[threadIdx.x] = my_eq;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const uint32_t v = threadIdx.x >= off ? scan[threadIdx.x - off] : 0u;
+    __syncthreads();
+    scan[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t rank = block_eq_excl[blockIdx.x] + scan[threadIdx.x] - my_eq;
+  for (int i = lo; i < hi && rank < need_eq; ++i) {
+    const uint32_t k = desc_key(scores[i]);
+    if (k == kth) {
+      cand[base_eq + rank] = ((uint64_t)k << 32) | (uint32_t)i;
+      ++rank;
+    }
+  }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void topk_final_sort_kernel(const float* __restrict__ scores,
+                                                                       const uint64_t* __restrict__ cand, int take,
+                                                                       int npad, int64_t* __restrict__ order_out,
+                                                                       float* __restrict__ scores_out,
+                                                                       int* __restrict__ count_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sort_smem[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(sort_smem);
+  for (int i = threadIdx.x; i < npad; i += SORT_THREADS) keys[i] = i < take ? cand[i] : ~0ull;
+  __syncthreads();
+  block_bitonic_sort(keys, npad);
+  for (int i = threadIdx.x; i < take; i += SORT_THREADS) {
+    const uint32_t idx = (uint32_t)(keys[i] & 0xFFFFFFFFu);
+    order_out[i] = (int64_t)idx;
+    scores_out[i] = scores[idx];
+  }
+  if (threadIdx.x == 0) count_out[0] = take;
+}
+
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ rows,
                                                          const int64_t* __restrict__ order,
                                                          const int* __restrict__ count, int max_count, int width,
@@ -476,17 +653,61 @@ extern "C" int frcnn_rpn_decode_clip(const float* rpn, int ld, const float* prob
   return check_launch("rpn_decode_clip_kernel");
 }
 
+constexpr int TOPK_MULTI_MIN_N = 16384;   // below this one workgroup does everything in LDS
+
+static size_t topk_multi_layout(int n, size_t* off_blocks, size_t* off_cand) {
+  const size_t nblocks = ((size_t)n + TOPK_BLOCK_ITEMS - 1) / TOPK_BLOCK_ITEMS;
+  size_t o = align_up(sizeof(TopkState), 256);
+  *off_blocks = o;
+  o = align_up(o + nblocks * sizeof(uint32_t), 256);
+  *off_cand = o;
+  return o + (size_t)16384 * sizeof(uint64_t);
+}
+
 extern "C" size_t frcnn_sort_topk_desc_ws_bytes(int n, int top_n) {
-  (void)n; (void)top_n;
-  return 0;  // everything lives in LDS
+  if (n <= TOPK_MULTI_MIN_N || n <= top_n) return 0;   // everything lives in LDS
+  size_t a, b;
+  return topk_multi_layout(n, &a, &b);
 }
 
 extern "C" int frcnn_sort_topk_desc(const float* scores, int n, int top_n, int64_t* order_out, float* scores_out,
                                     int* count_out, void* ws, size_t ws_bytes, void* stream_) {
-  (void)ws; (void)ws_bytes;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
   FRCNN_REQUIRE(scores && order_out && scores_out && count_out && n > 0 && top_n > 0, "sort_topk_desc: bad arguments");
   FRCNN_REQUIRE(top_n <= 16384, "sort_topk_desc: top_n %d > 16384", top_n);
-  const int npad = next_pow2(std::max(std::min(n, top_n), 2));
+  const int take = std::min(n, top_n);
+  const int npad = next_pow2(std::max(take, 2));
+  if (n > TOPK_MULTI_MIN_N && n > top_n) {
+    size_t off_blocks, off_cand;
+    const size_t need = topk_multi_layout(n, &off_blocks, &off_cand);
+    if (!ws || ws_bytes < need) return fail(FRCNN_ERR_WS, "sort_topk_desc: workspace %zu < %zu bytes", ws_bytes, need);
+    char* base = static_cast<char*>(ws);
+    TopkState* st = reinterpret_cast<TopkState*>(base);
+    uint32_t* block_eq = reinterpret_cast<uint32_t*>(base + off_blocks);
+    uint64_t* cand = reinterpret_cast<uint64_t*>(base + off_cand);
+    const int nblocks = (n + TOPK_BLOCK_ITEMS - 1) / TOPK_BLOCK_ITEMS;
+    hipLaunchKernelGGL(topk_init_kernel, dim3(1), dim3(256), 0, stream, st, take);
+    for (int pass = 0; pass < 3; ++pass) {
+      hipLaunchKernelGGL(topk_hist_kernel, dim3(nblocks), dim3(256), 0, stream, scores, n, pass, st);
+      hipLaunchKernelGGL(topk_pick_kernel, dim3(1), dim3(64), 0, stream, st, pass);
+    }
+    hipLaunchKernelGGL(topk_count_eq_kernel, dim3(nblocks), dim3(256), 0, stream, scores, n, st, block_eq);
+    hipLaunchKernelGGL(topk_scan_eq_kernel, dim3(1), dim3(1024), 0, stream, block_eq, nblocks);
+    hipLaunchKernelGGL(topk_compact_kernel, dim3(nblocks), dim3(256), 0, stream, scores, n, take, st, block_eq, cand);
+    int rc = check_launch("topk multi-workgroup select");
+    if (rc != FRCNN_OK) return rc;
+    const size_t lds = (size_t)npad * 8;
+    static size_t configured_f = 0;
+    if (lds > configured_f) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_final_sort_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "sort_topk_desc: set LDS size: %s", hipGetErrorString(e));
+      configured_f = lds;
+    }
+    hipLaunchKernelGGL(topk_final_sort_kernel, dim3(1), dim3(SORT_THREADS), lds, stream, scores, cand, take, npad,
+                       order_out, scores_out, count_out);
+    return check_launch("topk_final_sort_kernel");
+  }
   const size_t lds = (size_t)npad * 8 + 256 * 4 + SORT_THREADS * 4;
   static size_t configured = 0;
   if (lds > configured) {
@@ -495,8 +716,8 @@ extern "C" int frcnn_sort_topk_desc(const float* scores, int n, int top_n, int64
     if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "sort_topk_desc: set LDS size: %s", hipGetErrorString(e));
     configured = lds;
   }
-  hipLaunchKernelGGL(sort_topk_desc_kernel, dim3(1), dim3(SORT_THREADS), lds, static_cast<hipStream_t>(stream_), scores,
-                     n, top_n, npad, order_out, scores_out, count_out);
+  hipLaunchKernelGGL(sort_topk_desc_kernel, dim3(1), dim3(SORT_THREADS), lds, stream, scores, n, top_n, npad, order_out,
+                     scores_out, count_out);
   return check_launch("sort_topk_desc_kernel");
 }
 

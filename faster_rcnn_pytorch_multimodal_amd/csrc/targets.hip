@@ -65,21 +65,33 @@ __global__ __launch_bounds__(256) void atl_overlap_kernel(const float* __restric
                                                          const float* __restrict__ gt, int g, AtlFrame fr,
                                                          float* __restrict__ max_ov, int* __restrict__ argmax,
                                                          unsigned* __restrict__ gt_max) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const float4 a4 = reinterpret_cast<const float4*>(anchors)[i];
-    const float a[4] = {a4.x, a4.y, a4.z, a4.w};
-    const bool inside = a[0] >= fr.x_lo && a[1] >= fr.y_lo && a[2] < fr.x_hi && a[3] < fr.y_hi;
+  // every lane of a wave runs the same number of iterations so the per-gt maxima can be reduced with wave
+  // shuffles before ONE atomicMax per wave and gt box (a per-lane atomic serialises ~10^6 anchors on G addresses)
+  const int stride = gridDim.x * blockDim.x;
+  const int iters = (n + stride - 1) / stride;
+  for (int it = 0; it < iters; ++it) {
+    const int i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      const float4 a4 = reinterpret_cast<const float4*>(anchors)[i];
+      a[0] = a4.x; a[1] = a4.y; a[2] = a4.z; a[3] = a4.w;
+    }
+    const bool inside = live && a[0] >= fr.x_lo && a[1] >= fr.y_lo && a[2] < fr.x_hi && a[3] < fr.y_hi;
     float best = -1.f;
     int arg = 0;
-    if (inside) {
-      for (int j = 0; j < g; ++j) {
-        const float ov = iou_plus1(a, gt + (size_t)j * 5);
-        if (ov > best) { best = ov; arg = j; }            // first maximum, like argmax(dim=1)
-        atomicMax(gt_max + j, __float_as_uint(ov));         // ov >= 0: the bit pattern orders like the value
-      }
+    for (int j = 0; j < g; ++j) {
+      const float ov = inside ? iou_plus1(a, gt + (size_t)j * 5) : 0.f;
+      if (inside && ov > best) { best = ov; arg = j; }      // first maximum, like argmax(dim=1)
+      float wmax = ov;
+      for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
+      if ((threadIdx.x & 63) == 0 && wmax > 0.f)
+        atomicMax(gt_max + j, __float_as_uint(wmax));       // ov >= 0: the bit pattern orders like the value
     }
-    max_ov[i] = inside ? best : -1.f;                      // -1 marks an anchor outside the frame
-    argmax[i] = arg;
+    if (live) {
+      max_ov[i] = inside ? best : -1.f;                     // -1 marks an anchor outside the frame
+      argmax[i] = arg;
+    }
   }
 }
 
@@ -271,7 +283,7 @@ int next_pow2(int v) {
 unsigned grid_for(size_t items, unsigned cap = 4096) { return (unsigned)std::min<size_t>((items + 255) / 256, cap); }
 
 struct AtlLayout {
-  size_t gt_max, counters, max_ov, argmax, key_fg, key_bg, keep_fg, keep_bg, order, sorted, sort_count, total;
+  size_t gt_max, counters, max_ov, argmax, key_fg, key_bg, keep_fg, keep_bg, order, sorted, sort_count, sort_ws, sort_ws_bytes, total;
 };
 AtlLayout atl_layout(int n, int g, int top_n) {
   AtlLayout l;
@@ -288,6 +300,8 @@ AtlLayout atl_layout(int n, int g, int top_n) {
   l.order = take((size_t)top_n * 8);
   l.sorted = take((size_t)top_n * 4);
   l.sort_count = take(16);
+  l.sort_ws_bytes = frcnn_sort_topk_desc_ws_bytes(n, top_n);
+  l.sort_ws = take(l.sort_ws_bytes);
   l.total = o;
   return l;
 }
@@ -350,7 +364,8 @@ extern "C" int frcnn_anchor_target_layer(const float* anchors, int n, const floa
   if (rpn_batchsize <= 16384) {
     // random sub-sampling: the `quota` candidates with the largest random keys survive
     for (int which = 0; which < 2; ++which) {
-      rc = frcnn_sort_topk_desc(which == 0 ? key_fg : key_bg, n, top_n, order, sorted, sort_count, nullptr, 0, stream_);
+      rc = frcnn_sort_topk_desc(which == 0 ? key_fg : key_bg, n, top_n, order, sorted, sort_count,
+                                l.sort_ws_bytes ? base + l.sort_ws : nullptr, l.sort_ws_bytes, stream_);
       if (rc != FRCNN_OK) return rc;
       hipLaunchKernelGGL(atl_mark_keep_kernel, dim3(grid_for((size_t)top_n)), dim3(256), 0, stream, order, sorted, top_n,
                          counters, which, rpn_batchsize, num_fg_cap, which == 0 ? keep_fg : keep_bg);

@@ -243,8 +243,10 @@ def sort_topk_desc(scores, top_n):
     order = torch.empty((m,), dtype=torch.int64, device=scores.device)
     sout = torch.empty((m,), dtype=torch.float32, device=scores.device)
     count = torch.empty((1,), dtype=torch.int32, device=scores.device)
-    _hip.check(lib.frcnn_sort_topk_desc(_ptr(scores), n, top_n, _ptr(order), _ptr(sout), _ptr(count), None, 0, _stream()),
-               "frcnn_sort_topk_desc")
+    ws_bytes = lib.frcnn_sort_topk_desc_ws_bytes(n, top_n)
+    ws = _workspace(ws_bytes, scores.device) if ws_bytes else None
+    _hip.check(lib.frcnn_sort_topk_desc(_ptr(scores), n, top_n, _ptr(order), _ptr(sout), _ptr(count), _ptr(ws), ws_bytes,
+                                        _stream()), "frcnn_sort_topk_desc")
     return order, sout, count
 
 

@@ -123,7 +123,8 @@ int frcnn_lidar_bbox_transform_inv(const float* rois, int roi_ld, const float* a
 
 /* scores.sort(descending=True)[:top_n] (proposal_layer.py:39-42) with the canonical total order
  * (score desc, index asc).  order_out[top_n] int64 source indices, scores_out[top_n];
- * count_out[0] = min(n, top_n).  top_n <= 16384. */
+ * count_out[0] = min(n, top_n).  top_n <= 16384.  n <= 16384: one workgroup in LDS; larger n: multi-workgroup
+ * radix select over all CUs (workspace from frcnn_sort_topk_desc_ws_bytes), same result. */
 size_t frcnn_sort_topk_desc_ws_bytes(int n, int top_n);
 int frcnn_sort_topk_desc(const float* scores, int n, int top_n, int64_t* order_out, float* scores_out,
                          int* count_out, void* ws, size_t ws_bytes, void* stream);

@@ -206,7 +206,8 @@ def _sort_case(name, n, gen):
 
 
 @pytest.mark.parametrize("name", ["random", "ties", "saturated", "constant", "signed"])
-@pytest.mark.parametrize("n,top", [(59850, 6000), (59850, 12000), (1100, 6000), (5000, 5000), (37, 16), (1, 300), (16385, 16384)])
+@pytest.mark.parametrize("n,top", [(59850, 6000), (59850, 12000), (1100, 6000), (5000, 5000), (37, 16), (1, 300), (16385, 16384),
+                                   (937500, 12000), (16384, 256), (20000, 1)])
 def test_sort_topk_order_bit_exact(hip, name, n, top):
     ops = _ops()
     s = _sort_case(name, n, torch.Generator().manual_seed(n + top))
