@@ -179,8 +179,8 @@ class Network(nn.Module):
         self._anchor_component(h, w)
         rpn_out = self._rpn_head(x)                                   # (1, H, W, 6A)
         key = 'TRAIN' if self._mode == 'TRAIN' else 'TEST'
-        if cfg[key].get('MODE', 'nms') != 'nms' and key == 'TEST':
-            raise NotImplementedError("TEST.MODE='top' (proposal_top_layer) is not on the HIP path")
+        if key == 'TEST' and cfg.TEST.get('MODE', 'nms') == 'top':
+            return self._proposal_top(rpn_out, h, w)
         with torch.no_grad():   # proposals carry no gradient (proposal_layer.py works on detached scores/deltas)
             res = proposal_layer_device(self._anchors, self._info, self._num_anchors, cfg[key].RPN_PRE_NMS_TOP_N,
                                         cfg[key].RPN_POST_NMS_TOP_N, cfg[key].RPN_NMS_THRESH,
@@ -198,6 +198,23 @@ class Network(nn.Module):
             a3_sorted = ops.gather_rows(self._anchors_3d, res.order, res.sorted_count)
             self._predictions['roi_anchors_3d'] = ops.gather_rows(a3_sorted, res.keep_idx, res.count)
         return res.rois
+
+    def _proposal_top(self, rpn_out, h, w):
+        """cfg.TEST.MODE == 'top' (lib/model/config.py:263): RPN_TOP_N best anchors, no NMS (proposal_top_layer.py)."""
+        from ..layer_utils.proposal_top_layer import proposal_top_layer
+        a = self._num_anchors
+        flat = rpn_out.detach().view(h * w, rpn_out.shape[-1])
+        zero_anchor = torch.zeros_like(self._anchors)
+        # 2-way softmax through the decode kernel (its box output is ignored here), then the reference-shaped call
+        fg_prob, _ = ops.rpn_decode_clip(zero_anchor, self._info, a, rpn=flat)
+        fgv = fg_prob.view(1, h, w, a)
+        prob = torch.cat((torch.zeros_like(fgv), fgv), 3)      # proposal_top_layer reads the fg half only (:26)
+        deltas = flat[:, 2 * a:6 * a].contiguous().view(1, h, w, 4 * a)
+        rois, scores, _ = proposal_top_layer(prob, deltas, self._info, self._anchors, a)
+        p = self._predictions
+        p['rpn_out'], p['rois'], p['roi_scores'] = rpn_out, rois, scores
+        p['rois_count'] = torch.full((1,), rois.shape[0], dtype=torch.int32, device=rois.device)
+        return rois
 
     def _pyramid_scales(self):
         """MultiScaleRoIAlign.infer_scale (lib/utils/torchpoolers.py:107-117): 2 ** round(log2(feat / image))."""

@@ -1013,3 +1013,19 @@ def test_fpn_train_step_end_to_end(hip):
     _, cp, pb, rois, _ = net.test_frame(data, info)
     assert cp.shape[1] == 2 and pb.shape == (rois.shape[0], 8)
     C.reset_cfg()
+
+
+def test_proposal_top_layer_against_reference_golden(hip, golden_dir):
+    """TEST.MODE == 'top' (lib/layer_utils/proposal_top_layer.py): same anchors picked in the same order; boxes to
+    the exp() rounding."""
+    from faster_rcnn_pytorch_multimodal_amd.layer_utils.proposal_top_layer import proposal_top_layer
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    C.reset_cfg()
+    C.cfg.TEST.RPN_TOP_N = 120
+    z = np.load(os.path.join(golden_dir, "lidar_train.npz"))
+    blob, sc, anc = proposal_top_layer(torch.from_numpy(z["top_prob"]).to(DEV), torch.from_numpy(z["top_deltas"]).to(DEV),
+                                       z["top_info"], torch.from_numpy(z["top_anchors"]).to(DEV), 25)
+    np.testing.assert_array_equal(anc.cpu().numpy(), z["top_sel_anchors"])
+    np.testing.assert_array_equal(sc.cpu().numpy(), z["top_scores"])
+    np.testing.assert_allclose(blob.cpu().numpy(), z["top_blob"], rtol=3e-7, atol=1e-4)
+    C.reset_cfg()
