@@ -63,6 +63,88 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   return base + (b >> 3);
 }
 
+// Epilogue shared by the conv kernels.  The MFMA operands are (weights, activations), so D has the PIXEL on the
+// lane (col = lane&31) and the CHANNEL in the registers: row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Registers
+// 4g..4g+3 are four consecutive channels -> every access is a 16-byte vector per lane, and all residual loads of a
+// 32x32 tile are issued before its first store.
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc,
+                                              int lane) {
+  // The MFMA operands are (weights, activations), so D has the PIXEL on the lane (col = lane&31) and
+  // the CHANNEL in the registers: row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Registers 4g..4g+3 are four
+  // consecutive channels -> every access of the epilogue is a 16-byte vector per lane, and all
+  // residual loads of a 32x32 tile are issued before its first store (res may alias nothing we
+  // write, but the compiler cannot know: batching keeps 4 loads in flight instead of a
+  // load->wait->store chain per element).
+  const int mlane = lane & 31, nhalf = 4 * (lane >> 5);
+  const bool vec = (p.K & 3) == 0;
+  float* const slab = p.partial ? p.partial + (size_t)blockIdx.z * p.M * p.K : nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + (wr * TM + i) * 32 + mlane;
+    if (m >= p.M) continue;
+    size_t orow = (size_t)m * p.K;  // row of y / residual
+    if (p.ys != 1) {
+      const int img = m / (p.Ho * p.Wo);
+      const int rem = m - img * p.Ho * p.Wo;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      orow = ((size_t)(img * p.Hy + ho * p.ys) * p.Wy + wo * p.ys) * p.K;
+    }
+#if defined(FRCNN_ABLATE) && (FRCNN_ABLATE & 4)
+    if (acc[i][0][0] != 123.456f) continue;
+#endif
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nb = n0 + (wc * TN + j) * 32 + nhalf;
+      const size_t row = (size_t)m * p.K;
+      if (vec) {
+        if (slab) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int n = nb + 8 * g;
+            if (n < p.K)
+              *reinterpret_cast<f32x4*>(slab + row + n) =
+                  f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          }
+          continue;
+        }
+        f32x4 rv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = nb + 8 * g;
+          rv[g] = (p.res && n < p.K) ? *reinterpret_cast<const f32x4*>(p.res + orow + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = nb + 8 * g;
+          if (n >= p.K) continue;
+          const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+          const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = acc[i][j][4 * g + e] * sc[e] + sh[e];
+            t += rv[g][e];
+            v[e] = p.relu ? fmaxf(t, 0.f) : t;
+          }
+          *reinterpret_cast<f32x4*>(p.y + orow + n) = v;
+        }
+      } else {
+        // K % 4 != 0: rows are not 16-byte aligned, element-wise accesses
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = nb + (r & 3) + 8 * (r >> 2);
+          if (n >= p.K) continue;
+          if (slab) { slab[row + n] = acc[i][j][r]; continue; }
+          float t = acc[i][j][r] * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
+          if (p.res) t += p.res[orow + n];
+          p.y[orow + n] = p.relu ? fmaxf(t, 0.f) : t;
+        }
+      }
+    }
+  }
+}
+
 template <int WM, int WN, int TM, int TN, bool ALIGNED>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvParams p) {
   constexpr int NT = 64 * WM * WN;
@@ -224,80 +306,169 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
     cur ^= 1;
   }
 
-  // ---- epilogue -------------------------------------------------------------------------------
-  // The MFMA operands are (weights, activations), so D has the PIXEL on the lane (col = lane&31) and
-  // the CHANNEL in the registers: row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Registers 4g..4g+3 are four
-  // consecutive channels -> every access of the epilogue is a 16-byte vector per lane, and all
-  // residual loads of a 32x32 tile are issued before its first store (res may alias nothing we
-  // write, but the compiler cannot know: batching keeps 4 loads in flight instead of a
-  // load->wait->store chain per element).
-  const int mlane = lane & 31, nhalf = 4 * (lane >> 5);
-  const bool vec = (p.K & 3) == 0;
-  float* const slab = p.partial ? p.partial + (size_t)blockIdx.z * p.M * p.K : nullptr;
+  conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant for the 8-wave tiles (C % 32 == 0): the A/B tiles go global -> LDS with
+// global_load_lds_dwordx4 (no VGPR staging, no ds_write pass), three LDS stages, loads issued two K-steps
+// ahead, ONE raw s_barrier per K-step behind a counted vmcnt.
+//   LDS stage = [BM + BN rows][32 floats], 128-byte rows WITHOUT padding: an LDS-DMA wave instruction writes
+//   lane i at base + 16*i, i.e. 8 whole rows per instruction.  Bank conflicts of the ds_read_b128 fragment
+//   reads (lane -> row) are removed by an XOR swizzle of the 16-byte chunk index with (row >> 1) & 7, applied
+//   on the per-lane GLOBAL source address and again on the read address (guide rule 21).
+//   Out-of-range lanes (padding taps, M / K tails) read a zero page instead of branching.
+// Numerics are those of conv_igemm_f32 (same k order), so split_k == 1 results are bit-identical.
+// ------------------------------------------------------------------------------------------------
+__device__ float g_zero_page[64];
+
+template <int WM, int WN>
+__global__ __launch_bounds__(512, 2) void conv_igemm_dma_f32(const ConvParams p) {
+  constexpr int TM = 2, TN = 2;
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  static_assert(WM * WN == 8, "8 waves");
+  constexpr int PA = BM / 64, PB = BN / 64;          // LDS-DMA instructions (8 rows each) per wave per K-step
+  constexpr int STAGE = (BM + BN) * 32;              // floats per stage
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][BM + BN][32]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wr = wave / WN, wc = wave % WN;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int step_begin = blockIdx.z * p.steps_per_split;
+  const int step_end = min(step_begin + p.steps_per_split, p.ksteps);
+  const int nsteps = step_end - step_begin;
+
+  // ---- per-lane sources: lane i of instruction q feeds row 8q + (i >> 3), physical chunk i & 7 -------------
+  const int lrow = lane >> 3, lchunk = lane & 7;
+  int a_base[PA], a_hi0[PA], a_wi0[PA], a_swz[PA];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = m0 + (wr * TM + i) * 32 + mlane;
-    if (m >= p.M) continue;
-    size_t orow = (size_t)m * p.K;  // row of y / residual
-    if (p.ys != 1) {
+  for (int j = 0; j < PA; ++j) {
+    const int row = (wave * PA + j) * 8 + lrow;
+    const int m = m0 + row;
+    a_swz[j] = (lchunk ^ ((row >> 1) & 7)) * 4;
+    if (m < p.M) {
       const int img = m / (p.Ho * p.Wo);
       const int rem = m - img * p.Ho * p.Wo;
       const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-      orow = ((size_t)(img * p.Hy + ho * p.ys) * p.Wy + wo * p.ys) * p.K;
-    }
-#if defined(FRCNN_ABLATE) && (FRCNN_ABLATE & 4)
-    if (acc[i][0][0] != 123.456f) continue;
-#endif
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int nb = n0 + (wc * TN + j) * 32 + nhalf;
-      const size_t row = (size_t)m * p.K;
-      if (vec) {
-        if (slab) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int n = nb + 8 * g;
-            if (n < p.K)
-              *reinterpret_cast<f32x4*>(slab + row + n) =
-                  f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          }
-          continue;
-        }
-        f32x4 rv[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = nb + 8 * g;
-          rv[g] = (p.res && n < p.K) ? *reinterpret_cast<const f32x4*>(p.res + orow + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = nb + 8 * g;
-          if (n >= p.K) continue;
-          const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
-          const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float t = acc[i][j][4 * g + e] * sc[e] + sh[e];
-            t += rv[g][e];
-            v[e] = p.relu ? fmaxf(t, 0.f) : t;
-          }
-          *reinterpret_cast<f32x4*>(p.y + orow + n) = v;
-        }
-      } else {
-        // K % 4 != 0: rows are not 16-byte aligned, element-wise accesses
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int n = nb + (r & 3) + 8 * (r >> 2);
-          if (n >= p.K) continue;
-          if (slab) { slab[row + n] = acc[i][j][r]; continue; }
-          float t = acc[i][j][r] * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
-          if (p.res) t += p.res[orow + n];
-          p.y[orow + n] = p.relu ? fmaxf(t, 0.f) : t;
-        }
-      }
+      a_hi0[j] = ho * p.stride - p.pad;
+      a_wi0[j] = wo * p.stride - p.pad;
+      a_base[j] = ((img * p.H + a_hi0[j]) * p.W + a_wi0[j]) * p.C;
+    } else {
+      a_hi0[j] = -(1 << 20);
+      a_wi0[j] = 0;
+      a_base[j] = 0;
     }
   }
+  const float* b_src[PB];
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const int row = (wave * PB + j) * 8 + lrow;
+    const int n = n0 + row;
+    b_src[j] = n < p.K ? p.w + (size_t)n * p.Ktot + (lchunk ^ ((row >> 1) & 7)) * 4 : nullptr;
+  }
+  int tr, ts, tc;
+  {
+    const int kf = step_begin * BK;
+    const int tap = kf / p.C;
+    tc = kf - tap * p.C;
+    tr = tap / p.S;
+    ts = tap - tr * p.S;
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  // issue() is called for consecutive steps (the tap state advances by one step per call)
+  auto issue = [&](int step, int stage) {
+    float* sA = smem + stage * STAGE + (wave * PA) * 8 * 32;
+    float* sB = smem + stage * STAGE + BM * 32 + (wave * PB) * 8 * 32;
+    const int koff = (tr * p.W + ts) * p.C + tc;
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+      const int hi = a_hi0[j] + tr, wi = a_wi0[j] + ts;
+      const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      const float* src = ok ? p.x + a_base[j] + koff + a_swz[j] : g_zero_page;
+      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(sA + j * 8 * 32), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const float* src = b_src[j] ? b_src[j] + step * BK : g_zero_page;
+      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(sB + j * 8 * 32), 16, 0, 0);
+    }
+    tc += BK;
+    if (tc == p.C) {
+      tc = 0;
+      if (++ts == p.S) { ts = 0; ++tr; }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment reads: row = tile row of lane & 31, chunk 2*kk + (lane >> 5), XOR-swizzled
+  int fa_row[TM], fa_x[TM], fb_row[TN], fb_x[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row = (wr * TM + i) * 32 + (lane & 31);
+    fa_row[i] = row * 32;
+    fa_x[i] = (row >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int row = (wc * TN + j) * 32 + (lane & 31);
+    fb_row[j] = BM * 32 + row * 32;
+    fb_x[j] = (row >> 1) & 7;
+  }
+  const int lh = lane >> 5;
+  f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+  auto read_frags = [&](f32x4* fa, f32x4* fb, int stage, int kk) {
+    const float* base = smem + stage * STAGE;
+    const int c = 2 * kk + lh;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(base + fa_row[i] + ((c ^ fa_x[i]) << 2));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(base + fb_row[j] + ((c ^ fb_x[j]) << 2));
+  };
+  auto mma = [&](const f32x4* fa, const f32x4* fb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][q], fa[i][q], acc[i][j], 0, 0, 0);
+  };
+
+  if (nsteps > 0) issue(step_begin, 0);
+  if (nsteps > 1) issue(step_begin + 1, 1);
+  int stage = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    // stage s landed for THIS wave once at most the loads of step s+1 remain outstanding; the barrier extends
+    // that to every wave and also says every wave has finished reading stage (s+2)%3 (it was stage s-1)
+    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < nsteps) issue(step_begin + s + 2, stage == 0 ? 2 : stage - 1);
+    read_frags(fa0, fb0, stage, 0);
+    read_frags(fa1, fb1, stage, 1);
+    mma(fa0, fb0);
+    read_frags(fa0, fb0, stage, 2);
+    mma(fa1, fb1);
+    read_frags(fa1, fb1, stage, 3);
+    mma(fa0, fb0);
+    mma(fa1, fb1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (all fragment reads already consumed)
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+  conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
 }
 
 // Split-K second pass: y = act((sum_z partial[z]) * scale + shift + res), slabs summed in z order.
@@ -398,6 +569,25 @@ int launch_conv(const ConvParams& p, int splits, hipStream_t stream) {
   return frcnn::check_launch("conv_igemm_f32");
 }
 
+template <int WM, int WN>
+int launch_conv_dma(const ConvParams& p, int splits, hipStream_t stream) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr size_t lds = (size_t)3 * (BM + BN) * 32 * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_f32<WM, WN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return frcnn::fail(FRCNN_ERR_LAUNCH, "conv: set LDS size: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
+  hipLaunchKernelGGL((conv_igemm_dma_f32<WM, WN>), grid, dim3(512), lds, stream, p);
+  return frcnn::check_launch("conv_igemm_dma_f32");
+}
+
+// tuning hook: 0 = register-staged kernels only, 1 = LDS-DMA kernel for the 8-wave tiles when C % 32 == 0
+int g_use_dma = 1;
+
 bool conv_args_ok(int n, int h, int w, int c, int k, int r, int s, int stride, int pad) {
   return n > 0 && h > 0 && w > 0 && c > 0 && (c % 4) == 0 && k > 0 && r > 0 && s > 0 && stride > 0 && pad >= 0 &&
          (h + 2 * pad - r) >= 0 && (w + 2 * pad - s) >= 0;
@@ -412,6 +602,11 @@ extern "C" int frcnn_conv2d_set_tile(int tm, int tn) {
                        "{(4,2),(2,4),(2,2),(2,1),(1,2),(1,1)} ((0,0) = automatic)");
   g_force_tm = tm;
   g_force_tn = tn;
+  return FRCNN_OK;
+}
+
+extern "C" int frcnn_conv2d_set_staging(int use_lds_dma) {
+  g_use_dma = use_lds_dma ? 1 : 0;
   return FRCNN_OK;
 }
 
@@ -463,8 +658,14 @@ int run_conv(const float* x, const float* wgt, const float* scale, const float* 
   rc = aligned ? launch_conv<WM_, WN_, TM_, TN_, true>(p, pl.splits, stream) \
                : launch_conv<WM_, WN_, TM_, TN_, false>(p, pl.splits, stream)
   switch (pl.cfg) {
-    case 0: FRCNN_CONV_CASE(4, 2, 2, 2); break;
-    case 1: FRCNN_CONV_CASE(2, 4, 2, 2); break;
+    case 0:
+      if (aligned && g_use_dma) rc = launch_conv_dma<4, 2>(p, pl.splits, stream);
+      else FRCNN_CONV_CASE(4, 2, 2, 2);
+      break;
+    case 1:
+      if (aligned && g_use_dma) rc = launch_conv_dma<2, 4>(p, pl.splits, stream);
+      else FRCNN_CONV_CASE(2, 4, 2, 2);
+      break;
     case 2: FRCNN_CONV_CASE(2, 2, 2, 2); break;
     case 3: FRCNN_CONV_CASE(2, 2, 2, 1); break;
     case 4: FRCNN_CONV_CASE(2, 2, 1, 2); break;

@@ -73,6 +73,9 @@ int frcnn_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* d
  * following frcnn_conv2d_fwd calls of this process; (tm,tn) in {(4,2),(2,4)} (8 waves, one workgroup per
  * CU), {(2,2),(2,1),(1,2),(1,1)} (4 waves); (0,0) restores the automatic choice. */
 int frcnn_conv2d_set_tile(int tm, int tn);
+/* Tuning / test hook: 1 (default) stages the 8-wave tiles with LDS-DMA (global_load_lds) when C % 32 == 0,
+ * 0 uses the register-staged kernel everywhere.  Results are bit-identical for split_k = 1. */
+int frcnn_conv2d_set_staging(int use_lds_dma);
 
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1)  (lib/nets/resnet.py:156), NHWC. */
 int frcnn_maxpool3x3s2_fwd(const float* x, float* y, int n, int h, int w, int c, void* stream);

@@ -48,11 +48,13 @@ def main():
     ap.add_argument("--tile", default="0,0")
     ap.add_argument("--split", type=int, default=0)
     ap.add_argument("--only", default="")
+    ap.add_argument("--staging", type=int, default=1, help="1 = LDS-DMA for the 8-wave tiles, 0 = register staging")
     args = ap.parse_args()
     from faster_rcnn_pytorch_multimodal_amd import _hip, ops
     lib = _hip.load()
     tm, tn = (int(v) for v in args.tile.split(","))
     _hip.check(lib.frcnn_conv2d_set_tile(tm, tn), "set_tile")
+    _hip.check(lib.frcnn_conv2d_set_staging(args.staging), "set_staging")
     dev = "cuda:0"
     g = torch.Generator(device="cpu").manual_seed(0)
     tot_us = tot_fl = 0.0
