@@ -103,7 +103,8 @@ def roi_align_timing(net, steps):
     n, h, w, c = feat.shape
     bytes_ = h * w * c * 4 + rois.shape[0] * 7 * 7 * c * 4 + rois.numel() * 4
     return {"bound": "hbm", "kernel": "roi_align_fwd_nhwc", "achieved": bytes_ / us / 1e3, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": bytes_ / us / 1e3 / HBM_PEAK_GBS, "traffic": None, "us_per_launch": us,
+            "unit": "GB/s", "frac": bytes_ / us / 1e3 / HBM_PEAK_GBS, "traffic": pmc_traffic("roi_align_fwd_nhwc"),
+            "us_per_launch": us,
             "algorithmic_bytes": bytes_}
 
 
@@ -115,12 +116,43 @@ def cpu_baseline(sd, frames, info):
     net.load_state_dict(sd, strict=True)
     O.frame_detect(net, frames[0], info, NUM_CLASSES, THRESH, MAX_DETS)
     t0 = time.perf_counter()
-    for f in frames:
-        O.frame_detect(net, f, info, NUM_CLASSES, THRESH, MAX_DETS)
+    dets = [O.frame_detect(net, f, info, NUM_CLASSES, THRESH, MAX_DETS) for f in frames]
     dt = time.perf_counter() - t0
     return {"value": len(frames) / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "%d frames of the 1000x600 res101 workload (CPU oracle: torch-CPU convs + numpy NMS/RoIAlign), "
-                      "%.1f s, os.cpu_count()=%d" % (len(frames), dt, os.cpu_count())}
+                      "%.1f s, os.cpu_count()=%d" % (len(frames), dt, os.cpu_count())}, dets
+
+
+def map_delta(net, frames_host, info, cpu_dets):
+    """"mAP delta vs CPU ref" of the metric: ground truth := the CPU oracle's own detections of each frame (so
+    AP_cpu = 1 by construction); AP_gpu = VOC continuous-area AP (lib/datasets/voc_eval.py:53-69) at IoU 0.7 of
+    the device path's detections of the same frames against it.  0 when both paths keep the same boxes."""
+    from faster_rcnn_pytorch_multimodal_amd.model.test import detect_frame_device
+    from oracle import frcnn_oracle as O
+    aps = []
+    for f, ref in zip(frames_host, cpu_dets):
+        dets, counts = detect_frame_device(net, f, info, THRESH, MAX_DETS, MAX_DETS)
+        dets, counts = dets.cpu().numpy(), counts.cpu().numpy()
+        for j in range(1, NUM_CLASSES):
+            if len(ref[j]) == 0:
+                continue
+            aps.append(O.average_precision(dets[j, :counts[j]], ref[j][:, :4], iou_thresh=0.7))
+    if not aps:
+        return None
+    ap_gpu = float(np.mean(aps))
+    return {"ap_cpu": 1.0, "ap_gpu": ap_gpu, "delta": abs(1.0 - ap_gpu), "iou": 0.7, "frames": len(frames_host),
+            "ground_truth": "the CPU oracle's detections (thresh %.1f, max_dets %d)" % (THRESH, MAX_DETS)}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/r01_pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE are collected in separate runs, so they cannot be measured inside the timed run)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["kernels"][kernel]["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -214,7 +246,7 @@ def main():
         achieved = conv["flops_per_frame"] / (conv["ms_per_frame"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "conv_igemm_f32 (all instantiations, %d launches/frame)"
                     % round(conv["launches_per_frame"]), "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic("conv_igemm_f32"),
                     "flops_per_frame": conv["flops_per_frame"], "kernel_ms_per_frame": conv["ms_per_frame"],
                     "avg_launch_us": 1e3 * conv["ms_per_frame"] / conv["launches_per_frame"]}
         if args.layers:
@@ -234,7 +266,8 @@ def main():
             "roofline_roi_align": roi_align_timing(net, 20),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, frames_host[:args.cpu_frames], info)
+            out["cpu_baseline"], cpu_dets = cpu_baseline(sd, frames_host[:args.cpu_frames], info)
+            out["map_delta_vs_cpu"] = map_delta(net, frames_host[:args.cpu_frames], info, cpu_dets)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -42,6 +42,29 @@ SHAPES = [
 ]
 
 
+# trainable convolutions of the res101+FPN train step at 1000x600 (FIXED_BLOCKS = 1)
+FPN_TRAIN_SHAPES = [
+    ("l2 3x3 128", 1, 75, 125, 128, 128, 3, 1, 1, False, 4),
+    ("l2 1x1 128-512", 1, 75, 125, 128, 512, 1, 1, 0, True, 4),
+    ("l2 1x1 512-128", 1, 75, 125, 512, 128, 1, 1, 0, False, 3),
+    ("l3 3x3 256", 1, 38, 63, 256, 256, 3, 1, 1, False, 23),
+    ("l3 1x1 256-1024", 1, 38, 63, 256, 1024, 1, 1, 0, True, 23),
+    ("l3 1x1 1024-256", 1, 38, 63, 1024, 256, 1, 1, 0, False, 22),
+    ("l4 3x3/2 512", 1, 38, 63, 512, 512, 3, 2, 1, False, 1),
+    ("l4 3x3 512", 1, 19, 32, 512, 512, 3, 1, 1, False, 2),
+    ("l4 1x1 512-2048", 1, 19, 32, 512, 2048, 1, 1, 0, True, 3),
+    ("l4 1x1 2048-512", 1, 19, 32, 2048, 512, 1, 1, 0, False, 2),
+    ("fpn lat2 256-256", 1, 150, 250, 256, 256, 1, 1, 0, False, 1),
+    ("fpn lat3 512-256", 1, 75, 125, 512, 256, 1, 1, 0, False, 1),
+    ("fpn aa2 3x3 256", 1, 150, 250, 256, 256, 3, 1, 1, False, 1),
+    ("fpn aa3 3x3 256", 1, 75, 125, 256, 256, 3, 1, 1, False, 1),
+    ("rpn 3x3 256-512", 1, 150, 250, 256, 512, 3, 1, 1, False, 1),
+    ("rpn 1x1 512-152", 1, 150, 250, 512, 152, 1, 1, 0, False, 1),
+    ("t_fc1 12544-2048", 256, 1, 1, 12544, 2048, 1, 1, 0, False, 1),
+    ("t_fc2 2048-2048", 256, 1, 1, 2048, 2048, 1, 1, 0, False, 2),
+]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
@@ -49,6 +72,8 @@ def main():
     ap.add_argument("--split", type=int, default=0)
     ap.add_argument("--only", default="")
     ap.add_argument("--staging", type=int, default=1, help="1 = LDS-DMA for the 8-wave tiles, 0 = register staging")
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "dgrad", "wgrad"])
+    ap.add_argument("--fpn", action="store_true", help="use the trainable convolutions of the FPN train step instead")
     args = ap.parse_args()
     from faster_rcnn_pytorch_multimodal_amd import _hip, ops
     lib = _hip.load()
@@ -59,7 +84,8 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(0)
     tot_us = tot_fl = 0.0
     print("%-24s %6s %9s %9s %8s" % ("shape", "calls", "us/call", "TFLOP/s", "us/frame"))
-    for name, n, h, w, c, k, r, stride, pad, res, calls in SHAPES:
+    shapes = FPN_TRAIN_SHAPES if args.fpn else SHAPES
+    for name, n, h, w, c, k, r, stride, pad, res, calls in shapes:
         if args.only and args.only not in name:
             continue
         x = torch.randn((n, h, w, c), generator=g).to(dev)
@@ -69,13 +95,24 @@ def main():
         ho, wo = ops.conv_out_hw(h, w, r, r, stride, pad)
         rs = torch.randn((n, ho, wo, k), generator=g).to(dev) if res else None
         y = torch.empty((n, ho, wo, k), device=dev)
+        if args.mode == "fwd":
+            run = lambda: ops.conv2d_nhwc(x, wt, sc, sh, rs, stride=stride, pad=pad, relu=True, split_k=args.split, out=y)
+        elif args.mode == "dgrad":
+            if k % 4:
+                continue
+            w_t = ops.conv2d_transpose_filter(wt)
+            run = lambda: ops.conv2d_bwd_data(y, w_t, tuple(x.shape), stride=stride, pad=pad)
+        else:
+            if k % 4:
+                continue
+            run = lambda: ops.conv2d_bwd_weight(x, y, r, r, stride=stride, pad=pad)
         for _ in range(2):
-            ops.conv2d_nhwc(x, wt, sc, sh, rs, stride=stride, pad=pad, relu=True, split_k=args.split, out=y)
+            run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(args.reps):
-            ops.conv2d_nhwc(x, wt, sc, sh, rs, stride=stride, pad=pad, relu=True, split_k=args.split, out=y)
+            run()
         e1.record()
         torch.cuda.synchronize()
         us = 1e3 * e0.elapsed_time(e1) / args.reps
