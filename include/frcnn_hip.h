@@ -159,6 +159,8 @@ int frcnn_make_rois(const float* sorted_boxes, const float* sorted_scores, const
  * >= count to zero.  level_of_roi/level (may be NULL/-1): only rois with level_of_roi[r]==level
  * are written (MultiScaleRoIAlign, torchpoolers.py:187-199).
  * ------------------------------------------------------------------------------------------- */
+/* Tuning / test hook: 0 automatic, 1 generic kernel, 2 generic with per-XCD channel slices, 3 separable kernel. */
+int frcnn_roi_align_set_variant(int variant);
 int frcnn_roi_align_fwd(const float* feat, int h, int w, int c, const float* rois, const int* roi_count,
                         int num_rois, int pooled, float spatial_scale, int sampling_ratio,
                         const int* level_of_roi, int level, float* out, void* stream);

@@ -295,7 +295,7 @@ def test_proposal_layer_matches_oracle(hip, shape):
 # ------------------------------------------------------------------------------------------------
 # RoIAlign / detection tail / per-class filter
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("c", [64, 256])
+@pytest.mark.parametrize("c", [64, 256, 20])          # 20: no 8-way channel split
 @pytest.mark.parametrize("sampling", [0, 2])
 def test_roi_align_matches_oracle(hip, sampling, c):
     ops = _ops()
@@ -315,6 +315,17 @@ def test_roi_align_matches_oracle(hip, sampling, c):
     got2 = ops.roi_align_nhwc(feat.permute(0, 2, 3, 1).contiguous().to(DEV), rois.to(DEV), 7, 1 / 16.0, sampling,
                               roi_count=cnt)
     assert torch.equal(got2[:10], got[:10]) and (got2[10:] == 0).all()
+
+
+def test_roi_align_tall_window_fallback(hip):
+    """Windows taller than the separable kernel's LDS budget (48 feature rows) take its in-kernel direct path."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    feat = torch.randn(1, 32, 120, 12, generator=g)
+    rois = torch.tensor([[0., 0, 0, 180, 1900], [0, 20, 100, 150, 1500], [0, 10, 10, 60, 200]])
+    ref = O.roi_align(feat, rois, 7, 1 / 16.0, 0)
+    got = ops.roi_align_nhwc(feat.permute(0, 2, 3, 1).contiguous().to(DEV), rois.to(DEV), 7, 1 / 16.0, 0)
+    _close_feat(got.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), "roi_align tall", frac=2e-6)
 
 
 def test_head_fc_softmax_decode(hip):
