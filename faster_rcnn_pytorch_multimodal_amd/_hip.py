@@ -51,6 +51,8 @@ PROTOTYPES = {
     "frcnn_filter_per_class_lidar": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, c_int, c_int, _P, _P, _P,
                                              c_size_t, _P]),
     "frcnn_act_bwd": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, _P]),
+    "frcnn_spatial_mean_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "frcnn_spatial_mean_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "frcnn_upsample_bilinear_add_fwd": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P]),
     "frcnn_upsample_bilinear_bwd": (c_int, [_P, _P] + [c_int] * 6 + [_P]),
     "frcnn_roi_align_bwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_float, c_int, _P, c_int, _P, _P]),

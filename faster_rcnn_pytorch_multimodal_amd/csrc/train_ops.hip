@@ -175,6 +175,45 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nhwc(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// fc7 = x.mean(3).mean(2) of the layer4 output (_head_to_tail of the non-FPN detector) and its backward.
+// x (R,P,P,C) NHWC: mean over W inside each row, then over the P row means, like the reference's two calls.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spatial_mean_fwd_kernel(const float* __restrict__ x, int R, int P, int C4,
+                                                              float* __restrict__ out) {
+  const size_t total = (size_t)R * C4;
+  const float inv = (float)P;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const size_t r = i / C4;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x) + r * P * P * C4 + c4;
+    f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < P; ++h) {
+      f32x4 row = {0.f, 0.f, 0.f, 0.f};
+      for (int w = 0; w < P; ++w) {
+        const f32x4 v = xr[(size_t)(h * P + w) * C4];
+        for (int e = 0; e < 4; ++e) row[e] += v[e];
+      }
+      for (int e = 0; e < 4; ++e) tot[e] += row[e] / inv;
+    }
+    for (int e = 0; e < 4; ++e) tot[e] = tot[e] / inv;
+    reinterpret_cast<f32x4*>(out)[i] = tot;
+  }
+}
+
+__global__ __launch_bounds__(256) void spatial_mean_bwd_kernel(const float* __restrict__ dout, int R, int P, int C4,
+                                                              float* __restrict__ dx) {
+  const size_t total = (size_t)R * P * P * C4;
+  const float inv = 1.0f / ((float)P * (float)P);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const size_t r = i / ((size_t)P * P * C4);
+    f32x4 g = reinterpret_cast<const f32x4*>(dout)[r * C4 + c4];
+    for (int e = 0; e < 4; ++e) g[e] = g[e] * inv;
+    reinterpret_cast<f32x4*>(dx)[i] = g;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fixed-order block reduction helper: 256 threads -> lane 0 of wave 0 holds the sum.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float block_sum_256(float v, float* smem4) {
@@ -344,6 +383,20 @@ extern "C" int frcnn_act_bwd(const float* dy, const float* y, const float* scale
   hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n4)), dim3(256), 0, static_cast<hipStream_t>(stream_), dy, y, scale,
                      relu, n4, k / 4, d_conv, d_res);
   return check_launch("act_bwd_kernel");
+}
+
+extern "C" int frcnn_spatial_mean_fwd(const float* x, float* out, int rows, int pooled, int c, void* stream_) {
+  FRCNN_REQUIRE(x && out && rows > 0 && pooled > 0 && c > 0 && c % 4 == 0, "spatial_mean_fwd: bad arguments (c%%4==0)");
+  hipLaunchKernelGGL(spatial_mean_fwd_kernel, dim3(grid_for((size_t)rows * (c / 4))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), x, rows, pooled, c / 4, out);
+  return check_launch("spatial_mean_fwd_kernel");
+}
+
+extern "C" int frcnn_spatial_mean_bwd(const float* dout, float* dx, int rows, int pooled, int c, void* stream_) {
+  FRCNN_REQUIRE(dout && dx && rows > 0 && pooled > 0 && c > 0 && c % 4 == 0, "spatial_mean_bwd: bad arguments (c%%4==0)");
+  hipLaunchKernelGGL(spatial_mean_bwd_kernel, dim3(grid_for((size_t)rows * pooled * pooled * (c / 4))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), dout, rows, pooled, c / 4, dx);
+  return check_launch("spatial_mean_bwd_kernel");
 }
 
 extern "C" int frcnn_upsample_bilinear_add_fwd(const float* x, const float* lateral, float* out, int n, int h, int w,

@@ -325,6 +325,23 @@ def roi_align_train(feats, rois, levels, pooled, scales, sampling):
     return _MultiLevelRoIAlignFn.apply(rois, levels, (pooled, tuple(scales), sampling), *feats)
 
 
+class _SpatialMeanFn(torch.autograd.Function):
+    """fc7 = layer4(pool5).mean(3).mean(2) (tail of the non-FPN detector)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.pooled = x.shape[1]
+        return ops.spatial_mean(x)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ops.spatial_mean_bwd(dout.contiguous(), ctx.pooled)
+
+
+def spatial_mean_train(x):
+    return _SpatialMeanFn.apply(x)
+
+
 class _RpnLossFn(torch.autograd.Function):
     """cross_entropy over labelled anchors + smooth_l1_loss('RPN', ...) on the fused RPN head output."""
 

@@ -33,7 +33,7 @@ from ..layer_utils.snippets import generate_anchors_pre
 from ..model.config import cfg
 from . import resnet as custom_resnet
 from .autograd_ops import (conv_bn_act_train, det_loss_train, fused_head_train, fused_head_weights, linear_train,
-                           roi_align_train, rpn_loss_train)
+                           roi_align_train, rpn_loss_train, spatial_mean_train)
 from .hip_modules import conv_bn_act, pad4, to_nchw_view, to_nhwc
 
 ROI_ALIGN_SAMPLING_RATIO = 0
@@ -259,9 +259,8 @@ class Network(nn.Module):
             h = linear_train(x.reshape(r, p * p * c), self.t_fc1, relu=True, weight_nhwc_from=(c, p))
             h = linear_train(h, self.t_fc2, relu=True)
             return linear_train(h, self.t_fc3, relu=True)
-        if torch.is_grad_enabled():
-            raise NotImplementedError("training the layer4 tail (non-FPN detector) is not on the HIP path yet; "
-                                      "use USE_FPN + ENABLE_CUSTOM_TAIL (tools/trainval_net.py:326-330)")
+        if torch.is_grad_enabled() and self._mode == 'TRAIN':
+            return spatial_mean_train(self._layer4(to_nhwc(pool5)))      # Bottleneck nodes + mean, all differentiable
         y = self._layer4(to_nhwc(pool5))
         out = self._tail_kernel(y, self._predictions['rois'])
         self._predictions['_tail'] = out
@@ -399,4 +398,24 @@ class Network(nn.Module):
         return loss, [(k, float(v.item())) for k, v in self._losses.items()]
 
     def run_eval(self, blobs, batch_size, update_summaries=False):
-        raise NotImplementedError("validation step is not on the HIP path yet")
+        """Validation forward (lib/model/train_val.py:411-412): returns (summary, rois, roi_labels, cls_prob,
+        pred_boxes, uncertainties) — what ``filter_and_draw_prep`` consumes next (train_val.py:416-420).
+        ``roi_labels`` = class of the best-overlapping gt box when IoU >= cfg.TRAIN.FG_THRESH, else 0.  The summary
+        list carries (name, value) pairs of the detection counts instead of tensorboard protobufs."""
+        was_training = self.training
+        self.eval()
+        try:
+            cls_score, cls_prob, pred_boxes, rois, uncertainties = self.test_frame(blobs['data'], blobs['info'])
+        finally:
+            if was_training:
+                self.train()
+        gt = blobs.get('gt_boxes')
+        roi_labels = torch.zeros((rois.shape[0],), dtype=torch.float32, device=rois.device)
+        if gt is not None and len(gt) > 0 and rois.shape[0] > 0 and cfg.NET_TYPE == 'image':
+            gt_t = torch.as_tensor(np.asarray(gt, dtype=np.float32)).to(rois.device)
+            ov = ops.bbox_overlaps(rois[:, 1:5].contiguous(), gt_t[:, :4].contiguous())
+            best, arg = ov.max(1)
+            roi_labels = torch.where(best >= cfg.TRAIN.FG_THRESH, gt_t[arg, 4], roi_labels)
+        summary = [('val_num_rois', float(rois.shape[0])), ('val_num_fg_rois', float((roi_labels > 0).sum().item()))] \
+            if update_summaries else []
+        return summary, rois, roi_labels, cls_prob, pred_boxes, uncertainties

@@ -543,3 +543,22 @@ def fpn_level_map(rois, k_min, k_max, canonical_scale=224.0, canonical_level=4.0
     _hip.check(lib.frcnn_fpn_level_map(_ptr(rois), rois.shape[0], int(k_min), int(k_max), float(canonical_scale),
                                        float(canonical_level), float(eps), _ptr(levels), _stream()), "frcnn_fpn_level_map")
     return levels
+
+
+def spatial_mean(x):
+    """(R,P,P,C) NHWC -> (R,C): x.mean(3).mean(2) of the NCHW-shaped view."""
+    lib = _hip.load()
+    _dev_f32(x, "x")
+    r, p, _, c = x.shape
+    out = torch.empty((r, c), dtype=torch.float32, device=x.device)
+    _hip.check(lib.frcnn_spatial_mean_fwd(_ptr(x), _ptr(out), r, p, c, _stream()), "frcnn_spatial_mean_fwd")
+    return out
+
+
+def spatial_mean_bwd(dout, pooled):
+    lib = _hip.load()
+    _dev_f32(dout, "dout")
+    r, c = dout.shape
+    dx = torch.empty((r, pooled, pooled, c), dtype=torch.float32, device=dout.device)
+    _hip.check(lib.frcnn_spatial_mean_bwd(_ptr(dout), _ptr(dx), r, pooled, c, _stream()), "frcnn_spatial_mean_bwd")
+    return dx

@@ -214,6 +214,11 @@ int frcnn_filter_per_class(float* pred_boxes, const float* cls_prob, const int* 
 int frcnn_act_bwd(const float* dy, const float* y, const float* scale, int relu, int64_t rows, int k,
                   float* d_conv, float* d_res, void* stream);
 
+/* fc7 = x.mean(3).mean(2) (_head_to_tail of the non-FPN detector; x (rows,P,P,c) NHWC -> out (rows,c)) and its
+ * backward dx = dout / P^2 broadcast over the P x P positions. */
+int frcnn_spatial_mean_fwd(const float* x, float* out, int rows, int pooled, int c, void* stream);
+int frcnn_spatial_mean_bwd(const float* dout, float* dx, int rows, int pooled, int c, void* stream);
+
 /* fpn._upsample_add (lib/nets/fpn.py:42-45): out (n,out_h,out_w,c) = F.interpolate(x (n,h,w,c), size=(out_h,out_w),
  * mode='bilinear', align_corners=False) + lateral.  Backward: dx = interpolate^T(dout) (deterministic gather);
  * the gradient of `lateral` is dout itself. */

@@ -401,6 +401,61 @@ class ImageNetOracle(nn.Module):
         return cls_score, cls_prob, pred_boxes, rois, {}
 
 
+def _image_train_forward(self, data, info, gt_boxes, generator=None, pre_nms=12000, post_nms=2000, proposals=None):
+    """One TRAIN forward of the non-FPN image detector (layer4 tail): losses with a graph + the sampled targets.
+    Uses the differentiable roi_align_torch; RECONSTRUCTED like FpnNetOracle.train_forward below."""
+    image = torch.from_numpy(np.ascontiguousarray(data)).permute(0, 3, 1, 2).contiguous()
+    gt = torch.as_tensor(gt_boxes, dtype=torch.float32)
+    net_conv = self._image_to_head(image)
+    a, (h, w) = self._num_anchors, net_conv.shape[2:]
+    anchors = torch.from_numpy(generate_anchors_pre(h, w, self._feat_stride, self._anchor_scales, self._anchor_ratios,
+                                                    float(info[6]))[0])
+    rpn = F.relu(self.rpn_net(net_conv))
+    cls_score = self.rpn_cls_score_net(rpn)
+    bbox_pred = self.rpn_bbox_pred_net(rpn).permute(0, 2, 3, 1).contiguous()
+    with torch.no_grad():
+        prob = F.softmax(cls_score.view(1, 2, a * h, w), dim=1).view(1, 2 * a, h, w).permute(0, 2, 3, 1).contiguous()
+        rois, scores = proposal_layer(prob, bbox_pred, info, anchors, a, pre_nms, post_nms, TEST_RPN_NMS_THRESH)
+        if proposals is not None:
+            rois, scores = proposals
+        lab, tgt, inw, outw = anchor_target_layer(gt, info, anchors, a, h, w, generator=generator)
+        pl, prois, _, _, ptgt, pin, pout = proposal_target_layer(rois, scores, torch.zeros(rois.shape[0], 7), gt, None,
+                                                                 self._num_classes, 4, generator=generator)
+    logits = torch.stack((cls_score[0, :a].permute(1, 2, 0).reshape(-1), cls_score[0, a:].permute(1, 2, 0).reshape(-1)), 1)
+    labels_hwa = lab[0].permute(1, 2, 0).reshape(-1)
+    sel = labels_hwa >= 0
+    rpn_ce = F.cross_entropy(logits[sel], labels_hwa[sel].long())
+    rpn_box = smooth_l1_loss("RPN", bbox_pred, tgt, inw, outw, dim=(1, 2, 3))
+    pool5 = roi_align_torch(net_conv, prois, POOLING_SIZE, 1.0 / self._feat_stride)
+    fc7 = self.resnet.layer4(pool5).mean(3).mean(2)
+    det_cls, det_box = self.cls_score_net(fc7), self.bbox_pred_net(fc7)
+    ce = F.cross_entropy(det_cls, pl.view(-1).long())
+    box = smooth_l1_loss("DET", det_box, ptgt, pin, pout)
+    losses = {"rpn_cross_entropy": rpn_ce, "rpn_loss_box": rpn_box, "cross_entropy": ce, "loss_box": box,
+              "total_loss": rpn_ce + rpn_box + ce + box}
+    dbg = {"anchor_labels": labels_hwa, "anchor_targets": tgt.reshape(-1, 4), "anchor_inside": inw.reshape(-1, 4),
+           "anchor_outside": outw.reshape(-1, 4), "rois": prois, "labels": pl.view(-1), "targets": ptgt, "inside": pin,
+           "outside": pout, "net_conv": net_conv, "fc7": fc7, "cls_score": det_cls}
+    return losses, dbg
+
+
+def _image_set_trainable(self, fixed_blocks=1):
+    """imagenet.py:96-116: stem and layerN (N <= FIXED_BLOCKS) frozen, every BatchNorm frozen."""
+    frozen = [self.resnet.conv1, self.resnet.bn1] + [getattr(self.resnet, "layer%d" % n) for n in (1, 2, 3)
+                                                     if fixed_blocks >= n]
+    for m in frozen:
+        for p in m.parameters():
+            p.requires_grad = False
+    for m in self.resnet.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            for p in m.parameters():
+                p.requires_grad = False
+
+
+ImageNetOracle.train_forward = _image_train_forward
+ImageNetOracle.set_trainable = _image_set_trainable
+
+
 # ----------------------------------------------------------------------------------------------
 # filter_and_draw_prep / nms_hstack_torch — lib/utils/filter_predictions.py:45-130, and the max_dets
 # cut of lib/model/test.py:210-221.  Image detector only here.

@@ -1040,3 +1040,48 @@ def test_proposal_top_layer_against_reference_golden(hip, golden_dir):
     np.testing.assert_array_equal(sc.cpu().numpy(), z["top_scores"])
     np.testing.assert_allclose(blob.cpu().numpy(), z["top_blob"], rtol=3e-7, atol=1e-4)
     C.reset_cfg()
+
+
+def test_image_train_step_matches_oracle_autograd(hip):
+    """Default (non-FPN) image detector: layer4 on the sampled RoIs + mean tail, forward + backward of one step
+    against torch-CPU autograd on identical (injected) targets; then run_eval on the same module."""
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    net, oracle = _build_pair(seed=31)
+    oracle.set_trainable(1)
+    data, info, gt, rois, scores = _fpn_case()
+    losses, d = oracle.train_forward(data, info, gt, generator=torch.Generator().manual_seed(3), proposals=(rois, scores))
+    losses["total_loss"].backward()
+    assert int((d["labels"] > 0).sum()) >= 20
+    net.train()
+    net._target_override = {
+        "anchor": tuple(d[k].contiguous().to(DEV) for k in ("anchor_labels", "anchor_targets", "anchor_inside", "anchor_outside")),
+        "proposal": {k: d[k].contiguous().to(DEV) for k in ("rois", "labels", "targets", "inside", "outside")}}
+    net.zero_grad()
+    net.forward(data, info, gt, None, mode="TRAIN")
+    _close_feat(net._act_summaries["conv"].detach().cpu().permute(0, 3, 1, 2).numpy(), d["net_conv"].detach().numpy(),
+                "net_conv", 5e-5)
+    got = {k: float(v.item()) for k, v in net._losses.items()}
+    for k, v in losses.items():
+        assert abs(got[k] - float(v.item())) <= 2e-4 * max(1.0, abs(float(v.item()))), (k, got[k], float(v.item()))
+    net._losses["total_loss"].backward()
+    own = dict(net.named_parameters())
+    checked, worst = 0, 0.0
+    for name, p_ref in oracle.named_parameters():
+        p = own[name]
+        if not p_ref.requires_grad:
+            assert p.grad is None, name
+            continue
+        ref = p_ref.grad.numpy().astype(np.float64)
+        diff = p.grad.cpu().numpy().astype(np.float64) - ref
+        rel = np.sqrt((diff ** 2).sum()) / (np.sqrt((ref ** 2).sum()) + 1e-30)
+        worst = max(worst, rel)
+        assert rel <= 5e-3, "grad %s: relative L2 error %.3e" % (name, rel)
+        checked += 1
+    assert checked == 103          # layer2..4 convs (93) + RPN (6) + heads (4)
+    print("image train step: %d parameter gradients checked, worst relative L2 error %.2e" % (checked, worst))
+    net._target_override = None
+    blobs = {"data": data, "info": info, "gt_boxes": gt}
+    summary, r, rl, cp, pb, unc = net.run_eval(blobs, 1, update_summaries=True)
+    assert net.training and r.shape[1] == 5 and rl.shape[0] == r.shape[0] and cp.shape == (r.shape[0], 2)
+    assert pb.shape == (r.shape[0], 8) and unc == {} and dict(summary)["val_num_rois"] == r.shape[0]
+    C.reset_cfg()
