@@ -28,6 +28,11 @@
 // of the tile configuration for split_k == 1.
 #include "common.h"
 
+#include <array>
+#include <map>
+#include <mutex>
+#include <vector>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -553,6 +558,44 @@ Plan choose_plan(int M, int K, int ksteps, int forced_splits) {
   return best;
 }
 
+// ---- plan cache / autotuner -----------------------------------------------------------------------
+// The analytic model above ranks (tile, split) pairs well for large GEMMs but not for the small, latency-bound
+// layers (layer1..3 at one frame): there the 64x64 tile without a K split usually wins by 10-40 %.  With
+// frcnn_conv2d_set_autotune(1) the first call of a shape outside stream capture times every candidate on the
+// caller's own tensors (HIP events on the launch stream) and caches the winner; later calls — including the
+// captured ones — look the plan up.  Off by default: results for split_k = 0 then depend only on the model.
+typedef std::array<int, 10> ShapeKey;
+std::map<ShapeKey, Plan> g_plan_cache;
+std::mutex g_plan_mutex;
+int g_autotune = 0;
+constexpr size_t kTuneWsCap = (size_t)256 << 20;   // candidates whose split-K slabs exceed this are not tried
+
+ShapeKey shape_key(int n, int h, int w, int c, int k, int r, int s, int stride, int pad, int out_stride) {
+  return ShapeKey{n, h, w, c, k, r, s, stride, pad, out_stride};
+}
+
+std::vector<Plan> tune_candidates(long M, int k, int ksteps, bool allow_split) {
+  static const int split_cand[] = {1, 2, 3, 4, 6, 8, 12, 16};
+  std::vector<Plan> out;
+  for (int ci = 0; ci < kNumTiles; ++ci)
+    for (int sp : split_cand) {
+      if (sp > 1 && (!allow_split || ksteps / sp < 2)) continue;
+      const int sps = (ksteps + sp - 1) / sp;
+      if ((ksteps + sps - 1) / sps != sp) continue;
+      if (sp > 1 && (size_t)sp * M * k * sizeof(float) > kTuneWsCap) continue;
+      out.push_back(Plan{ci, sp, sps});
+    }
+  return out;
+}
+
+bool lookup_plan(const ShapeKey& key, Plan* pl) {
+  std::lock_guard<std::mutex> lock(g_plan_mutex);
+  auto it = g_plan_cache.find(key);
+  if (it == g_plan_cache.end()) return false;
+  *pl = it->second;
+  return true;
+}
+
 template <int WM, int WN, int TM, int TN, bool ALIGNED>
 int launch_conv(const ConvParams& p, int splits, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -616,43 +659,43 @@ extern "C" size_t frcnn_conv2d_fwd_ws_bytes(int n, int h, int w, int c, int k, i
   const int ho = (h + 2 * pad - r) / stride + 1, wo = (w + 2 * pad - s) / stride + 1;
   const long M = (long)n * ho * wo;
   const int ksteps = (r * s * c + BK - 1) / BK;
+  if (split_k <= 0 && g_force_tm == 0) {
+    Plan cached;
+    if (lookup_plan(shape_key(n, h, w, c, k, r, s, stride, pad, 1), &cached))
+      return cached.splits > 1 ? (size_t)cached.splits * M * k * sizeof(float) : 0;
+  }
+  if (split_k <= 0 && g_force_tm == 0 && g_autotune) {
+    size_t need = 0;   // not tuned yet: room for the largest split-K candidate the tuner may try
+    for (const Plan& cand : tune_candidates(M, k, ksteps, true))
+      if (cand.splits > 1) need = std::max(need, (size_t)cand.splits * M * k * sizeof(float));
+    return need;
+  }
   const Plan pl = choose_plan((int)M, k, ksteps, split_k);
   return pl.splits > 1 ? (size_t)pl.splits * M * k * sizeof(float) : 0;
 }
 
+extern "C" int frcnn_conv2d_set_autotune(int enable) {
+  g_autotune = enable ? 1 : 0;
+  return FRCNN_OK;
+}
+
+extern "C" int frcnn_conv2d_clear_plans(void) {
+  std::lock_guard<std::mutex> lock(g_plan_mutex);
+  g_plan_cache.clear();
+  return FRCNN_OK;
+}
+
 namespace {
-// Shared driver of the forward entry point and of the data-gradient entry point (which is a forward
-// convolution of dy with the flipped/transposed filter).  out_stride > 1 scatters the output pixels onto
-// a (hy x wy) map at stride out_stride (the map must be zero-filled by the caller); split-K is disabled then.
-int run_conv(const float* x, const float* wgt, const float* scale, const float* shift, const float* residual,
-             float* y, int n, int h, int w, int c, int k, int r, int s, int stride, int pad, int relu, int split_k,
-             void* ws, size_t ws_bytes, hipStream_t stream, int out_stride, int hy, int wy) {
-  ConvParams p;
-  p.x = x; p.w = wgt; p.scale = scale; p.shift = shift; p.res = residual; p.y = y; p.partial = nullptr;
-  p.H = h; p.W = w; p.C = c; p.K = k; p.R = r; p.S = s; p.stride = stride; p.pad = pad;
-  p.Ho = (h + 2 * pad - r) / stride + 1;
-  p.Wo = (w + 2 * pad - s) / stride + 1;
-  const long M = (long)n * p.Ho * p.Wo;
-  FRCNN_REQUIRE(M * (long)k < (1L << 31) && (long)n * h * w * c < (1L << 31), "conv2d: tensor too large for int32 indexing");
-  p.M = (int)M;
-  p.Ktot = r * s * c;
-  p.ksteps = (p.Ktot + BK - 1) / BK;
-  p.relu = relu;
-  p.ys = out_stride; p.Hy = hy; p.Wy = wy;
-  if (out_stride != 1) split_k = 1;
-  const Plan pl = choose_plan(p.M, k, p.ksteps, split_k);
+// launch one plan: main kernel + the split-K second pass
+int launch_plan(ConvParams p, const Plan& pl, long M, int k, const float* scale, const float* shift,
+                const float* residual, float* y, int relu, void* ws, hipStream_t stream) {
   const TileCfg& tc = kTiles[pl.cfg];
   p.steps_per_split = pl.steps_per_split;
   const int bm = 64 * tc.tm, bn = 64 * tc.tn;
   p.tiles_m = (p.M + bm - 1) / bm;
   p.tiles_n = (k + bn - 1) / bn;
-  if (pl.splits > 1) {
-    const size_t need = (size_t)pl.splits * M * k * sizeof(float);
-    if (!ws || ws_bytes < need)
-      return frcnn::fail(FRCNN_ERR_WS, "conv2d: workspace %zu < %zu bytes", ws_bytes, need);
-    p.partial = static_cast<float*>(ws);
-  }
-  const bool aligned = (c % BK) == 0;
+  p.partial = pl.splits > 1 ? static_cast<float*>(ws) : nullptr;
+  const bool aligned = (p.C % BK) == 0;
   int rc;
 #define FRCNN_CONV_CASE(WM_, WN_, TM_, TN_)                                   \
   rc = aligned ? launch_conv<WM_, WN_, TM_, TN_, true>(p, pl.splits, stream) \
@@ -681,6 +724,75 @@ int run_conv(const float* x, const float* wgt, const float* scale, const float* 
     return frcnn::check_launch("conv_splitk_epilogue");
   }
   return FRCNN_OK;
+}
+
+// time every candidate plan on the caller's tensors; returns false when tuning is not possible here
+bool tune_plan(const ConvParams& p, long M, int k, const float* scale, const float* shift, const float* residual,
+               float* y, int relu, void* ws, size_t ws_bytes, hipStream_t stream, bool allow_split, Plan* best) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess) return false;
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return false; }
+  float best_ms = 1e30f;
+  bool found = false;
+  for (const Plan& pl : tune_candidates(M, k, p.ksteps, allow_split)) {
+    const size_t need = pl.splits > 1 ? (size_t)pl.splits * M * k * sizeof(float) : 0;
+    if (need > ws_bytes || (need > 0 && !ws)) continue;
+    if (launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, stream) != FRCNN_OK) continue;   // warm-up
+    (void)hipEventRecord(e0, stream);
+    const int reps = 3;
+    bool ok = true;
+    for (int i = 0; i < reps && ok; ++i) ok = launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, stream) == FRCNN_OK;
+    (void)hipEventRecord(e1, stream);
+    if (hipEventSynchronize(e1) != hipSuccess || !ok) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
+    if (ms < best_ms) { best_ms = ms; *best = pl; found = true; }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return found;
+}
+
+// Shared driver of the forward entry point and of the data-gradient entry point (which is a forward
+// convolution of dy with the flipped/transposed filter).  out_stride > 1 scatters the output pixels onto
+// a (hy x wy) map at stride out_stride (the map must be zero-filled by the caller); split-K is disabled then.
+int run_conv(const float* x, const float* wgt, const float* scale, const float* shift, const float* residual,
+             float* y, int n, int h, int w, int c, int k, int r, int s, int stride, int pad, int relu, int split_k,
+             void* ws, size_t ws_bytes, hipStream_t stream, int out_stride, int hy, int wy) {
+  ConvParams p;
+  p.x = x; p.w = wgt; p.scale = scale; p.shift = shift; p.res = residual; p.y = y; p.partial = nullptr;
+  p.H = h; p.W = w; p.C = c; p.K = k; p.R = r; p.S = s; p.stride = stride; p.pad = pad;
+  p.Ho = (h + 2 * pad - r) / stride + 1;
+  p.Wo = (w + 2 * pad - s) / stride + 1;
+  const long M = (long)n * p.Ho * p.Wo;
+  FRCNN_REQUIRE(M * (long)k < (1L << 31) && (long)n * h * w * c < (1L << 31), "conv2d: tensor too large for int32 indexing");
+  p.M = (int)M;
+  p.Ktot = r * s * c;
+  p.ksteps = (p.Ktot + BK - 1) / BK;
+  p.relu = relu;
+  p.ys = out_stride; p.Hy = hy; p.Wy = wy;
+  p.steps_per_split = p.ksteps; p.tiles_m = p.tiles_n = 0;
+  const bool allow_split = out_stride == 1;
+  Plan pl;
+  bool have = false;
+  if (split_k <= 0 && g_force_tm == 0) {   // cached plans always apply; new shapes are tuned only in autotune mode
+    const ShapeKey key = shape_key(n, h, w, c, k, r, s, stride, pad, out_stride);
+    have = lookup_plan(key, &pl);
+    if (!have && g_autotune && tune_plan(p, M, k, scale, shift, residual, y, relu, ws, ws_bytes, stream, allow_split, &pl)) {
+      std::lock_guard<std::mutex> lock(g_plan_mutex);
+      g_plan_cache[key] = pl;
+      have = true;
+    }
+  }
+  if (!have) pl = choose_plan(p.M, k, p.ksteps, allow_split ? split_k : 1);
+  if (pl.splits > 1) {
+    const size_t need = (size_t)pl.splits * M * k * sizeof(float);
+    if (!ws || ws_bytes < need)
+      return frcnn::fail(FRCNN_ERR_WS, "conv2d: workspace %zu < %zu bytes", ws_bytes, need);
+  }
+  return launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, stream);
 }
 }  // namespace
 

@@ -17,7 +17,8 @@ class FrameRunner:
     """Fixed-shape frame pipeline: ``run(frame)`` -> (dets (K, max_out, 5), det_count (K,)) device tensors
     that are overwritten by the next ``run``."""
 
-    def __init__(self, net, height, width, channels, info, thresh=0.5, max_dets=100, use_graph=True, warmup=2):
+    def __init__(self, net, height, width, channels, info, thresh=0.5, max_dets=100, use_graph=True, warmup=2,
+                 autotune=True):
         self.net = net
         self.info = np.asarray(info, dtype=np.float32)
         self.thresh, self.max_dets = thresh, max_dets
@@ -27,9 +28,19 @@ class FrameRunner:
         self.out = None
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
+        from .. import ops
         with torch.cuda.stream(side):
-            for _ in range(max(warmup, 1)):   # lazy work happens here: weight layout, anchors, LDS attributes
-                self.out = self._frame()
+            # lazy work happens here: weight layout, anchors, LDS attributes and — with autotune — the timing of the
+            # (tile, split-K) candidates of every convolution shape (the plan cache is process-wide)
+            ops.set_conv_autotune(autotune)
+            try:
+                for _ in range(max(warmup, 1)):
+                    self.out = self._frame()
+            finally:
+                torch.cuda.synchronize(dev)
+                ops.set_conv_autotune(False)
+            if autotune:
+                self.out = self._frame()   # one more eager frame with the tuned plans (allocator warm-up)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         if use_graph:

@@ -38,6 +38,12 @@ def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+def set_conv_autotune(enable):
+    """Turn the convolution plan autotuner on/off (frcnn_conv2d_set_autotune): tune during eager warm-up frames,
+    the cached plans are then used inside captured graphs."""
+    _hip.check(_hip.load().frcnn_conv2d_set_autotune(int(bool(enable))), "frcnn_conv2d_set_autotune")
+
+
 def conv_out_hw(h, w, r, s, stride, pad):
     return (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
 

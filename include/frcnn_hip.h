@@ -73,6 +73,14 @@ int frcnn_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* d
  * following frcnn_conv2d_fwd calls of this process; (tm,tn) in {(4,2),(2,4)} (8 waves, one workgroup per
  * CU), {(2,2),(2,1),(1,2),(1,1)} (4 waves); (0,0) restores the automatic choice. */
 int frcnn_conv2d_set_tile(int tm, int tn);
+/* Plan autotuner (like a "benchmark mode"): when enabled, the first frcnn_conv2d_fwd / _bwd_data call of a shape
+ * OUTSIDE stream capture times every (tile, split-K) candidate on the caller's tensors with HIP events — this
+ * synchronises with the host — and caches the fastest; later calls (also captured ones) reuse it.  While enabled,
+ * frcnn_conv2d_fwd_ws_bytes returns room for the largest candidate of a not-yet-tuned shape.  Default: off (the
+ * analytic model picks).  frcnn_conv2d_clear_plans forgets the cache. */
+int frcnn_conv2d_set_autotune(int enable);
+int frcnn_conv2d_clear_plans(void);
+
 /* Tuning / test hook: 1 (default) stages the 8-wave tiles with LDS-DMA (global_load_lds) when C % 32 == 0,
  * 0 uses the register-staged kernel everywhere.  Results are bit-identical for split_k = 1. */
 int frcnn_conv2d_set_staging(int use_lds_dma);
