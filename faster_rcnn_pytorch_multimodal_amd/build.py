@@ -29,8 +29,6 @@ SOURCES = {
     "targets.hip": ["-ffp-contract=off"],
 }
 COMMON_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-if os.environ.get("FRCNN_ABLATE"):   # tuning experiments only (tools/): skips parts of the conv kernel
-    COMMON_FLAGS.append("-DFRCNN_ABLATE=" + os.environ["FRCNN_ABLATE"])
 
 
 def _hipcc():

@@ -95,9 +95,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
       const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
       orow = ((size_t)(img * p.Hy + ho * p.ys) * p.Wy + wo * p.ys) * p.K;
     }
-#if defined(FRCNN_ABLATE) && (FRCNN_ABLATE & 4)
-    if (acc[i][0][0] != 123.456f) continue;
-#endif
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int nb = n0 + (wc * TN + j) * 32 + nhalf;
@@ -297,14 +294,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
     mma(fa0, fb0);
     read_frags(fa0, fb0, cur, 2);
     mma(fa1, fb1);
-#if !defined(FRCNN_ABLATE) || !(FRCNN_ABLATE & 2)
     if (more) store_tiles(cur ^ 1);  // tile step+1: its loads were issued >= 3/4 step ago
-#endif
     read_frags(fa1, fb1, cur, 3);
     mma(fa0, fb0);
-#if !defined(FRCNN_ABLATE) || !(FRCNN_ABLATE & 1)
     if (step + 2 < step_end) load_tiles(step + 2);
-#endif
     __syncthreads();  // buffer cur^1 complete; every wave has its last fragments of buffer cur in registers
     if (more) read_frags(fa0, fb0, cur ^ 1, 0);
     mma(fa1, fb1);
@@ -451,27 +444,40 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_f32(const ConvParams p)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][q], fa[i][q], acc[i][j], 0, 0, 0);
   };
 
+  // Schedule of one K-step (4 groups of 16 MFMAs per wave).  The barrier sits in the MIDDLE of the step:
+  //   group 0, 1   on stage s (its group-0 fragments were read at the end of the previous step)
+  //   vmcnt + barrier: stage s+1 has landed for every wave, and every wave is past step s-1
+  //   issue the loads of step s+2 into the stage step s-1 used
+  //   group 2, then the group-0 fragment reads of stage s+1, group 3
+  // so neither the barrier nor the first fragment reads of a stage leave the MFMA pipe without queued work.
   if (nsteps > 0) issue(step_begin, 0);
   if (nsteps > 1) issue(step_begin + 1, 1);
-  int stage = 0;
-  for (int s = 0; s < nsteps; ++s) {
-    // stage s landed for THIS wave once at most the loads of step s+1 remain outstanding; the barrier extends
-    // that to every wave and also says every wave has finished reading stage (s+2)%3 (it was stage s-1)
-    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+  if (nsteps > 0) {
+    if (nsteps > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (s + 2 < nsteps) issue(step_begin + s + 2, stage == 0 ? 2 : stage - 1);
-    read_frags(fa0, fb0, stage, 0);
+    read_frags(fa0, fb0, 0, 0);
+  }
+  int stage = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    const int next = stage == 2 ? 0 : stage + 1;
     read_frags(fa1, fb1, stage, 1);
     mma(fa0, fb0);
     read_frags(fa0, fb0, stage, 2);
     mma(fa1, fb1);
+    if (s + 1 < nsteps) {
+      // only the loads of step s+1 are outstanding here (step s+2 is issued below)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 2 < nsteps) issue(step_begin + s + 2, stage == 0 ? 2 : stage - 1);
+    }
     read_frags(fa1, fb1, stage, 3);
     mma(fa0, fb0);
+    if (s + 1 < nsteps) read_frags(fa0, fb0, next, 0);
     mma(fa1, fb1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (all fragment reads already consumed)
-    stage = stage == 2 ? 0 : stage + 1;
+    stage = next;
   }
   conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
 }

@@ -10,11 +10,21 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// VARIANT 3 = VARIANT 2 with signed, full-mantissa pseudo-random operands (what a conv layer feeds the pipe):
+// DVFS holds a lower clock on such data than on the smooth positive ramp of variants 0-2.
 template <int VARIANT, int NT>
 __global__ __launch_bounds__(NT) void probe(float* out, int iters) {
   __shared__ __attribute__((aligned(16))) float lds[2 * 128 * 36];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (int i = t; i < 2 * 128 * 36; i += NT) lds[i] = (float)((i * 2654435761u) >> 20) * 1e-4f;
+  for (int i = t; i < 2 * 128 * 36; i += NT) {
+    if (VARIANT >= 3) {
+      unsigned h = (i + 1) * 2654435761u;
+      h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
+      lds[i] = ((float)(int)(h & 0xFFFFFF) - 8388608.f) * (1.0f / 8388608.f) * (1.f + (float)((h >> 24) & 7));
+    } else {
+      lds[i] = (float)((i * 2654435761u) >> 20) * 1e-4f;
+    }
+  }
   __syncthreads();
   f32x16 acc[2][2];
   for (int i = 0; i < 2; ++i)
@@ -43,6 +53,10 @@ __global__ __launch_bounds__(NT) void probe(float* out, int iters) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][q], a[i][q], acc[i][j], 0, 0, 0);
     }
     if (VARIANT >= 2) __syncthreads();
+    if (VARIANT >= 3 && (it & 63) == 63)   // keep the accumulators bounded without leaving the MFMA-bound regime
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+          for (int r = 0; r < 16; ++r) acc[i][j][r] *= 0.001f;
   }
   float s = 0.f;
   for (int i = 0; i < 2; ++i)
@@ -53,7 +67,7 @@ __global__ __launch_bounds__(NT) void probe(float* out, int iters) {
 
 template <int VARIANT, int NT>
 void run(const char* name, int blocks_per_cu, float* out) {
-  const int iters = 2000, blocks = 256 * blocks_per_cu;
+  const int iters = 20000, blocks = 256 * blocks_per_cu;
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
@@ -81,6 +95,9 @@ int main() {
   run<2, 256>("V2 +barrier/64 MFMA, 1 wave/SIMD", 1, out);
   run<2, 512>("V2 +barrier/64 MFMA, 2 waves/SIMD", 1, out);
   run<2, 256>("V2 +barrier/64 MFMA, 2 WGs of 256 per CU", 2, out);
+  run<3, 512>("V3 random signed operands, 2 waves/SIMD", 1, out);
+  run<3, 256>("V3 random signed operands, 2 WGs of 256 per CU", 2, out);
+  run<3, 512>("V3 again (sustained)", 1, out);
   hipFree(out);
   return 0;
 }
