@@ -177,7 +177,10 @@ class Network(nn.Module):
         x = to_nhwc(net_conv)
         h, w = x.shape[1], x.shape[2]
         self._anchor_component(h, w)
-        rpn_out = self._rpn_head(x)                                   # (1, H, W, 6A)
+        rpn_out = self._rpn_head(x)                                   # (1, H, W, ld >= 6A)
+        override = getattr(self, '_rpn_override', None)               # evaluation hook: injected RPN logits | deltas
+        if override is not None:
+            rpn_out = override
         key = 'TRAIN' if self._mode == 'TRAIN' else 'TEST'
         if key == 'TEST' and cfg.TEST.get('MODE', 'nms') == 'top':
             return self._proposal_top(rpn_out, h, w)
