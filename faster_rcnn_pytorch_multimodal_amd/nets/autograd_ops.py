@@ -15,6 +15,56 @@ from .. import ops
 from .hip_modules import pad4, prepared_conv
 
 
+# Filter gradients are off the critical path of backward (only the data gradient feeds the next node), so they CAN
+# run on a side HIP stream and be accumulated into ``param.grad`` there; ``join_weight_grads()`` (called by
+# Network.backward before clipping / the optimizer) makes the main stream wait for them.  Measured on the FPN train
+# step (round 1): no gain — the step is bound by GPU throughput, not by the dependency chain — so the default keeps
+# the plain autograd flow.
+ASYNC_WGRAD = False
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
+def join_weight_grads(device=None):
+    """Main stream waits for every filter-gradient launch issued so far (no-op when none were issued)."""
+    for key, side in _SIDE.items():
+        if device is None or key == str(torch.device(device)):
+            torch.cuda.current_stream(side.device).wait_stream(side)
+
+
+def _accumulate(param, grad):
+    if param.grad is None:
+        param.grad = grad
+    else:
+        param.grad.add_(grad)
+
+
+def _wgrad(x, d_conv, r, s, stride, pad, targets):
+    """Filter (and bias) gradient of one convolution.  ``targets`` = list of (param, fn) where fn maps
+    (dw_krsc, db) to that parameter's gradient.  Synchronous mode returns the list of gradients; asynchronous mode
+    launches on the side stream, accumulates into param.grad there and returns None for each."""
+    want_bias = any(kind == 'b' for _, _, kind in targets)
+    if not ASYNC_WGRAD:
+        dw_krsc, db = ops.conv2d_bwd_weight(x, d_conv, r, s, stride=stride, pad=pad, want_bias=want_bias)
+        return [fn(dw_krsc, db) for _, fn, _ in targets]
+    main = torch.cuda.current_stream(x.device)
+    side = _side_stream(x.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        dw_krsc, db = ops.conv2d_bwd_weight(x, d_conv, r, s, stride=stride, pad=pad, want_bias=want_bias)
+        for param, fn, _ in targets:
+            _accumulate(param, fn(dw_krsc, db))
+    x.record_stream(side)
+    d_conv.record_stream(side)
+    return [None for _ in targets]
+
+
 def _transposed_filter(conv_like, w_krsc):
     """Cached (C,R,S,K) flipped filter of the data-gradient convolution, keyed like the forward filter."""
     cache = conv_like.__dict__.get('_frcnn_wt')
@@ -64,12 +114,17 @@ class _ConvFn(torch.autograd.Function):
             d_conv, d_res = dy, None
         dx = dw = db = None
         r, s = w_krsc.shape[1], w_krsc.shape[2]
-        if need_w or (bias is not None and need_b):
-            dw_krsc, db = ops.conv2d_bwd_weight(x, d_conv, r, s, stride=stride, pad=pad, want_bias=bias is not None)
+        targets = []
+        if need_w:
+            targets.append((weight, lambda dwk, dbk, w=weight: _param_grad_from_krsc(dwk, w), 'w'))
+        if bias is not None and need_b:
+            targets.append((bias, lambda dwk, dbk: dbk, 'b'))
+        if targets:
+            grads = _wgrad(x, d_conv, r, s, stride, pad, targets)
             if need_w:
-                dw = _param_grad_from_krsc(dw_krsc, weight)
-            if not need_b:
-                db = None
+                dw = grads[0]
+            if bias is not None and need_b:
+                db = grads[-1]
         if need_x:
             dx = ops.conv2d_bwd_data(d_conv, _transposed_filter(owner, w_krsc), tuple(x.shape), stride=stride, pad=pad)
         return dx, d_res, dw, db, None
@@ -128,8 +183,8 @@ class _PermutedLinearFn(torch.autograd.Function):
         dy4 = dy.contiguous().view(r, 1, 1, -1)
         d_conv = ops.act_bwd(dy4, y, None, relu=True)[0] if relu else dy4
         x4 = x2d.view(r, 1, 1, -1)
-        dw_krsc, db = ops.conv2d_bwd_weight(x4, d_conv, 1, 1, want_bias=True)
-        dw = dw_krsc.view(lin.out_features, p, p, c).permute(0, 3, 1, 2).reshape(lin.out_features, -1)
+        to_w = lambda dwk, dbk: dwk.view(lin.out_features, p, p, c).permute(0, 3, 1, 2).reshape(lin.out_features, -1)
+        dw, db = _wgrad(x4, d_conv, 1, 1, 1, 0, [(lin.weight, to_w, 'w'), (lin.bias, lambda dwk, dbk: dbk, 'b')])
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_bwd_data(d_conv, _transposed_filter(lin, w_krsc), tuple(x4.shape)).view(r, -1)
@@ -145,6 +200,7 @@ class _FusedHeadFn(torch.autograd.Function):
         w_krsc, bias_cat, owner = pack
         y = ops.conv2d_nhwc(x, w_krsc, None, bias_cat, None)
         ctx.pack = pack
+        ctx.biases = (b1, b2)
         ctx.save_for_backward(x, w1, w2)
         return y
 
@@ -153,14 +209,17 @@ class _FusedHeadFn(torch.autograd.Function):
         x, w1, w2 = ctx.saved_tensors
         w_krsc, _, owner = ctx.pack
         dy = dy.contiguous()
-        dw_krsc, db = ops.conv2d_bwd_weight(x, dy, w_krsc.shape[1], w_krsc.shape[2], want_bias=True)
         k1, k2 = w1.shape[0], w2.shape[0]
-        dw1 = _param_grad_from_krsc(dw_krsc[:k1], w1)
-        dw2 = _param_grad_from_krsc(dw_krsc[k1:k1 + k2], w2)
+        b1, b2 = ctx.biases
+        dw1, db1, dw2, db2 = _wgrad(x, dy, w_krsc.shape[1], w_krsc.shape[2], 1, 0, [
+            (w1, lambda dwk, dbk: _param_grad_from_krsc(dwk[:k1], w1), 'w'),
+            (b1, lambda dwk, dbk: dbk[:k1].contiguous(), 'b'),
+            (w2, lambda dwk, dbk: _param_grad_from_krsc(dwk[k1:k1 + k2], w2), 'w'),
+            (b2, lambda dwk, dbk: dbk[k1:k1 + k2].contiguous(), 'b')])
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_bwd_data(dy, _transposed_filter(owner, w_krsc), tuple(x.shape))
-        return dx, dw1, db[:k1].contiguous(), dw2, db[k1:k1 + k2].contiguous(), None
+        return dx, dw1, db1, dw2, db2, None
 
 
 def fused_head_weights(owner, m1, m2, cache_name):
@@ -234,29 +293,33 @@ class _BottleneckFn(torch.autograd.Function):
         blk = ctx.block
         p1, p2, p3, pd, s1, s2, sd = ctx.meta
         need_w = [w.requires_grad for w in (blk.conv1.weight, blk.conv2.weight, blk.conv3.weight)]
+
+        def wg(inp, dz, conv, r, stride, pad):
+            w = conv.weight
+            return _wgrad(inp, dz, r, r, stride, pad, [(w, lambda dwk, dbk: _param_grad_from_krsc(dwk, w), 'w')])[0]
+
         dz3, d_id = ops.act_bwd(dy.contiguous(), out, p3[1], relu=True, want_res=True)
-        dw3 = ops.conv2d_bwd_weight(o2, dz3, 1, 1)[0] if need_w[2] else None
+        dw3 = wg(o2, dz3, blk.conv3, 1, 1, 0) if need_w[2] else None
         d_o2 = ops.conv2d_bwd_data(dz3, _transposed_filter(blk.conv3, p3[0]), tuple(o2.shape))
         dz2, _ = ops.act_bwd(d_o2, o2, p2[1], relu=True)
-        dw2 = ops.conv2d_bwd_weight(o1, dz2, 3, 3, stride=s2, pad=1)[0] if need_w[1] else None
+        dw2 = wg(o1, dz2, blk.conv2, 3, s2, 1) if need_w[1] else None
         d_o1 = ops.conv2d_bwd_data(dz2, _transposed_filter(blk.conv2, p2[0]), tuple(o1.shape), stride=s2, pad=1)
         dz1, _ = ops.act_bwd(d_o1, o1, p1[1], relu=True)
-        dw1 = ops.conv2d_bwd_weight(x, dz1, 1, 1, stride=s1)[0] if need_w[0] else None
+        dw1 = wg(x, dz1, blk.conv1, 1, s1, 0) if need_w[0] else None
         dwd = None
         dx = None
         if pd is not None:
             dzd, _ = ops.act_bwd(d_id, None, pd[1], relu=False)
             if blk.downsample[0].weight.requires_grad:
-                dwd = ops.conv2d_bwd_weight(x, dzd, 1, 1, stride=sd)[0]
+                dwd = wg(x, dzd, blk.downsample[0], 1, sd, 0)
             if ctx.needs_input_grad[0]:
                 dx = ops.conv2d_bwd_data(dzd, _transposed_filter(blk.downsample[0], pd[0]), tuple(x.shape), stride=sd)
                 dx = ops.conv2d_bwd_data(dz1, _transposed_filter(blk.conv1, p1[0]), tuple(x.shape), stride=s1, add=dx)
         elif ctx.needs_input_grad[0]:
             dx = ops.conv2d_bwd_data(dz1, _transposed_filter(blk.conv1, p1[0]), tuple(x.shape), stride=s1, add=d_id)
-        grads = [None if g is None else _param_grad_from_krsc(g, w) for g, w in
-                 ((dw1, blk.conv1.weight), (dw2, blk.conv2.weight), (dw3, blk.conv3.weight))]
+        grads = [dw1, dw2, dw3]     # parameter-layout gradients, or None when they were accumulated on the side stream
         if pd is not None:
-            grads.append(None if dwd is None else _param_grad_from_krsc(dwd, blk.downsample[0].weight))
+            grads.append(dwd)
         return (dx, None, None) + tuple(grads)
 
 

@@ -32,6 +32,7 @@ from ..layer_utils.proposal_target_layer import proposal_target_layer_device
 from ..layer_utils.snippets import generate_anchors_pre
 from ..model.config import cfg
 from . import resnet as custom_resnet
+from . import autograd_ops
 from .autograd_ops import (conv_bn_act_train, det_loss_train, fused_head_train, fused_head_weights, linear_train,
                            roi_align_train, rpn_loss_train, spatial_mean_train)
 from .hip_modules import conv_bn_act, pad4, to_nchw_view, to_nhwc
@@ -381,12 +382,18 @@ class Network(nn.Module):
             if prm.grad is not None:
                 prm.grad.clamp_(-clip, clip)
 
+    def backward(self, loss):
+        """loss.backward() plus the join of the filter-gradient side stream (autograd_ops.ASYNC_WGRAD): afterwards every
+        ``param.grad`` is complete as seen from the current stream."""
+        loss.backward()
+        autograd_ops.join_weight_grads(self._device)
+
     def train_step(self, blobs, optimizer, update_weights=False):
         """One forward/backward on a frame (lib/model/train_val.py:458).  Gradients accumulate over calls and the
         optimizer steps only when ``update_weights`` (pseudo-batching, train_val.py:379-382).  Returns the loss."""
         self.forward(blobs['data'], blobs['info'], blobs['gt_boxes'], blobs.get('gt_boxes_dc'), mode='TRAIN')
         loss = self._losses['total_loss']
-        loss.backward()
+        self.backward(loss)
         if update_weights:
             self._clip_gradients()
             optimizer.step()

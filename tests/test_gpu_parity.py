@@ -970,7 +970,7 @@ def test_fpn_train_step_matches_oracle_autograd(hip):
     got = {k: float(v.item()) for k, v in net._losses.items()}
     for k, v in losses.items():
         assert abs(got[k] - float(v.item())) <= 2e-4 * max(1.0, abs(float(v.item()))), (k, got[k], float(v.item()))
-    net._losses["total_loss"].backward()
+    net.backward(net._losses["total_loss"])
     own = dict(net.named_parameters())
     checked, worst = 0, 0.0
     for name, p_ref in oracle.named_parameters():
@@ -1063,7 +1063,7 @@ def test_image_train_step_matches_oracle_autograd(hip):
     got = {k: float(v.item()) for k, v in net._losses.items()}
     for k, v in losses.items():
         assert abs(got[k] - float(v.item())) <= 2e-4 * max(1.0, abs(float(v.item()))), (k, got[k], float(v.item()))
-    net._losses["total_loss"].backward()
+    net.backward(net._losses["total_loss"])
     own = dict(net.named_parameters())
     checked, worst = 0, 0.0
     for name, p_ref in oracle.named_parameters():
