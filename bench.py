@@ -68,10 +68,18 @@ def conv_roofline(net, frame, info, steps):
         detect_frame_device(net, frame, info, THRESH, MAX_DETS, MAX_DETS)
     torch.cuda.synchronize()
     prof, ops.PROFILE = ops.PROFILE, None
+    # an (event, event) pair with nothing in between still measures the event packets themselves; calibrate that on
+    # the same stream and take it off every interval (rocprofv3's per-dispatch durations do not contain it)
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
+    for a, b in pairs:
+        a.record()
+        b.record()
+    torch.cuda.synchronize()
+    null_ms = float(np.median([a.elapsed_time(b) for a, b in pairs]))
     per_layer = {}
     total_ms, total_flops = 0.0, 0.0
     for shp, e0, e1 in prof:
-        ms = e0.elapsed_time(e1)
+        ms = max(e0.elapsed_time(e1) - null_ms, 1e-4)
         fl = shp["flops"] * (3.0 / 4.0 if (shp["r"] == 7 and shp["c"] == 4) else 1.0)  # stem: 3 real channels
         total_ms += ms
         total_flops += fl
@@ -82,6 +90,7 @@ def conv_roofline(net, frame, info, steps):
         ent[2] += fl
     launches = len(prof) / steps
     return {"ms_per_frame": total_ms / steps, "flops_per_frame": total_flops / steps, "launches_per_frame": launches,
+            "event_pair_overhead_us": 1e3 * null_ms,
             "per_layer": {k: {"calls_per_frame": v[0] / steps, "us_per_call": 1e3 * v[1] / v[0],
                               "tflops": v[2] / v[1] / 1e9} for k, v in per_layer.items()}}
 
@@ -287,6 +296,7 @@ def main():
                     % round(conv["launches_per_frame"]), "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic("conv_igemm_f32"),
                     "flops_per_frame": conv["flops_per_frame"], "kernel_ms_per_frame": conv["ms_per_frame"],
+                    "event_pair_overhead_us": conv["event_pair_overhead_us"],
                     "avg_launch_us": 1e3 * conv["ms_per_frame"] / conv["launches_per_frame"]}
         if args.layers:
             for k, v in sorted(conv["per_layer"].items(), key=lambda kv: -kv[1]["us_per_call"] * kv[1]["calls_per_frame"]):

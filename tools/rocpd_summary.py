@@ -25,5 +25,31 @@ def main(path, title=""):
         print("| `%s` | %d | %.1f | %.2f | %.2f |" % (short, calls, tot, avg, pct))
 
 
+def conv_cross_check(path, frames=5, launches_per_frame=106):
+    """bench.py measures its `roofline` over its LAST `frames` eager frames (after the timed region): sum the
+    conv_igemm* dispatches of exactly those frames (plus the split-K second passes that follow them) from the
+    per-dispatch table, for comparison with bench.py's kernel_ms_per_frame / avg_launch_us."""
+    db = sqlite3.connect(path)
+    rows = list(db.execute("select name, start, end from kernels where name like '%conv_igemm%' or name like "
+                           "'%conv_splitk_epilogue%' order by start"))
+    main = [r for r in rows if "conv_igemm" in r[0]]
+    if len(main) < frames * launches_per_frame:
+        return
+    first = main[-frames * launches_per_frame][1]
+    sel = [r for r in rows if r[1] >= first]
+    igemm = sum(e - s for n, s, e in sel if "conv_igemm" in n) / 1e3
+    epi = sum(e - s for n, s, e in sel if "splitk" in n) / 1e3
+    print("\n## cross-check with bench.py's roofline (last %d eager frames, %d conv launches each)\n" % (frames, launches_per_frame))
+    print("| quantity | value |\n|---|---:|")
+    print("| conv_igemm* kernel time per frame | %.1f us |" % (igemm / frames))
+    print("| + conv_splitk_epilogue per frame | %.1f us |" % (epi / frames))
+    print("| average per frcnn_conv2d_fwd call (main kernel + second pass) | %.2f us |"
+          % ((igemm + epi) / (frames * launches_per_frame)))
+    print("| => conv rate at 628.4 GFLOP/frame | %.1f TFLOP/s |" % (628.4e9 / ((igemm + epi) / frames * 1e-6) / 1e12))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], " ".join(sys.argv[2:]))
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    main(args[0], " ".join(args[1:]))
+    if "--conv-cross-check" in sys.argv:
+        conv_cross_check(args[0])
