@@ -27,6 +27,7 @@ SOURCES = {
     "head.hip": ["-ffp-contract=off"],
     "train_ops.hip": ["-ffp-contract=off"],
     "targets.hip": ["-ffp-contract=off"],
+    "prep.hip": ["-ffp-contract=off"],
 }
 COMMON_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -92,6 +92,15 @@ int frcnn_maxpool3x3s2_fwd(const float* x, float* y, int n, int h, int w, int c,
  * count padded with zeros to c_pad (multiple of 4) so the stem conv reads 16-byte pixels. */
 int frcnn_pad_channels(const float* x, float* y, int64_t pixels, int c, int c_pad, void* stream);
 
+/* Image input producer: prep_im_for_blob + im_list_to_blob (lib/utils/blob.py:16-54) for one frame on
+ * the device.  img (h,w,3) uint8 in cv2.imread order -> blob (out_h,out_w,c_out) fp32 with
+ * blob[..,c] = (resize(img)[.., arrange[c]] - means[c]) / stddevs[c], c_out = 3 or 4 (4th channel zero).
+ * cv2.resize(fx=fy=scale, INTER_LINEAR) semantics restated (cv2 is not vendored by the reference).
+ * means / stddevs (3 doubles) and arrange (3 ints) are HOST pointers. */
+int frcnn_prep_image_out_size(int h, int w, float scale, int* out_h, int* out_w);
+int frcnn_prep_image(const uint8_t* img_hwc3, int h, int w, float scale, const double* means_host,
+                     const double* stddevs_host, const int* arrange_host, int c_out, float* blob, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * RPN / proposal stage
  * ------------------------------------------------------------------------------------------- */

@@ -1034,3 +1034,34 @@ class FpnNetOracle(nn.Module):
                "pyramid": pyr, "pool5": pool5, "fc7": fc7, "cls_score": det_cls, "bbox_pred": det_box,
                "rpn_cls_score": cls_score, "rpn_bbox_pred": bbox_pred}
         return losses, dbg
+
+
+# ----------------------------------------------------------------------------------------------
+# prep_im_for_blob — lib/utils/blob.py:32-54.  cv2.resize(INTER_LINEAR) is restated from its documented
+# semantics (cv2 is neither vendored nor installed here: PARITY UNPINNED): dsize = round-half-even(size*scale),
+# source coordinate (dst+0.5)/scale - 0.5 in fp32, clamped taps, horizontal blend then vertical.
+# ----------------------------------------------------------------------------------------------
+def _resize_taps(n_out, inv_scale, size):
+    f = ((np.arange(n_out, dtype=np.float64) + 0.5) * np.float64(np.float32(inv_scale)) - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    frac = (f - s.astype(np.float32)).astype(np.float32)
+    lo = s < 0
+    frac[lo], s[lo] = 0.0, 0
+    hi = s >= size - 1
+    frac[hi], s[hi] = 0.0, size - 1
+    return s, np.minimum(s + 1, size - 1), (np.float32(1.0) - frac).astype(np.float32), frac
+
+
+def prep_im_for_blob(im, pixel_means, pixel_stddev, pixel_arrange, im_scale):
+    im = im.astype(np.float32, copy=False)
+    h, w = im.shape[:2]
+    oh, ow = int(np.rint(h * float(im_scale))), int(np.rint(w * float(im_scale)))
+    inv = np.float32(1.0 / float(im_scale))
+    y0, y1, b0, b1 = _resize_taps(oh, inv, h)
+    x0, x1, a0, a1 = _resize_taps(ow, inv, w)
+    top = im[y0][:, x0] * a0[None, :, None] + im[y0][:, x1] * a1[None, :, None]
+    bot = im[y1][:, x0] * a0[None, :, None] + im[y1][:, x1] * a1[None, :, None]
+    out = (top * b0[:, None, None] + bot * b1[:, None, None]).astype(np.float32)
+    out = out[:, :, list(pixel_arrange)]
+    out -= np.asarray(pixel_means, dtype=np.float64)                    # in-place: float32(float64 - mean)
+    return (out / np.asarray(pixel_stddev)).astype(np.float32)          # float64 quotient, stored as float32

@@ -1085,3 +1085,30 @@ def test_image_train_step_matches_oracle_autograd(hip):
     assert net.training and r.shape[1] == 5 and rl.shape[0] == r.shape[0] and cp.shape == (r.shape[0], 2)
     assert pb.shape == (r.shape[0], 8) and unc == {} and dict(summary)["val_num_rois"] == r.shape[0]
     C.reset_cfg()
+
+
+@pytest.mark.parametrize("scale", [1.0, 0.5, 0.75, 1.3])
+def test_prep_im_for_blob_matches_oracle(hip, scale):
+    """Device image producer (lib/utils/blob.py:32-54) vs the numpy restatement, plus known answers."""
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.utils.blob import im_list_to_blob, image_info, prep_im_for_blob
+    C.reset_cfg()
+    rng = np.random.default_rng(11)
+    im = rng.integers(0, 256, (37, 52, 3), dtype=np.uint8)
+    means, stds, arrange = C.cfg.PIXEL_MEANS, np.array([[[1.0, 2.0, 0.5]]]), [2, 0, 1]
+    ref = O.prep_im_for_blob(im, means, stds, arrange, scale)
+    got = prep_im_for_blob(im, means, stds, arrange, scale, device=DEV)
+    assert tuple(got.shape) == ref.shape
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=0, atol=2e-5)
+    got4 = prep_im_for_blob(im, means, stds, arrange, scale, pad_to=4, device=DEV)
+    assert torch.equal(got4[..., :3], got) and (got4[..., 3] == 0).all()
+    blob = im_list_to_blob([got4])
+    assert tuple(blob.shape) == (1,) + tuple(got4.shape) and image_info(blob, scale).tolist()[:4] == [0, ref.shape[1], 0, ref.shape[0]]
+    if scale == 1.0:      # identity resize: exactly (pixel - mean) / std
+        want = (im[:, :, arrange].astype(np.float64) - np.asarray(means).reshape(1, 1, 3)).astype(np.float32)
+        np.testing.assert_array_equal(got.cpu().numpy(), (want / stds).astype(np.float32))
+    if scale == 0.5:      # 2x decimation = mean of horizontally / vertically adjacent pixel pairs
+        e = im[:36, :, :].astype(np.float32)
+        avg = ((e[0::2, 0::2] * 0.5 + e[0::2, 1::2] * 0.5) * 0.5 + (e[1::2, 0::2] * 0.5 + e[1::2, 1::2] * 0.5) * 0.5)
+        want = ((avg[:, :, arrange].astype(np.float64) - np.asarray(means).reshape(1, 1, 3)).astype(np.float32) / stds)
+        np.testing.assert_allclose(got.cpu().numpy()[:18], want.astype(np.float32), rtol=0, atol=1e-5)
