@@ -59,7 +59,7 @@ def lidar_forward(steps, streams=4):
                        "detections_last_frame": outs[0][1].cpu().tolist()}}
 
 
-def fpn_train(steps):
+def fpn_train(steps, autotune=True):
     from faster_rcnn_pytorch_multimodal_amd import ops
     from faster_rcnn_pytorch_multimodal_amd.model import config as C
     from faster_rcnn_pytorch_multimodal_amd.nets.imagenet import imagenet
@@ -85,8 +85,14 @@ def fpn_train(steps):
                           weight_decay=C.cfg.TRAIN.WEIGHT_DECAY)
     blobs = {"data": data, "info": info, "gt_boxes": gt, "gt_boxes_dc": np.zeros((0, 4), np.float32)}
     torch.manual_seed(C.cfg.RNG_SEED)
-    for _ in range(2):
-        net.train_step(blobs, opt, update_weights=False)
+    ops.set_conv_autotune(autotune)      # time the (tile, split-K) candidates of every forward / data-gradient shape once
+    try:
+        for _ in range(2):
+            net.train_step(blobs, opt, update_weights=False)
+    finally:
+        torch.cuda.synchronize()
+        ops.set_conv_autotune(False)
+    opt.zero_grad()
     # forward FLOPs of one step from the per-launch conv log
     ops.PROFILE = []
     net.train_step(blobs, opt, update_weights=False)
@@ -113,12 +119,13 @@ def main():
     ap.add_argument("--lidar", action="store_true")
     ap.add_argument("--train", action="store_true")
     ap.add_argument("--steps", type=int, default=0)
+    ap.add_argument("--no-autotune", action="store_true", help="heuristic conv plans in the training step")
     args = ap.parse_args()
     both = not (args.lidar or args.train)
     if args.lidar or both:
         print(json.dumps(lidar_forward(args.steps or 80)))
     if args.train or both:
-        print(json.dumps(fpn_train(args.steps or 16)))
+        print(json.dumps(fpn_train(args.steps or 16, not args.no_autotune)))
 
 
 if __name__ == "__main__":
