@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Fold two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, one counter per run, CSV output) into the per-launch HBM
+traffic file bench.py reads (profiles/r01_pmc_traffic.json).
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_FETCH_SIZE -o pmc -- python3 bench.py ...
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_WRITE_SIZE -o pmc -- python3 bench.py ...
+    python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE "<command>" > profiles/r01_pmc_traffic.json
+
+Both counters are reported in KB.  FETCH_SIZE is doubled: gfx950 counts half of the wide (16 B per lane) streaming
+reads these kernels issue (MI355X_MICROARCH.md, HBM / rocprofv3 section).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+# family -> substring of the kernel name (all template instances of the conv kernel count as one family, like
+# bench.py's per-frcnn_conv2d_fwd-launch timing)
+FAMILIES = {"conv_igemm": "conv_igemm", "roi_align_fwd": "roi_align_fwd", "conv_wgrad_f32": "conv_wgrad_f32"}
+
+
+# bench.py tunes its conv plans during the first frames (extra candidate launches); its roofline is timed over the
+# LAST 5 eager frames x 106 conv launches, so the conv traffic is averaged over exactly those dispatches.
+LAST = {"conv_igemm": 5 * 106}
+
+
+def per_kernel(directory, counter):
+    paths = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
+    if not paths:
+        raise SystemExit("no *counter_collection.csv under %s" % directory)
+    vals = {}
+    with open(paths[0], newline="") as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            for fam, sub in FAMILIES.items():
+                if sub in row["Kernel_Name"]:
+                    vals.setdefault(fam, []).append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+                    break
+    acc = {}
+    for fam, rows in vals.items():
+        rows.sort()
+        if fam in LAST:
+            rows = rows[-LAST[fam]:]
+        acc[fam] = (len(rows), sum(v for _, v in rows))
+    return acc
+
+
+def main(fetch_dir, write_dir, command=""):
+    fetch = per_kernel(fetch_dir, "FETCH_SIZE")
+    write = per_kernel(write_dir, "WRITE_SIZE")
+    out = {"command": command + " (one counter per pass)",
+           "method": "per-dispatch FETCH_SIZE / WRITE_SIZE (KB) summed per kernel family and divided by its launch "
+                     "count; FETCH_SIZE doubled (gfx950 reports half of wide 16 B/lane streaming reads, "
+                     "MI355X_MICROARCH.md HBM section); Infinity-Cache hits are included in FETCH_SIZE",
+           "kernels": {}}
+    for fam in FAMILIES:
+        if fam not in fetch or fam not in write:
+            continue
+        n, kb = fetch[fam]
+        nw, kbw = write[fam]
+        fb = 2.0 * kb * 1024.0 / n
+        wb = kbw * 1024.0 / nw
+        out["kernels"][fam] = {"launches": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+                               "traffic_bytes_per_launch": fb + wb}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], " ".join(sys.argv[3:]))
