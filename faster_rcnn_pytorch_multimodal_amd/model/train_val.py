@@ -1,0 +1,274 @@
+"""Solver loop of the reference (lib/model/train_val.py:58-503) for the HIP Network, plus the data-parallel step the
+reference does not have ("solver loop + DP all-reduce").
+
+Same schedule as ``SolverWrapper.train_model``: iterations count frames, the optimizer steps every ``batch_size``
+frames (train_val.py:379-382), the learning rate is multiplied by ``cfg.TRAIN.GAMMA`` at ``stepsize + 1``
+(train_val.py:383-389), a snapshot (``.pth`` weights + ``.pkl`` sampler state) every ``cfg.TRAIN.SNAPSHOT_ITERS``
+and at most ``cfg.TRAIN.SNAPSHOT_KEPT`` kept (train_val.py:476-485, 294-307).  Tensorboard writers, the dataset
+classes and the drawing hooks are the caller's (out of scope); ``frames`` is any object with
+``next()`` returning a blob dict and optionally ``get_pointer()/set_pointer()``.
+
+Data parallel = one process per GPU, every rank draws its own frame, gradients accumulate locally for
+``batch_size`` frames in ONE flat fp32 buffer (``GradientBucket``: every ``param.grad`` is a view into it) and a single
+RCCL all-reduce of that buffer runs right before the optimizer step - one 190 MB collective per 16 frames instead of
+one per layer per frame, sized for xGMI's per-link bound ring rather than for latency.
+"""
+import glob
+import os
+import pickle
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .config import cfg
+
+
+def scale_lr(optimizer, scale):
+    """lib/model/train_val.py:48-51."""
+    for group in optimizer.param_groups:
+        group['lr'] *= scale
+
+
+def sgd_param_groups(net):
+    """lib/model/train_val.py:188-208: one group per parameter; biases get ``lr * (DOUBLE_BIAS + 1)`` and no weight
+    decay unless BIAS_DECAY."""
+    lr = cfg.TRAIN.LEARNING_RATE
+    groups = []
+    for key, value in dict(net.named_parameters()).items():
+        if not value.requires_grad:
+            continue
+        if 'bias' in key:
+            groups.append({'params': [value], 'lr': lr * (cfg.TRAIN.DOUBLE_BIAS + 1),
+                           'weight_decay': cfg.TRAIN.BIAS_DECAY and cfg.TRAIN.WEIGHT_DECAY or 0})
+        else:
+            groups.append({'params': [value], 'lr': lr,
+                           'weight_decay': getattr(value, 'weight_decay', cfg.TRAIN.WEIGHT_DECAY)})
+    return groups
+
+
+class GradientBucket:
+    """All trainable gradients of a network as views into one flat fp32 buffer resident in HBM."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise ValueError("GradientBucket needs fp32 parameters on one device")
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, group=None):
+        """Average the accumulated gradients over the ranks (no-op for a single process)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.div_(dist.get_world_size(group))
+
+
+class DataParallelOptimizer:
+    """The optimizer object handed to ``Network.train_step(blobs, optimizer, update_weights)``: ``step()`` first
+    averages the flat gradient bucket over the ranks, ``zero_grad()`` clears the bucket in place (the views stay)."""
+
+    def __init__(self, optimizer, bucket, group=None):
+        self.optimizer = optimizer
+        self.bucket = bucket
+        self.group = group
+
+    @property
+    def param_groups(self):
+        return self.optimizer.param_groups
+
+    def step(self):
+        self.bucket.all_reduce_mean(self.group)
+        self.optimizer.step()
+
+    def zero_grad(self, set_to_none=False):
+        self.bucket.zero()
+
+    def state_dict(self):
+        return self.optimizer.state_dict()
+
+    def load_state_dict(self, state):
+        self.optimizer.load_state_dict(state)
+
+
+def broadcast_parameters(net, src=0, group=None):
+    """Make every replica start from rank ``src``'s weights and buffers."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    for t in list(net.parameters()) + list(net.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+
+
+class SolverWrapper:
+    """lib/model/train_val.py:58-503 without the dataset / tensorboard plumbing."""
+
+    def __init__(self, network, num_classes, frames, val_frames=None, output_dir='.', sum_size=128, val_sum_size=0,
+                 epoch_size=0, batch_size=None, val_batch_size=None, data_parallel=None, log=print):
+        self.net = network
+        self.num_classes = num_classes
+        self.data_gen = frames
+        self.data_gen_val = val_frames
+        self.output_dir = output_dir
+        self.sum_size = sum_size
+        self.val_sum_size = val_sum_size
+        self.epoch_size = epoch_size
+        self.batch_size = batch_size or cfg.TRAIN.BATCH_SIZE
+        self.val_batch_size = val_batch_size or cfg.TRAIN.VAL_BATCH_SIZE
+        self.log = log
+        if data_parallel is None:
+            data_parallel = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.data_parallel = data_parallel
+        self.rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        self.optimizer = None
+        self.summaries = []          # (iter, name, value) instead of tensorboard events
+        self.val_summaries = []
+
+    # -- graph / optimizer -------------------------------------------------------------------------------------
+    def construct_graph(self):
+        """train_val.py:167-213.  The architecture is created here unless the caller already did."""
+        torch.manual_seed(cfg.RNG_SEED)
+        if not list(self.net.parameters()):
+            if cfg.NET_TYPE == 'lidar':
+                self.net.create_architecture(self.num_classes, tag='default', anchor_scales=cfg.LIDAR.ANCHOR_SCALES,
+                                             anchor_ratios=cfg.LIDAR.ANCHOR_ANGLES)
+            else:
+                self.net.create_architecture(self.num_classes, tag='default', anchor_scales=cfg.ANCHOR_SCALES,
+                                             anchor_ratios=cfg.ANCHOR_RATIOS)
+        self.net.to(self.net._device)
+        if self.data_parallel:
+            broadcast_parameters(self.net)
+        sgd = torch.optim.SGD(sgd_param_groups(self.net), momentum=cfg.TRAIN.MOMENTUM)
+        self.bucket = GradientBucket([p for g in sgd.param_groups for p in g['params']])
+        self.optimizer = DataParallelOptimizer(sgd, self.bucket)
+        return cfg.TRAIN.LEARNING_RATE, self.optimizer
+
+    # -- snapshots ---------------------------------------------------------------------------------------------
+    def _snapshot_name(self, it, ext):
+        return os.path.join(self.output_dir, '%s_%s_iter_%d%s' % (cfg.NET_TYPE, cfg.TRAIN.SNAPSHOT_PREFIX, it, ext))
+
+    def snapshot(self, it):
+        """train_val.py:100-129: weights as .pth, numpy RNG + sampler pointers + iteration as consecutive pickles.
+        Only rank 0 writes."""
+        sfile, nfile = self._snapshot_name(it, '.pth'), self._snapshot_name(it, '.pkl')
+        if self.rank != 0:
+            return sfile, nfile
+        os.makedirs(self.output_dir, exist_ok=True)
+        torch.save(self.net.state_dict(), sfile)
+        cur, perm = self.data_gen.get_pointer() if hasattr(self.data_gen, 'get_pointer') else (0, None)
+        cur_val, perm_val = (self.data_gen_val.get_pointer() if hasattr(self.data_gen_val, 'get_pointer')
+                             else (0, None))
+        with open(nfile, 'wb') as fid:
+            for obj in (np.random.get_state(), cur, perm, cur_val, perm_val, it):
+                pickle.dump(obj, fid, pickle.HIGHEST_PROTOCOL)
+        self.log('Wrote snapshot to: %s' % sfile)
+        return sfile, nfile
+
+    def from_snapshot(self, sfile, nfile):
+        """train_val.py:131-150."""
+        self.net.load_state_dict(torch.load(str(sfile), map_location=self.net._device))
+        with open(nfile, 'rb') as fid:
+            st0, cur, perm, cur_val, perm_val, last = [pickle.load(fid) for _ in range(6)]
+        np.random.set_state(st0)
+        if hasattr(self.data_gen, 'set_pointer'):
+            self.data_gen.set_pointer(cur, perm)
+        if hasattr(self.data_gen_val, 'set_pointer'):
+            self.data_gen_val.set_pointer(cur_val, perm_val)
+        return last
+
+    def find_previous(self):
+        """train_val.py:215-241: snapshots by age, without the ones written just before a learning-rate drop."""
+        red = [self._snapshot_name(s + 1, '.pth') for s in cfg.TRAIN.STEPSIZE]
+        sfiles = sorted(glob.glob(self._snapshot_name(0, '.pth').replace('_iter_0.pth', '_iter_*.pth')),
+                        key=os.path.getmtime)
+        sfiles = [s for s in sfiles if s not in red]
+        nfiles = sorted(glob.glob(self._snapshot_name(0, '.pkl').replace('_iter_0.pkl', '_iter_*.pkl')),
+                        key=os.path.getmtime)
+        nfiles = [n for n in nfiles if n not in [r.replace('.pth', '.pkl') for r in red]]
+        assert len(nfiles) == len(sfiles)
+        return len(sfiles), nfiles, sfiles
+
+    def initialize(self):
+        """train_val.py:243-262 (pretrained weights are loaded by the caller through load_state_dict)."""
+        return cfg.TRAIN.LEARNING_RATE, 0, list(cfg.TRAIN.STEPSIZE), [], []
+
+    def restore(self, sfile, nfile):
+        """train_val.py:264-278."""
+        last = self.from_snapshot(sfile, nfile)
+        lr_scale, stepsizes = 1.0, []
+        for stepsize in cfg.TRAIN.STEPSIZE:
+            if last > stepsize:
+                lr_scale *= cfg.TRAIN.GAMMA
+            else:
+                stepsizes.append(stepsize)
+        scale_lr(self.optimizer, lr_scale)
+        return cfg.TRAIN.LEARNING_RATE * lr_scale, last, stepsizes, [nfile], [sfile]
+
+    def remove_snapshot(self, np_paths, ss_paths):
+        """train_val.py:280-294."""
+        for paths in (np_paths, ss_paths):
+            while len(paths) > cfg.TRAIN.SNAPSHOT_KEPT:
+                victim = paths.pop(0)
+                if self.rank == 0 and os.path.exists(victim):
+                    os.remove(str(victim))
+
+    # -- the loop ----------------------------------------------------------------------------------------------
+    def train_model(self, max_iters):
+        """train_val.py:296-503.  Returns the per-iteration losses of this rank."""
+        lr, _ = self.construct_graph()
+        lsf, nfiles, sfiles = self.find_previous()
+        if lsf == 0:
+            lr, last_snapshot_iter, stepsizes, np_paths, ss_paths = self.initialize()
+        else:
+            lr, last_snapshot_iter, stepsizes, np_paths, ss_paths = self.restore(str(sfiles[-1]), str(nfiles[-1]))
+        it = last_snapshot_iter + 1
+        stepsizes.append(max_iters)
+        stepsizes.reverse()
+        next_stepsize = stepsizes.pop()
+        self.net.train()
+        self.optimizer.zero_grad()
+        losses, loss_cumsum = [], 0.0
+        while it < max_iters + 1:
+            update_weights = (it % self.batch_size == 0 and it != 0)
+            if it == next_stepsize + 1:
+                self.snapshot(it)
+                lr *= cfg.TRAIN.GAMMA
+                scale_lr(self.optimizer, cfg.TRAIN.GAMMA)
+                next_stepsize = stepsizes.pop()
+            blobs = self.data_gen.next()
+            if self.val_sum_size and self.data_gen_val is not None and it % self.val_sum_size == 0:
+                for i in range(self.val_batch_size):
+                    out = self.net.run_eval(self.data_gen_val.next(), self.val_batch_size,
+                                            i == self.val_batch_size - 1)
+                    self.val_summaries += [(it, k, v) for k, v in out[0]]
+            if self.sum_size and it % self.sum_size == 0:
+                total_loss, summary = self.net.train_step_with_summary(blobs, self.optimizer, self.sum_size,
+                                                                       update_weights)
+                self.summaries += [(it, k, v) for k, v in summary]
+            else:
+                total_loss = self.net.train_step(blobs, self.optimizer, update_weights)
+            losses.append(total_loss)
+            loss_cumsum += total_loss
+            if self.epoch_size and it % self.epoch_size == 0:
+                self.log('epoch average loss: %f' % (loss_cumsum / self.epoch_size))
+                loss_cumsum = 0.0
+            if it % cfg.TRAIN.SNAPSHOT_ITERS == 0:
+                last_snapshot_iter = it
+                ss_path, np_path = self.snapshot(it)
+                np_paths.append(np_path)
+                ss_paths.append(ss_path)
+                if len(np_paths) > cfg.TRAIN.SNAPSHOT_KEPT:
+                    self.remove_snapshot(np_paths, ss_paths)
+            it += 1
+        if last_snapshot_iter != it - 1:
+            self.snapshot(it - 1)
+        return losses
