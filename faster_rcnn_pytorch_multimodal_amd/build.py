@@ -28,6 +28,7 @@ SOURCES = {
     "train_ops.hip": ["-ffp-contract=off"],
     "targets.hip": ["-ffp-contract=off"],
     "prep.hip": ["-ffp-contract=off"],
+    "batchnorm.hip": ["-ffp-contract=off"],
 }
 COMMON_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -5,8 +5,9 @@ lib/model/train_val.py:458): each node's forward AND backward are libfrcnn_hip.s
 and owns the ``.grad`` buffers; gradient accumulation inside a residual block is fused into the data-gradient
 kernel's epilogue (``add=``), so a Bottleneck is ONE node.
 
-BatchNorm is frozen on this path (lib/nets/imagenet.py:110-116): it is a per-channel scale/shift of the
-convolution output and receives no gradient.  Activations are NHWC; parameters keep the reference's layouts
+BatchNorm of the image detector is frozen (lib/nets/imagenet.py:110-116): a per-channel scale/shift of the
+convolution output that receives no gradient.  The LiDAR backbone trains its BatchNorm layers with batch statistics
+(lib/nets/lidarnet.py:110,152-175): ``_BnTrainFn`` = ``frcnn_bn_train_fwd / _bwd``.  Activations are NHWC; parameters keep the reference's layouts
 (Conv2d (K,C,R,S), Linear (out,in)) and are re-laid out as KRSC through ``hip_modules.prepared_conv`` caches.
 """
 import torch
@@ -130,14 +131,56 @@ class _ConvFn(torch.autograd.Function):
         return dx, d_res, dw, db, None
 
 
+class _BnTrainFn(torch.autograd.Function):
+    """act(batch_norm(y, batch statistics) [+ residual]) - frcnn_bn_train_fwd / _bwd.  The module's running statistics
+    are updated in place by the forward launch (F.batch_norm(training=True))."""
+
+    @staticmethod
+    def forward(ctx, y, residual, gamma, beta, bn, relu):
+        track = bn.track_running_stats and bn.running_mean is not None
+        momentum = bn.momentum
+        if track and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+            if momentum is None:                       # cumulative moving average (torch.nn.modules.batchnorm)
+                momentum = 1.0 / float(bn.num_batches_tracked)
+        out, mean, invstd = ops.bn_train_fwd(y, gamma.detach() if gamma is not None else None,
+                                             beta.detach() if beta is not None else None, bn.eps, momentum or 0.0,
+                                             bn.running_mean if track else None, bn.running_var if track else None,
+                                             residual, relu)
+        if track:
+            bn.__dict__['_frcnn_stats_version'] = bn.__dict__.get('_frcnn_stats_version', 0) + 1
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(y, out if relu else None, gamma, mean, invstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, out, gamma, mean, invstd = ctx.saved_tensors
+        dy, dres, dgamma, dbeta = ops.bn_train_bwd(dout.contiguous(), out, y, gamma.detach() if gamma is not None else None,
+                                                   mean, invstd, relu=ctx.relu,
+                                                   want_res=ctx.has_res and ctx.needs_input_grad[1])
+        return (dy if ctx.needs_input_grad[0] else None, dres, dgamma if ctx.needs_input_grad[2] else None,
+                dbeta if ctx.needs_input_grad[3] else None, None, None)
+
+
 def conv_bn_act_train(x, conv, bn=None, relu=False, residual=None, use_bn=True):
-    """Differentiable counterpart of hip_modules.conv_bn_act (frozen / eval-mode BatchNorm only)."""
+    """Differentiable counterpart of hip_modules.conv_bn_act.  An eval-mode (frozen) BatchNorm is folded into the
+    convolution's epilogue; a BatchNorm in train() mode (LiDAR backbone, lib/nets/lidarnet.py:152-175) runs as its own
+    node on the raw convolution output with batch statistics."""
+    stride, pad = _stride_pad(conv)
     if bn is not None and use_bn and bn.training:
-        raise NotImplementedError("BatchNorm with batch statistics is not on the HIP path (the image detector freezes BN)")
+        w_krsc, _, shift = prepared_conv(conv, None, False)
+        if x.shape[-1] != w_krsc.shape[-1]:
+            raise NotImplementedError("differentiable conv needs C % 4 == 0 inputs (only the frozen stem pads its input)")
+        y = _ConvFn.apply(x, None, conv.weight, conv.bias, (w_krsc, None, shift, stride, pad, False, conv))
+        return _BnTrainFn.apply(y, residual, bn.weight, bn.bias, bn, relu)
+    if bn is not None and use_bn and any(p.requires_grad for p in bn.parameters()):
+        raise NotImplementedError("trainable BatchNorm affine parameters with frozen (eval-mode) statistics are not on "
+                                  "the HIP path: the reference either freezes both or trains both")
     w_krsc, scale, shift = prepared_conv(conv, bn, use_bn)
     if x.shape[-1] != w_krsc.shape[-1]:
         raise NotImplementedError("differentiable conv needs C % 4 == 0 inputs (only the frozen stem pads its input)")
-    stride, pad = _stride_pad(conv)
     # with a folded BN the effective bias is shift = bn.bias - mean*scale (+ conv.bias*scale); conv.bias itself only
     # exists on the BN-free convolutions (RPN, FPN), where shift == conv.bias and d(bias) = sum(d_conv)
     return _ConvFn.apply(x, residual, conv.weight, conv.bias, (w_krsc, scale, shift, stride, pad, relu, conv))
@@ -324,11 +367,20 @@ class _BottleneckFn(torch.autograd.Function):
 
 
 def bottleneck_train(x, block):
-    """Differentiable Bottleneck (frozen BN).  Falls back to the plain inference launches when nothing in or below
-    the block needs a gradient."""
-    for bn in (block.bn1, block.bn2, block.bn3):
-        if block.batchnorm_en and bn.training:
-            raise NotImplementedError("BatchNorm with batch statistics is not on the HIP path")
+    """Differentiable Bottleneck.  With every BatchNorm frozen (image detector) or absent (LiDAR layer4) the block is
+    ONE autograd node; a block holding a BatchNorm in train() mode is the chain conv -> batch-norm node per layer."""
+    bn_on = block.batchnorm_en
+    live = [bn for bn in (block.bn1, block.bn2, block.bn3) if bn_on and bn.training]
+    if block.downsample is not None and block.downsample[1].training:
+        live.append(block.downsample[1])
+    if live:
+        if block.downsample is not None:
+            identity = conv_bn_act_train(x, block.downsample[0], block.downsample[1], relu=False)
+        else:
+            identity = x
+        out = conv_bn_act_train(x, block.conv1, block.bn1, relu=True, use_bn=bn_on)
+        out = conv_bn_act_train(out, block.conv2, block.bn2, relu=True, use_bn=bn_on)
+        return conv_bn_act_train(out, block.conv3, block.bn3, relu=True, residual=identity, use_bn=bn_on)
     weights = [block.conv1.weight, block.conv2.weight, block.conv3.weight]
     if block.downsample is not None:
         weights.append(block.downsample[0].weight)

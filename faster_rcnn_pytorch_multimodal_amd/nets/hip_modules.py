@@ -30,7 +30,10 @@ def prepared_conv(conv, bn=None, use_bn=True):
     key_tensors = [conv.weight, conv.bias]
     if bn is not None:
         key_tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
-    key = (_versions(*key_tensors), str(conv.weight.device))
+    # the batch-norm training kernel updates the running statistics through raw pointers (no torch version bump):
+    # autograd_ops._BnTrainFn counts those updates on the module instead
+    stats_version = bn.__dict__.get('_frcnn_stats_version', 0) if bn is not None else 0
+    key = (_versions(*key_tensors), str(conv.weight.device), stats_version)
     cache = conv.__dict__.get('_frcnn_prepared')
     if cache is not None and cache[0] == key:
         return cache[1]

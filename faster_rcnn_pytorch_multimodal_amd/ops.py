@@ -410,6 +410,55 @@ def act_bwd(dy, y=None, scale=None, relu=False, want_res=False):
     return d_conv, d_res
 
 
+def bn_train_fwd(y, gamma, beta, eps, momentum, running_mean=None, running_var=None, residual=None, relu=False):
+    """BatchNorm with batch statistics over the rows of an NHWC tensor (+ residual, ReLU); the running statistics are
+    updated in place.  Returns (out, save_mean, save_invstd)."""
+    lib = _hip.load()
+    _dev_f32(y, "y")
+    c = y.shape[-1]
+    rows = y.numel() // c
+    for nm, t in (("gamma", gamma), ("beta", beta), ("running_mean", running_mean), ("running_var", running_var)):
+        if t is not None:
+            _dev_f32(t, nm)
+            if t.numel() != c:
+                raise _hip.HipError("bn_train_fwd: %s has %d elements, expected %d" % (nm, t.numel(), c))
+    if residual is not None:
+        _dev_f32(residual, "residual")
+        if residual.shape != y.shape:
+            raise _hip.HipError("bn_train_fwd: residual %s vs %s" % (tuple(residual.shape), tuple(y.shape)))
+    out = torch.empty_like(y)
+    mean = torch.empty((c,), dtype=torch.float32, device=y.device)
+    invstd = torch.empty_like(mean)
+    nbytes = lib.frcnn_bn_train_ws_bytes(c)
+    ws = _workspace(nbytes, y.device)
+    _hip.check(lib.frcnn_bn_train_fwd(_ptr(y), rows, c, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
+                                      _ptr(running_mean), _ptr(running_var), _ptr(residual), int(bool(relu)), _ptr(out),
+                                      _ptr(mean), _ptr(invstd), _ptr(ws), nbytes, _stream()), "frcnn_bn_train_fwd")
+    return out, mean, invstd
+
+
+def bn_train_bwd(dout, out, y, gamma, save_mean, save_invstd, relu=False, want_res=False):
+    """Backward of bn_train_fwd: returns (dy, dres or None, dgamma, dbeta)."""
+    lib = _hip.load()
+    _dev_f32(dout, "dout"); _dev_f32(y, "y"); _dev_f32(save_mean, "save_mean"); _dev_f32(save_invstd, "save_invstd")
+    if relu:
+        _dev_f32(out, "out")
+    c = y.shape[-1]
+    rows = y.numel() // c
+    if dout.shape != y.shape or save_mean.numel() != c or save_invstd.numel() != c:
+        raise _hip.HipError("bn_train_bwd: shape mismatch")
+    dy = torch.empty_like(y)
+    dres = torch.empty_like(y) if want_res else None
+    dgamma = torch.empty((c,), dtype=torch.float32, device=y.device)
+    dbeta = torch.empty_like(dgamma)
+    nbytes = lib.frcnn_bn_train_ws_bytes(c)
+    ws = _workspace(nbytes, y.device)
+    _hip.check(lib.frcnn_bn_train_bwd(_ptr(dout), _ptr(out) if relu else None, _ptr(y), rows, c, _ptr(gamma),
+                                      _ptr(save_mean), _ptr(save_invstd), int(bool(relu)), _ptr(dy), _ptr(dres),
+                                      _ptr(dgamma), _ptr(dbeta), _ptr(ws), nbytes, _stream()), "frcnn_bn_train_bwd")
+    return dy, dres, dgamma, dbeta
+
+
 def upsample_bilinear_add(x, lateral):
     """F.interpolate(x, size=lateral.shape[1:3], mode='bilinear', align_corners=False) + lateral, NHWC."""
     lib = _hip.load()

@@ -231,6 +231,23 @@ int frcnn_filter_per_class(float* pred_boxes, const float* cls_prob, const int* 
 int frcnn_act_bwd(const float* dy, const float* y, const float* scale, int relu, int64_t rows, int k,
                   float* d_conv, float* d_res, void* stream);
 
+/* BatchNorm2d with BATCH statistics (module in train() mode; the LiDAR backbone trains layer2/layer3 this way,
+ * lib/nets/lidarnet.py:110,152-175; torch.nn.functional.batch_norm(training=True)).  y/out/residual/dout/dy/dres are
+ * rows x c fp32 (NHWC activations), c % 4 == 0.
+ *   fwd: mean/biased var over the rows -> save_mean, save_invstd = 1/sqrt(var+eps);
+ *        out = act((y - mean)*alpha + beta [+ residual]), alpha = gamma*invstd (gamma/beta may be NULL = 1/0);
+ *        running_mean/var (may be NULL) <- (1-momentum)*running + momentum*(mean | UNBIASED var).
+ *   bwd: g = relu ? (out > 0 ? dout : 0) : dout; dbeta = sum g; dgamma = sum g*xhat;
+ *        dy = gamma*invstd*(g - dbeta/rows - xhat*dgamma/rows); dres = g (may be NULL).
+ * Column sums are carried in fp64 and added in a fixed order. */
+size_t frcnn_bn_train_ws_bytes(int c);
+int frcnn_bn_train_fwd(const float* y, int64_t rows, int c, const float* gamma, const float* beta, float eps,
+                       float momentum, float* running_mean, float* running_var, const float* residual, int relu,
+                       float* out, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, void* stream);
+int frcnn_bn_train_bwd(const float* dout, const float* out, const float* y, int64_t rows, int c, const float* gamma,
+                       const float* save_mean, const float* save_invstd, int relu, float* dy, float* dres,
+                       float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+
 /* fc7 = x.mean(3).mean(2) (_head_to_tail of the non-FPN detector; x (rows,P,P,c) NHWC -> out (rows,c)) and its
  * backward dx = dout / P^2 broadcast over the P x P positions. */
 int frcnn_spatial_mean_fwd(const float* x, float* out, int rows, int pooled, int c, void* stream);

@@ -1026,6 +1026,57 @@ def test_fpn_train_step_end_to_end(hip):
     C.reset_cfg()
 
 
+@pytest.mark.parametrize("rows,c,relu,res", [(8800, 128, True, False), (2200, 1024, True, True), (1, 8, False, False),
+                                            (12544, 2048, False, False), (777, 36, True, True)])
+def test_batchnorm_batch_statistics_fwd_bwd(hip, rows, c, relu, res):
+    """frcnn_bn_train_fwd/_bwd against torch-CPU F.batch_norm(training=True) and its autograd (the LiDAR backbone's
+    train()-mode BatchNorm, lib/nets/lidarnet.py:152-175): output, saved statistics, running statistics (unbiased
+    variance), d_input, d_residual, d_gamma, d_beta."""
+    from faster_rcnn_pytorch_multimodal_amd import ops
+    g = torch.Generator().manual_seed(rows + c)
+    y = (torch.randn(rows, c, generator=g) * 3 + torch.randn(c, generator=g) * 5).requires_grad_(True)
+    gamma = (torch.rand(c, generator=g) + 0.5).requires_grad_(True)
+    beta = torch.randn(c, generator=g).requires_grad_(True)
+    resid = torch.randn(rows, c, generator=g).requires_grad_(True) if res else None
+    rm, rv = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    eps, mom = 1e-5, 0.1
+    ref = F.batch_norm(y.t().reshape(1, c, rows, 1) if rows > 1 else y.t().reshape(1, c, 1, 1).expand(2, c, 1, 1),
+                       rm_ref, rv_ref, gamma, beta, True, mom, eps) if rows > 1 else None
+    if rows == 1:
+        # a single row has zero variance: out = beta, invstd = 1/sqrt(eps); torch refuses 1 value per channel
+        out, mean, invstd = ops.bn_train_fwd(y.detach().to(DEV), gamma.detach().to(DEV), beta.detach().to(DEV), eps, mom)
+        np.testing.assert_allclose(out.cpu().numpy(), beta.detach().numpy()[None], atol=1e-6)
+        np.testing.assert_allclose(mean.cpu().numpy(), y.detach().numpy()[0], atol=0)
+        return
+    ref = ref.reshape(c, rows).t()
+    if res:
+        ref = ref + resid
+    if relu:
+        ref = F.relu(ref)
+    dout = torch.randn(rows, c, generator=g)
+    ref.backward(dout)
+    rm_d, rv_d = rm.to(DEV), rv.to(DEV)
+    out, mean, invstd = ops.bn_train_fwd(y.detach().to(DEV), gamma.detach().to(DEV), beta.detach().to(DEV), eps, mom, rm_d, rv_d,
+                                         resid.detach().to(DEV) if res else None, relu)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=2e-5)
+    yd = y.detach().double()
+    np.testing.assert_allclose(mean.cpu().numpy(), yd.mean(0).float().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(invstd.cpu().numpy(), (1.0 / torch.sqrt(yd.var(0, unbiased=False) + eps)).float().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(rm_d.cpu().numpy(), rm_ref.numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(rv_d.cpu().numpy(), rv_ref.numpy(), rtol=1e-5, atol=1e-6)
+    dy, dres, dgamma, dbeta = ops.bn_train_bwd(dout.to(DEV), out, y.detach().to(DEV), gamma.detach().to(DEV), mean, invstd,
+                                               relu=relu, want_res=res)
+    scale = float(y.grad.abs().max())
+    np.testing.assert_allclose(dy.cpu().numpy(), y.grad.numpy(), rtol=1e-4, atol=2e-5 * max(scale, 1.0))
+    np.testing.assert_allclose(dgamma.cpu().numpy(), gamma.grad.numpy(), rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(dbeta.cpu().numpy(), beta.grad.numpy(), rtol=2e-4, atol=2e-3)
+    if res:
+        np.testing.assert_array_equal(dres.cpu().numpy(), resid.grad.numpy())
+    else:
+        assert dres is None
+
+
 def test_solver_loop_on_device(hip, tmp_path):
     """model/train_val.SolverWrapper (lib/model/train_val.py:296-503) driving the HIP network: gradients of every
     trainable filter accumulate inside the flat bucket (views, no copies), the optimizer steps every batch_size
