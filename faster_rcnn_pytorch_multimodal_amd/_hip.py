@@ -68,6 +68,8 @@ PROTOTYPES = {
     "frcnn_rpn_loss_ws_bytes": (c_size_t, []),
     "frcnn_rpn_loss": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, c_size_t, _P]),
     "frcnn_det_loss": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_float, c_float, _P, _P, _P, _P]),
+    "frcnn_det_loss_lidar": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, POINTER(c_float), c_int, c_float, c_float, _P,
+                                     _P, _P, _P]),
     "frcnn_bbox_overlaps": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, _P]),
     "frcnn_anchor_target_layer_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "frcnn_anchor_target_layer": (c_int, [_P, c_int, _P, c_int, POINTER(c_float), c_int, c_float, c_float, c_float,
@@ -75,6 +77,9 @@ PROTOTYPES = {
     "frcnn_proposal_target_layer": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_float, c_float, c_float,
                                             c_float, POINTER(c_float), POINTER(c_float), c_uint32, _P, _P, _P, _P, _P,
                                             _P, _P, _P, _P]),
+    "frcnn_proposal_target_layer_lidar": (c_int, [_P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_float, c_float,
+                                                  c_float, c_float, POINTER(c_float), POINTER(c_float), c_uint32, _P, _P,
+                                                  _P, _P, _P, _P, _P, _P, _P, _P]),
     "frcnn_filter_per_class_ws_bytes": (c_size_t, [c_int, c_int]),
     "frcnn_filter_per_class": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int,
                                        c_int, _P, _P, _P, c_size_t, _P]),

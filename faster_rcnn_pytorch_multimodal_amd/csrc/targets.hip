@@ -179,11 +179,32 @@ __global__ __launch_bounds__(256) void atl_finalize_kernel(const float* __restri
 constexpr int PTL_THREADS = 1024;
 
 struct PtlNorm {
-  float means[4], stds[4];
+  float means[7], stds[7];
 };
 
+// lidar_3d_bbox_transform (lib/model/bbox_transform.py:16-49): centre deltas over the RoI's BEV diagonal, z and the
+// height from the RoI's 3-D anchor, yaw = the gt yaw itself.
+__device__ __forceinline__ void encode_box_lidar(const float* roi, const float* anc, const float* gt7, float* o) {
+  const float ln = roi[2] - roi[0] + 1.f, wd = roi[3] - roi[1] + 1.f, ht = anc[5];
+  const float cx = roi[0] + ln / 2.0f, cy = roi[1] + wd / 2.0f, cz = anc[2];
+  const float diag = sqrtf(ln * ln + wd * wd);
+  o[0] = (gt7[0] - cx) / diag;
+  o[1] = (gt7[1] - cy) / diag;
+  o[2] = (gt7[2] - cz) / ht;
+  o[3] = logf(gt7[3] / ln);
+  o[4] = logf(gt7[4] / wd);
+  o[5] = logf(gt7[5] / ht);
+  o[6] = gt7[6];
+}
+
+// E = 4: image detector (gt rows [x1,y1,x2,y2,cls]).  E = 7: LiDAR detector - overlaps on the BEV rectangles `gt`,
+// regression targets against `true_gt` rows [xc,yc,zc,l,w,h,ry,cls] and the RoI's 3-D anchor, which is carried along.
+template <int E>
 __global__ __launch_bounds__(PTL_THREADS) void ptl_kernel(const float* __restrict__ rois, const float* __restrict__ scores,
                                                          const int* __restrict__ roi_count, int num_rois,
+                                                         const float* __restrict__ anchors3d,
+                                                         const float* __restrict__ true_gt,
+                                                         float* __restrict__ out_anchors3d,
                                                          const float* __restrict__ gt, int g, int num_classes,
                                                          int rois_per_frame, int fg_quota, float fg_thresh, float bg_hi,
                                                          float bg_lo, PtlNorm norm, uint32_t seed, int npad,
@@ -228,7 +249,7 @@ __global__ __launch_bounds__(PTL_THREADS) void ptl_kernel(const float* __restric
   else if (nfg_c > 0) { n_fg = rois_per_frame; n_bg = 0; }
   else { n_fg = 0; n_bg = nbg_c > 0 ? rois_per_frame : 0; }
   if (t == 0) { out_counts[0] = n_fg; out_counts[1] = n_bg; out_counts[2] = nfg_c; out_counts[3] = nbg_c; }
-  const int cols = 4 * num_classes;
+  const int cols = E * num_classes;
   for (int j = t; j < rois_per_frame; j += PTL_THREADS) {
     int src = -1;
     bool is_fg = false;
@@ -259,15 +280,18 @@ __global__ __launch_bounds__(PTL_THREADS) void ptl_kernel(const float* __restric
       if (is_fg) lab = gb[4];                                  // :198,238: class of the assigned gt, bg rows -> 0
       const int c = (int)lab;
       if (c > 0 && c < num_classes) {
-        float o[4];
-        encode_box(r5 + 1, gb, o);
-        for (int q = 0; q < 4; ++q) {                          // :160-163 normalised targets, :64-103 class slot
-          tr[4 * c + q] = (o[q] - norm.means[q]) / norm.stds[q];
-          ir[4 * c + q] = 1.f;
-          orow[4 * c + q] = 1.f;
+        float o[E];
+        if (E == 7) encode_box_lidar(r5 + 1, anchors3d + (size_t)src * 7, true_gt + (size_t)as * 8, o);
+        else encode_box(r5 + 1, gb, o);
+        for (int q = 0; q < E; ++q) {                          // :142-163 normalised targets, :64-103 class slot
+          tr[E * c + q] = (o[q] - norm.means[q]) / norm.stds[q];
+          ir[E * c + q] = 1.f;
+          orow[E * c + q] = 1.f;
         }
       }
     }
+    if (E == 7)
+      for (int q = 0; q < 7; ++q) out_anchors3d[(size_t)j * 7 + q] = src >= 0 ? anchors3d[(size_t)src * 7 + q] : 0.f;
     out_labels[j] = lab;
     for (int q = 0; q < 5; ++q) out_rois[(size_t)j * 5 + q] = r5[q];
     out_scores[j] = sc;
@@ -385,6 +409,34 @@ extern "C" int frcnn_anchor_target_layer(const float* anchors, int n, const floa
   return FRCNN_OK;
 }
 
+namespace {
+template <int E>
+int launch_ptl(const float* rois, const float* roi_scores, const int* roi_count, int num_rois, const float* anchors3d,
+               const float* true_gt, float* out_anchors3d, const float* gt_boxes, int num_gt, int num_classes,
+               int rois_per_frame, float fg_fraction, float fg_thresh, float bg_thresh_hi, float bg_thresh_lo,
+               const float* means_host, const float* stds_host, uint32_t seed, float* labels, float* out_rois,
+               float* out_scores, float* targets, float* inside, float* outside, int* gt_assignment, int* counts,
+               void* stream_) {
+  PtlNorm norm;
+  for (int q = 0; q < 7; ++q) { norm.means[q] = q < E ? means_host[q] : 0.f; norm.stds[q] = q < E ? stds_host[q] : 1.f; }
+  const int npad = next_pow2(std::max(num_rois, 2));
+  const size_t lds = (size_t)npad * 16 + (size_t)num_rois * 4;
+  static size_t configured = 0;
+  if (lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ptl_kernel<E>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "proposal_target_layer: set LDS size: %s", hipGetErrorString(e));
+    configured = lds;
+  }
+  const int fg_quota = (int)lrintf(fg_fraction * (float)rois_per_frame);   // int(round(...)) (:44-45)
+  hipLaunchKernelGGL(ptl_kernel<E>, dim3(1), dim3(PTL_THREADS), lds, static_cast<hipStream_t>(stream_), rois, roi_scores,
+                     roi_count, num_rois, anchors3d, true_gt, out_anchors3d, gt_boxes, num_gt, num_classes,
+                     rois_per_frame, fg_quota, fg_thresh, bg_thresh_hi, bg_thresh_lo, norm, seed, npad, labels, out_rois,
+                     out_scores, targets, inside, outside, gt_assignment, counts);
+  return check_launch("ptl_kernel");
+}
+}  // namespace
+
 extern "C" int frcnn_proposal_target_layer(const float* rois, const float* roi_scores, const int* roi_count,
                                            int num_rois, const float* gt_boxes, int num_gt, int num_classes,
                                            int rois_per_frame, float fg_fraction, float fg_thresh, float bg_thresh_hi,
@@ -396,21 +448,25 @@ extern "C" int frcnn_proposal_target_layer(const float* rois, const float* roi_s
                     outside && gt_assignment && counts && num_rois > 0 && num_rois <= 4096 && num_gt > 0 &&
                     num_classes > 1 && rois_per_frame > 0,
                 "proposal_target_layer: bad arguments (num_rois <= 4096, at least one gt box)");
-  PtlNorm norm;
-  for (int q = 0; q < 4; ++q) { norm.means[q] = means_host[q]; norm.stds[q] = stds_host[q]; }
-  const int npad = next_pow2(std::max(num_rois, 2));
-  const size_t lds = (size_t)npad * 16 + (size_t)num_rois * 4;
-  static size_t configured = 0;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ptl_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "proposal_target_layer: set LDS size: %s", hipGetErrorString(e));
-    configured = lds;
-  }
-  const int fg_quota = (int)lrintf(fg_fraction * (float)rois_per_frame);   // int(round(...)) (:44-45)
-  hipLaunchKernelGGL(ptl_kernel, dim3(1), dim3(PTL_THREADS), lds, static_cast<hipStream_t>(stream_), rois, roi_scores,
-                     roi_count, num_rois, gt_boxes, num_gt, num_classes, rois_per_frame, fg_quota, fg_thresh, bg_thresh_hi,
-                     bg_thresh_lo, norm, seed, npad, labels, out_rois, out_scores, targets, inside, outside, gt_assignment,
-                     counts);
-  return check_launch("ptl_kernel");
+  return launch_ptl<4>(rois, roi_scores, roi_count, num_rois, nullptr, nullptr, nullptr, gt_boxes, num_gt, num_classes,
+                       rois_per_frame, fg_fraction, fg_thresh, bg_thresh_hi, bg_thresh_lo, means_host, stds_host, seed,
+                       labels, out_rois, out_scores, targets, inside, outside, gt_assignment, counts, stream_);
+}
+
+extern "C" int frcnn_proposal_target_layer_lidar(const float* rois, const float* roi_scores, const int* roi_count,
+                                                 int num_rois, const float* anchors3d, const float* gt_boxes,
+                                                 const float* true_gt_boxes, int num_gt, int num_classes,
+                                                 int rois_per_frame, float fg_fraction, float fg_thresh,
+                                                 float bg_thresh_hi, float bg_thresh_lo, const float* means_host,
+                                                 const float* stds_host, uint32_t seed, float* labels, float* out_rois,
+                                                 float* out_scores, float* out_anchors3d, float* targets, float* inside,
+                                                 float* outside, int* gt_assignment, int* counts, void* stream_) {
+  FRCNN_REQUIRE(rois && anchors3d && gt_boxes && true_gt_boxes && means_host && stds_host && labels && out_rois &&
+                    out_scores && out_anchors3d && targets && inside && outside && gt_assignment && counts &&
+                    num_rois > 0 && num_rois <= 4096 && num_gt > 0 && num_classes > 1 && rois_per_frame > 0,
+                "proposal_target_layer_lidar: bad arguments (num_rois <= 4096, at least one gt box)");
+  return launch_ptl<7>(rois, roi_scores, roi_count, num_rois, anchors3d, true_gt_boxes, out_anchors3d, gt_boxes, num_gt,
+                       num_classes, rois_per_frame, fg_fraction, fg_thresh, bg_thresh_hi, bg_thresh_lo, means_host,
+                       stds_host, seed, labels, out_rois, out_scores, targets, inside, outside, gt_assignment, counts,
+                       stream_);
 }

@@ -335,10 +335,18 @@ __global__ __launch_bounds__(256) void rpn_loss_grad_kernel(const float* __restr
 // smooth_l1_loss('DET', bbox_pred, targets, inside, outside) = mean over RoIs of the row sums.
 // One workgroup: fixed-order reductions, then the gradients.  losses[0] = CE, losses[1] = box loss.
 // ------------------------------------------------------------------------------------------------
+// LiDAR 'DET' stage (loss_utils.py:61-77): the element `sin_elem` of every E-group (the yaw) goes through sin()
+// before the Huber term (cfg.LIDAR.EN_RY_SIN), and each element is scaled by cfg.LIDAR.REG_LOSS_WEIGHT.
+struct DetLossOpt {
+  float w[8];
+  int sin_elem;   // -1: plain smooth-L1 on every element (image detector)
+};
+
 __global__ __launch_bounds__(256) void det_loss_kernel(const float* __restrict__ cls_score, const float* __restrict__ labels,
                                                       int R, int K, const float* __restrict__ bbox_pred,
                                                       const float* __restrict__ targets, const float* __restrict__ inside,
-                                                      const float* __restrict__ outside, int E, float g_ce, float g_box,
+                                                      const float* __restrict__ outside, int E, DetLossOpt opt, float g_ce,
+                                                      float g_box,
                                                       float* __restrict__ losses, float* __restrict__ dcls,
                                                       float* __restrict__ dbox) {
   __shared__ float red[4];
@@ -358,9 +366,16 @@ __global__ __launch_bounds__(256) void det_loss_kernel(const float* __restrict__
     float rowsum = 0.f;
     for (int q = 0; q < cols; ++q) {
       const size_t o = (size_t)r * cols + q;
-      const float diff = bbox_pred[o] * inside[o] - targets[o] * inside[o];
-      rowsum += outside[o] * huber1(diff);
-      if (dbox) dbox[o] = g_box / (float)R * outside[o] * huber1_grad(diff) * inside[o];
+      float diff = bbox_pred[o] * inside[o] - targets[o] * inside[o];
+      const int e = q % E;
+      float chain = inside[o];
+      if (e == opt.sin_elem) {
+        chain = chain * cosf(diff);
+        diff = sinf(diff);
+      }
+      const float we = e < 8 ? opt.w[e] : 1.f;
+      rowsum += outside[o] * (huber1(diff) * we);
+      if (dbox) dbox[o] = g_box / (float)R * outside[o] * (huber1_grad(diff) * we) * chain;
     }
     box += rowsum;
   }
@@ -460,14 +475,38 @@ extern "C" int frcnn_rpn_loss(const float* rpn, int ld, int num_anchors, int hw,
   return check_launch("rpn_loss_grad_kernel");
 }
 
-extern "C" int frcnn_det_loss(const float* cls_score, const float* labels, int num_rois, int num_classes,
-                              const float* bbox_pred, const float* targets, const float* inside, const float* outside,
-                              int bbox_elem, float grad_ce, float grad_box, float* losses, float* dcls, float* dbox,
-                              void* stream_) {
+namespace {
+int launch_det_loss(const float* cls_score, const float* labels, int num_rois, int num_classes, const float* bbox_pred,
+                    const float* targets, const float* inside, const float* outside, int bbox_elem, DetLossOpt opt,
+                    float grad_ce, float grad_box, float* losses, float* dcls, float* dbox, void* stream_) {
   FRCNN_REQUIRE(cls_score && labels && bbox_pred && targets && inside && outside && losses && num_rois > 0 &&
                     num_rois <= 4096 && num_classes > 1 && bbox_elem > 0,
                 "det_loss: bad arguments (num_rois <= 4096)");
   hipLaunchKernelGGL(det_loss_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream_), cls_score, labels, num_rois,
-                     num_classes, bbox_pred, targets, inside, outside, bbox_elem, grad_ce, grad_box, losses, dcls, dbox);
+                     num_classes, bbox_pred, targets, inside, outside, bbox_elem, opt, grad_ce, grad_box, losses, dcls,
+                     dbox);
   return check_launch("det_loss_kernel");
+}
+}  // namespace
+
+extern "C" int frcnn_det_loss(const float* cls_score, const float* labels, int num_rois, int num_classes,
+                              const float* bbox_pred, const float* targets, const float* inside, const float* outside,
+                              int bbox_elem, float grad_ce, float grad_box, float* losses, float* dcls, float* dbox,
+                              void* stream_) {
+  DetLossOpt opt;
+  for (int e = 0; e < 8; ++e) opt.w[e] = 1.f;
+  opt.sin_elem = -1;
+  return launch_det_loss(cls_score, labels, num_rois, num_classes, bbox_pred, targets, inside, outside, bbox_elem, opt,
+                         grad_ce, grad_box, losses, dcls, dbox, stream_);
+}
+
+extern "C" int frcnn_det_loss_lidar(const float* cls_score, const float* labels, int num_rois, int num_classes,
+                                    const float* bbox_pred, const float* targets, const float* inside,
+                                    const float* outside, const float* reg_loss_weight_host, int ry_sin, float grad_ce,
+                                    float grad_box, float* losses, float* dcls, float* dbox, void* stream_) {
+  DetLossOpt opt;
+  for (int e = 0; e < 8; ++e) opt.w[e] = (reg_loss_weight_host && e < 7) ? reg_loss_weight_host[e] : 1.f;
+  opt.sin_elem = ry_sin ? 6 : -1;
+  return launch_det_loss(cls_score, labels, num_rois, num_classes, bbox_pred, targets, inside, outside, 7, opt, grad_ce,
+                         grad_box, losses, dcls, dbox, stream_);
 }

@@ -1,11 +1,14 @@
 """Second-stage RoI sampling and regression targets on the device — counterpart of
-lib/layer_utils/proposal_target_layer.py:22-262 for the image detector.
+lib/layer_utils/proposal_target_layer.py:22-262 (image detector and the 7-DoF LiDAR form).
 
 ``frcnn_proposal_target_layer`` (one workgroup): IoU (+1 convention) of every proposal with every gt box,
 foreground (>= FG_THRESH) / background ([BG_THRESH_LO, BG_THRESH_HI)) candidates, random sampling to
 ROI_BATCH_SIZE rows with at most FG_FRACTION foreground (with replacement when a pool is too small, :207-231),
 bbox_transform targets normalised by cfg.TRAIN.IMAGE.BBOX_NORMALIZE_{MEANS,STDS} and expanded to the 4-of-4K
 class layout (:64-103).  Foreground rows come first, like the reference's ``torch.cat([fg_inds, bg_inds])``.
+LiDAR (NET_TYPE 'lidar', :142-154,239-243): overlaps on the BEV rectangles, ``lidar_3d_bbox_transform`` targets against
+the 8-column ``true_gt_boxes`` and each RoI's 3-D anchor, normalised by cfg.TRAIN.LIDAR.BBOX_NORMALIZE_*, 7-of-7K
+layout; the sampled rows' 3-D anchors are returned as well.
 """
 import torch
 
@@ -14,12 +17,18 @@ from ..model.config import cfg
 from .anchor_target_layer import _draw_seed
 
 
-def proposal_target_layer_device(rpn_rois, rpn_scores, gt_boxes, num_classes, roi_count=None, seed=None):
+def proposal_target_layer_device(rpn_rois, rpn_scores, gt_boxes, num_classes, roi_count=None, seed=None,
+                                 anchors_3d=None, true_gt_boxes=None):
     if cfg.TRAIN.USE_GT or cfg.TRAIN.IGNORE_DC:
         raise NotImplementedError("TRAIN.USE_GT / TRAIN.IGNORE_DC are not on the HIP path")
-    if cfg.NET_TYPE != 'image':
-        raise NotImplementedError("proposal targets for the LiDAR detector are not on the HIP path")
     scores = None if rpn_scores is None else rpn_scores.contiguous().view(-1)
+    if anchors_3d is not None:
+        return ops.proposal_target_layer(rpn_rois.contiguous(), scores, gt_boxes[:, :5].contiguous(), num_classes,
+                                         cfg.TRAIN.ROI_BATCH_SIZE, cfg.TRAIN.FG_FRACTION, cfg.TRAIN.FG_THRESH,
+                                         cfg.TRAIN.BG_THRESH_HI, cfg.TRAIN.BG_THRESH_LO,
+                                         cfg.TRAIN.LIDAR.BBOX_NORMALIZE_MEANS, cfg.TRAIN.LIDAR.BBOX_NORMALIZE_STDS,
+                                         _draw_seed() if seed is None else seed, roi_count=roi_count,
+                                         anchors_3d=anchors_3d.contiguous(), true_gt_boxes=true_gt_boxes.contiguous())
     return ops.proposal_target_layer(rpn_rois.contiguous(), scores, gt_boxes[:, :5].contiguous(), num_classes,
                                      cfg.TRAIN.ROI_BATCH_SIZE, cfg.TRAIN.FG_FRACTION, cfg.TRAIN.FG_THRESH,
                                      cfg.TRAIN.BG_THRESH_HI, cfg.TRAIN.BG_THRESH_LO,
@@ -31,8 +40,11 @@ def proposal_target_layer(rpn_rois, rpn_scores, anchors_3d, gt_boxes, true_gt_bo
                           num_bbox_elem):
     """Reference signature (:22) and return tuple: labels (R,1), rois (R,5), anchors_3d, roi_scores (R,),
     bbox_targets, bbox_inside_weights, bbox_outside_weights."""
-    if num_bbox_elem != 4:
-        raise NotImplementedError("7-DoF (LiDAR) proposal targets are not on the HIP path")
+    if num_bbox_elem == 7:
+        out = proposal_target_layer_device(rpn_rois, rpn_scores, gt_boxes, _num_classes, anchors_3d=anchors_3d,
+                                           true_gt_boxes=true_gt_boxes)
+        return (out["labels"].view(-1, 1), out["rois"], out["anchors_3d"], out["scores"], out["targets"], out["inside"],
+                out["outside"])
     out = proposal_target_layer_device(rpn_rois, rpn_scores, gt_boxes, _num_classes)
     return (out["labels"].view(-1, 1), out["rois"], anchors_3d, out["scores"], out["targets"], out["inside"],
             out["outside"])

@@ -483,16 +483,17 @@ def rpn_loss_train(rpn2d, labels, targets, inside, outside, num_anchors):
 
 class _DetLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cls_score, bbox_pred, labels, targets, inside, outside):
-        losses, dcls, dbox = ops.det_loss(cls_score, labels, bbox_pred, targets, inside, outside, 4, 1.0, 1.0)
+    def forward(ctx, cls_score, bbox_pred, labels, targets, inside, outside, lidar):
+        losses, dcls, dbox = ops.det_loss(cls_score, labels, bbox_pred, targets, inside, outside, 4, 1.0, 1.0, lidar=lidar)
         ctx.save_for_backward(dcls, dbox)
         return losses
 
     @staticmethod
     def backward(ctx, g):
         dcls, dbox = ctx.saved_tensors
-        return dcls * g[0], dbox * g[1], None, None, None, None
+        return dcls * g[0], dbox * g[1], None, None, None, None, None
 
 
-def det_loss_train(cls_score, bbox_pred, labels, targets, inside, outside):
-    return _DetLossFn.apply(cls_score.contiguous(), bbox_pred.contiguous(), labels, targets, inside, outside)
+def det_loss_train(cls_score, bbox_pred, labels, targets, inside, outside, lidar=None):
+    """``lidar=(REG_LOSS_WEIGHT, EN_RY_SIN)`` selects the 7-element form of lib/utils/loss_utils.py:61-77."""
+    return _DetLossFn.apply(cls_score.contiguous(), bbox_pred.contiguous(), labels, targets, inside, outside, lidar)

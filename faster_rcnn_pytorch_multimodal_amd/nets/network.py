@@ -31,6 +31,7 @@ from ..layer_utils.proposal_layer import proposal_layer_device
 from ..layer_utils.proposal_target_layer import proposal_target_layer_device
 from ..layer_utils.snippets import generate_anchors_pre
 from ..model.config import cfg
+from ..utils.bbox import bbaa_graphics_gems
 from . import resnet as custom_resnet
 from . import autograd_ops
 from .autograd_ops import (conv_bn_act_train, det_loss_train, fused_head_train, fused_head_weights, linear_train,
@@ -318,8 +319,15 @@ class Network(nn.Module):
                 self._proposal_targets = dict(ov['proposal'])
             else:
                 p = self._predictions
-                self._proposal_targets = proposal_target_layer_device(p['rois'], p['roi_scores'], self._gt_boxes,
-                                                                      self._num_classes, roi_count=p['rois_count'])
+                if cfg.NET_TYPE == 'lidar':
+                    self._proposal_targets = proposal_target_layer_device(
+                        p['rois'], p['roi_scores'], self._gt_boxes, self._num_classes, roi_count=p['rois_count'],
+                        anchors_3d=p['roi_anchors_3d'], true_gt_boxes=self._true_gt_boxes)
+                else:
+                    self._proposal_targets = proposal_target_layer_device(p['rois'], p['roi_scores'], self._gt_boxes,
+                                                                          self._num_classes, roi_count=p['rois_count'])
+        if 'anchors_3d' in self._proposal_targets:
+            self._predictions['roi_anchors_3d'] = self._proposal_targets['anchors_3d']   # follows the sampled rows
         self._predictions['rois_sampled'] = self._proposal_targets['rois']
         self._predictions['rois_count'] = None            # every sampled row is live
         return self._proposal_targets['rois']
@@ -330,7 +338,9 @@ class Network(nn.Module):
         hw, ld = rpn_out.shape[1] * rpn_out.shape[2], rpn_out.shape[3]
         rpn_l = rpn_loss_train(rpn_out.view(hw, ld), at['labels'], at['targets'], at['inside'], at['outside'],
                                self._num_anchors)
-        det_l = det_loss_train(p['cls_score'], p['bbox_pred'], pt['labels'], pt['targets'], pt['inside'], pt['outside'])
+        lidar = (tuple(cfg.LIDAR.REG_LOSS_WEIGHT), bool(cfg.LIDAR.EN_RY_SIN)) if cfg.NET_TYPE == 'lidar' else None
+        det_l = det_loss_train(p['cls_score'], p['bbox_pred'], pt['labels'], pt['targets'], pt['inside'], pt['outside'],
+                               lidar=lidar)
         self._losses = {'rpn_cross_entropy': rpn_l[0], 'rpn_loss_box': rpn_l[1], 'cross_entropy': det_l[0],
                         'loss_box': det_l[1]}
         self._losses['total_loss'] = rpn_l[0] + rpn_l[1] + det_l[0] + det_l[1]
@@ -355,9 +365,18 @@ class Network(nn.Module):
         if mode == 'TEST':
             with torch.no_grad():
                 return self._predict()
-        if cfg.NET_TYPE != 'image':
-            raise NotImplementedError("training the LiDAR detector is not on the HIP path yet")
         gt = np.asarray(gt_boxes, dtype=np.float32) if not isinstance(gt_boxes, torch.Tensor) else gt_boxes
+        if cfg.NET_TYPE == 'lidar':
+            # blobs['gt_boxes'] rows are [xc,yc,zc,l,w,h,ry,cls] in voxel-grid units (minibatch.py:147-167).  The target
+            # layers take both forms (proposal_target_layer.py:174-175): the 3-D rows and their axis-aligned BEV
+            # rectangles [x1,y1,x2,y2,cls]; the rectangle is the same bbaa_graphics_gems the 3-D anchors go through
+            # (which helper the missing network.py used is unpinned).
+            gt_np = gt.detach().cpu().numpy() if isinstance(gt, torch.Tensor) else gt
+            if gt_np.ndim != 2 or gt_np.shape[1] != 8:
+                raise ValueError("LiDAR gt_boxes must be (G, 8) [xc,yc,zc,l,w,h,ry,cls], got %s" % (gt_np.shape,))
+            aabb = np.concatenate((bbaa_graphics_gems(gt_np[:, :7]), gt_np[:, 7:8]), 1).astype(np.float32)
+            self._true_gt_boxes = torch.from_numpy(np.ascontiguousarray(gt_np, dtype=np.float32)).to(dev)
+            gt = aabb
         self._gt_boxes = (torch.from_numpy(np.ascontiguousarray(gt)) if isinstance(gt, np.ndarray) else gt).to(
             dev, dtype=torch.float32)
         out = self._predict()

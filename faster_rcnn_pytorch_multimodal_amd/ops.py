@@ -516,8 +516,9 @@ def rpn_loss(rpn, num_anchors, labels, targets, inside, outside, grad_ce=1.0, gr
 
 
 def det_loss(cls_score, labels, bbox_pred, targets, inside, outside, bbox_elem=4, grad_ce=1.0, grad_box=1.0,
-             want_grad=True):
-    """Returns (losses (2,) [ce, box], dcls, dbox)."""
+             want_grad=True, lidar=None):
+    """Returns (losses (2,) [ce, box], dcls, dbox).  ``lidar=(reg_loss_weight[7], ry_sin)`` selects the 7-element LiDAR
+    form (sin() on the yaw difference, per-element weights)."""
     lib = _hip.load()
     for nm, t in (("cls_score", cls_score), ("labels", labels), ("bbox_pred", bbox_pred), ("targets", targets),
                   ("inside", inside), ("outside", outside)):
@@ -526,6 +527,15 @@ def det_loss(cls_score, labels, bbox_pred, targets, inside, outside, bbox_elem=4
     losses = torch.empty((2,), dtype=torch.float32, device=cls_score.device)
     dcls = torch.empty_like(cls_score) if want_grad else None
     dbox = torch.empty_like(bbox_pred) if want_grad else None
+    if lidar is not None:
+        weights, ry_sin = lidar
+        if bbox_pred.shape[1] != 7 * k:
+            raise _hip.HipError("det_loss: LiDAR bbox_pred must be (R, 7*K), got %s" % (tuple(bbox_pred.shape),))
+        _hip.check(lib.frcnn_det_loss_lidar(_ptr(cls_score), _ptr(labels), r, k, _ptr(bbox_pred), _ptr(targets),
+                                            _ptr(inside), _ptr(outside), _hip.float_array([float(v) for v in weights]),
+                                            int(bool(ry_sin)), float(grad_ce), float(grad_box), _ptr(losses), _ptr(dcls),
+                                            _ptr(dbox), _stream()), "frcnn_det_loss_lidar")
+        return losses, dcls, dbox
     _hip.check(lib.frcnn_det_loss(_ptr(cls_score), _ptr(labels), r, k, _ptr(bbox_pred), _ptr(targets), _ptr(inside),
                                   _ptr(outside), int(bbox_elem), float(grad_ce), float(grad_box), _ptr(losses), _ptr(dcls),
                                   _ptr(dbox), _stream()), "frcnn_det_loss")
@@ -565,14 +575,37 @@ def anchor_target_layer(anchors, gt_boxes, info, rpn_batchsize, fg_fraction, neg
 
 
 def proposal_target_layer(rois, roi_scores, gt_boxes, num_classes, rois_per_frame, fg_fraction, fg_thresh, bg_hi, bg_lo,
-                          means, stds, seed, roi_count=None):
-    """Returns dict(labels (R,), rois (R,5), scores (R,), targets/inside/outside (R,4K), assign int32 (R,), counts int32 (4,))."""
+                          means, stds, seed, roi_count=None, anchors_3d=None, true_gt_boxes=None):
+    """Returns dict(labels (R,), rois (R,5), scores (R,), targets/inside/outside (R,4K), assign int32 (R,), counts int32 (4,)).
+    With ``anchors_3d`` (num_rois,7) and ``true_gt_boxes`` (G,8) the LiDAR form: 7K-wide targets and ``anchors_3d`` (R,7)."""
     lib = _hip.load()
     _dev_f32(rois, "rois"); _dev_f32(gt_boxes, "gt_boxes")
     if roi_scores is not None:
         _dev_f32(roi_scores, "roi_scores")
     dev = rois.device
     r = int(rois_per_frame)
+    if anchors_3d is not None:
+        _dev_f32(anchors_3d, "anchors_3d"); _dev_f32(true_gt_boxes, "true_gt_boxes")
+        if anchors_3d.shape != (rois.shape[0], 7) or true_gt_boxes.shape != (gt_boxes.shape[0], 8) or gt_boxes.shape[1] != 5:
+            raise _hip.HipError("proposal_target_layer: LiDAR form needs anchors_3d (num_rois,7), gt_boxes (G,5), "
+                                "true_gt_boxes (G,8)")
+        e = 7
+        out = {"labels": torch.empty((r,), dtype=torch.float32, device=dev),
+               "rois": torch.empty((r, 5), dtype=torch.float32, device=dev),
+               "scores": torch.empty((r,), dtype=torch.float32, device=dev),
+               "anchors_3d": torch.empty((r, 7), dtype=torch.float32, device=dev),
+               "targets": torch.empty((r, e * num_classes), dtype=torch.float32, device=dev),
+               "inside": torch.empty((r, e * num_classes), dtype=torch.float32, device=dev),
+               "outside": torch.empty((r, e * num_classes), dtype=torch.float32, device=dev),
+               "assign": torch.empty((r,), dtype=torch.int32, device=dev),
+               "counts": torch.zeros((4,), dtype=torch.int32, device=dev)}
+        _hip.check(lib.frcnn_proposal_target_layer_lidar(
+            _ptr(rois), _ptr(roi_scores), _ptr(roi_count), rois.shape[0], _ptr(anchors_3d), _ptr(gt_boxes),
+            _ptr(true_gt_boxes), gt_boxes.shape[0], int(num_classes), r, float(fg_fraction), float(fg_thresh), float(bg_hi),
+            float(bg_lo), _hip.float_array(means), _hip.float_array(stds), int(seed) & 0xFFFFFFFF, _ptr(out["labels"]),
+            _ptr(out["rois"]), _ptr(out["scores"]), _ptr(out["anchors_3d"]), _ptr(out["targets"]), _ptr(out["inside"]),
+            _ptr(out["outside"]), _ptr(out["assign"]), _ptr(out["counts"]), _stream()), "frcnn_proposal_target_layer_lidar")
+        return out
     out = {"labels": torch.empty((r,), dtype=torch.float32, device=dev),
            "rois": torch.empty((r, 5), dtype=torch.float32, device=dev),
            "scores": torch.empty((r,), dtype=torch.float32, device=dev),

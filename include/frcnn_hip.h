@@ -313,6 +313,26 @@ int frcnn_proposal_target_layer(const float* rois, const float* roi_scores, cons
                                 float* out_rois, float* out_scores, float* targets, float* inside, float* outside,
                                 int* gt_assignment, int* counts, void* stream);
 
+/* LiDAR form (proposal_target_layer.py:142-154, NET_TYPE 'lidar'): overlaps and labels on the BEV rectangles gt_boxes
+ * (num_gt,5); targets = lidar_3d_bbox_transform(roi, the RoI's 3-D anchor, true_gt_boxes (num_gt,8)
+ * [xc,yc,zc,l,w,h,ry,cls]) (lib/model/bbox_transform.py:16-49) normalised with 7 means/stds; anchors3d (num_rois,7)
+ * follows the RoIs, out_anchors3d (rois_per_frame,7) the sampled rows; targets/inside/outside are (.,7*num_classes). */
+int frcnn_proposal_target_layer_lidar(const float* rois, const float* roi_scores, const int* roi_count, int num_rois,
+                                      const float* anchors3d, const float* gt_boxes, const float* true_gt_boxes,
+                                      int num_gt, int num_classes, int rois_per_frame, float fg_fraction, float fg_thresh,
+                                      float bg_thresh_hi, float bg_thresh_lo, const float* means_host,
+                                      const float* stds_host, uint32_t seed, float* labels, float* out_rois,
+                                      float* out_scores, float* out_anchors3d, float* targets, float* inside,
+                                      float* outside, int* gt_assignment, int* counts, void* stream);
+
+/* frcnn_det_loss for the 7-element LiDAR boxes (lib/utils/loss_utils.py:61-77): the yaw difference goes through
+ * sin() before the Huber term when ry_sin (cfg.LIDAR.EN_RY_SIN), every element is scaled by reg_loss_weight_host[7]
+ * (cfg.LIDAR.REG_LOSS_WEIGHT, NULL = ones). */
+int frcnn_det_loss_lidar(const float* cls_score, const float* labels, int num_rois, int num_classes,
+                         const float* bbox_pred, const float* targets, const float* inside, const float* outside,
+                         const float* reg_loss_weight_host, int ry_sin, float grad_ce, float grad_box, float* losses,
+                         float* dcls, float* dbox, void* stream);
+
 /* LiDAR form (filter_predictions.py:55-62,67, db_type 'lidar'): no clamp, NMS on the yaw-less BEV rectangle
  * xc -+ l/2, yc -+ w/2 of the 7-DoF boxes, dets (K, max_out, 8) [xc,yc,zc,l,w,h,ry,score].
  * Workspace: frcnn_filter_per_class_ws_bytes. */

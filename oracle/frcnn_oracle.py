@@ -834,6 +834,82 @@ class LidarNetOracle(ImageNetOracle):
         return cls_score, cls_prob, pred_boxes, rois, {}
 
 
+def _lidar_set_trainable(self, fixed_blocks=1):
+    """lidarnet.py:104-134: every BatchNorm trainable (set_bn_var) except in the frozen blocks; the stem is frozen
+    for FIXED_BLOCKS >= 0, layerN for N <= FIXED_BLOCKS."""
+    for m in self.resnet.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            for p in m.parameters():
+                p.requires_grad = True
+    frozen = [self.resnet.conv1, self.resnet.bn1] + [getattr(self.resnet, "layer%d" % n) for n in (1, 2, 3, 4)
+                                                     if fixed_blocks >= n]
+    for m in frozen:
+        for p in m.parameters():
+            p.requires_grad = False
+
+
+def _lidar_train_mode(self, fixed_blocks=1):
+    """lidarnet.py:152-175: the network in train() mode, every backbone BatchNorm in eval() mode except those of
+    layerN, N > FIXED_BLOCKS, which use batch statistics."""
+    self.train()
+    for m in self.resnet.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.eval()
+    for n in (1, 2, 3):
+        if fixed_blocks <= n:
+            for m in getattr(self.resnet, "layer%d" % (n + 1)).modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.train()
+
+
+def _lidar_train_forward(self, data, info, true_gt_boxes, generator=None, pre_nms=12000, post_nms=2000, proposals=None):
+    """One TRAIN forward of the LiDAR detector (RECONSTRUCTED contract, like the image forms above): the RPN and
+    anchor targets work on the BEV rectangles of the 3-D anchors / gt boxes, the second stage on the 7-of-7K targets
+    (proposal_target_layer.py:142-154) with the sin(ry) Huber term (loss_utils.py:61-77).
+    ``proposals=(rois (N,5), scores (N,1), anchors_3d (N,7))`` replaces the proposal_layer output."""
+    image = torch.from_numpy(np.ascontiguousarray(data)).permute(0, 3, 1, 2).contiguous()
+    tgt3 = torch.as_tensor(true_gt_boxes, dtype=torch.float32)
+    gt = torch.cat((torch.from_numpy(bbaa_graphics_gems(tgt3[:, :7].numpy())), tgt3[:, 7:8]), 1)
+    net_conv = self._image_to_head(image)
+    a, (h, w) = self._num_anchors, net_conv.shape[2:]
+    _, a3 = generate_anchors_3d(h, w, self._feat_stride, frame_scale=float(info[6]))
+    anchors = torch.from_numpy(bbaa_graphics_gems(a3))
+    rpn = F.relu(self.rpn_net(net_conv))
+    cls_score = self.rpn_cls_score_net(rpn)
+    bbox_pred = self.rpn_bbox_pred_net(rpn).permute(0, 2, 3, 1).contiguous()
+    with torch.no_grad():
+        prob = F.softmax(cls_score.view(1, 2, a * h, w), dim=1).view(1, 2 * a, h, w).permute(0, 2, 3, 1).contiguous()
+        rois, scores, dbg = proposal_layer(prob, bbox_pred, info, anchors, a, pre_nms, post_nms, TEST_RPN_NMS_THRESH,
+                                           return_debug=True)
+        roi_a3 = torch.from_numpy(a3)[dbg["order"]][dbg["keep"]]
+        if proposals is not None:
+            rois, scores, roi_a3 = proposals
+        lab, tgt, inw, outw = anchor_target_layer(gt, info, anchors, a, h, w, generator=generator)
+        pl, prois, pa3, _, ptgt, pin, pout = proposal_target_layer(rois, scores, roi_a3, gt, tgt3, self._num_classes, 7,
+                                                                   net_type="lidar", generator=generator)
+    logits = torch.stack((cls_score[0, :a].permute(1, 2, 0).reshape(-1), cls_score[0, a:].permute(1, 2, 0).reshape(-1)), 1)
+    labels_hwa = lab[0].permute(1, 2, 0).reshape(-1)
+    sel = labels_hwa >= 0
+    rpn_ce = F.cross_entropy(logits[sel], labels_hwa[sel].long())
+    rpn_box = smooth_l1_loss("RPN", bbox_pred, tgt, inw, outw, dim=(1, 2, 3))
+    pool5 = roi_align_torch(net_conv, prois, POOLING_SIZE, 1.0 / self._feat_stride)
+    fc7 = self.resnet.layer4(pool5).mean(3).mean(2)
+    det_cls, det_box = self.cls_score_net(fc7), self.bbox_pred_net(fc7)
+    ce = F.cross_entropy(det_cls, pl.view(-1).long())
+    box = smooth_l1_loss("DET", det_box, ptgt, pin, pout, net_type="lidar")
+    losses = {"rpn_cross_entropy": rpn_ce, "rpn_loss_box": rpn_box, "cross_entropy": ce, "loss_box": box,
+              "total_loss": rpn_ce + rpn_box + ce + box}
+    dbg = {"anchor_labels": labels_hwa, "anchor_targets": tgt.reshape(-1, 4), "anchor_inside": inw.reshape(-1, 4),
+           "anchor_outside": outw.reshape(-1, 4), "rois": prois, "anchors_3d": pa3, "labels": pl.view(-1), "targets": ptgt,
+           "inside": pin, "outside": pout, "net_conv": net_conv, "fc7": fc7, "cls_score": det_cls, "gt_aabb": gt}
+    return losses, dbg
+
+
+LidarNetOracle.train_forward = _lidar_train_forward
+LidarNetOracle.set_trainable = _lidar_set_trainable
+LidarNetOracle.train_mode = _lidar_train_mode
+
+
 def filter_and_draw_prep_lidar(rois, cls_prob, pred_boxes, num_classes, thresh=0.1, nms_thresh=TEST_NMS_THRESH):
     """filter_predictions.py:45-72,92-93 with db_type 'lidar': no clamp, NMS on xc -+ l/2, yc -+ w/2, dets rows
     [xc,yc,zc,l,w,h,ry,score]."""

@@ -136,3 +136,17 @@ def test_anchor_type_table_matches_oracle_bev_boxes():
         for k in range(2):          # the two anchor types at cell (0, 0)
             np.testing.assert_array_equal(t[k, 4:], a3[k, 2:])
             np.testing.assert_array_equal(t[k, :4], a2[k])
+
+
+def test_bbaa_graphics_gems_matches_reference_vectors():
+    """utils/bbox.bbaa_graphics_gems (host helper of the LiDAR training path) against the reference's own outputs
+    (tests/golden/lidar_train.npz: BEV rectangles of the 3-D anchor grids)."""
+    import os
+    import numpy as np
+    from faster_rcnn_pytorch_multimodal_amd.utils.bbox import bbaa_graphics_gems
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lidar_train.npz"))
+    for tag in ("25x22_fs0.5", "50x44_fs1", "7x5_fs0.3"):
+        np.testing.assert_array_equal(bbaa_graphics_gems(z["a3d_" + tag]), z["a2d_" + tag])
+    assert bbaa_graphics_gems(np.zeros((0, 7), np.float32)).shape == (0, 4)
+    clipped = bbaa_graphics_gems(np.array([[5.0, 5.0, 0, 20.0, 8.0, 2.0, 0.3]], np.float32), 16, 12, clip=True)
+    assert clipped.min() >= 0 and clipped[0, 2] <= 15 and clipped[0, 3] <= 11

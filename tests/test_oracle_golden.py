@@ -213,6 +213,18 @@ def test_proposal_target_layer_matches_reference(golden_dir):
     assert int((lab > 0).sum()) == int(z["ptl_num_fg"][0]) == 40
 
 
+def test_proposal_target_layer_lidar_matches_reference(golden_dir):
+    """NET_TYPE 'lidar': 7-of-7K targets = lidar_3d_bbox_transform(roi, 3-D anchor, true gt) / LiDAR stds."""
+    z = _lt(golden_dir)
+    rois, sc, gt, a3, tgt = (torch.from_numpy(z[k]) for k in ("ptl_rois", "ptl_scores", "ptl_gt", "ptl_lidar_anchors_3d",
+                                                             "ptl_lidar_true_gt"))
+    lab, r, a3s, s, bt, biw, bow = O.proposal_target_layer(rois, sc, a3, gt, tgt, 2, 7, net_type="lidar",
+                                                           generator=torch.Generator().manual_seed(1))
+    packed = torch.cat((r, lab, s.view(-1, 1), a3s, bt, biw, bow), 1).numpy()
+    packed = packed[np.lexsort(packed.T[::-1])]
+    np.testing.assert_array_equal(packed, z["ptl_lidar_packed_sorted"])
+
+
 def test_losses_match_reference(golden_dir):
     z = _lt(golden_dir)
     p, t, iw, ow = (torch.from_numpy(a) for a in z["sl1_rpn_in"])
