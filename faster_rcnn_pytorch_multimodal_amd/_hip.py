@@ -56,6 +56,10 @@ PROTOTYPES = {
     "frcnn_filter_per_class_lidar": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, c_int, c_int, _P, _P, _P,
                                              c_size_t, _P]),
     "frcnn_act_bwd": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, _P]),
+    "frcnn_bev_voxelize_grid": (c_int, [POINTER(c_float), POINTER(c_float), POINTER(c_int)]),
+    "frcnn_bev_voxelize_ws_bytes": (c_size_t, [c_int, POINTER(c_float), POINTER(c_float), c_int]),
+    "frcnn_bev_voxelize": (c_int, [_P, c_int, c_int, POINTER(c_float), POINTER(c_float), c_float, c_int, c_int, c_int,
+                                   c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "frcnn_bn_train_ws_bytes": (c_size_t, [c_int]),
     "frcnn_bn_train_fwd": (c_int, [_P, c_int64, c_int, _P, _P, c_float, c_float, _P, _P, _P, c_int, _P, _P, _P, _P,
                                    c_size_t, _P]),

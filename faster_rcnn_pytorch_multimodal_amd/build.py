@@ -29,6 +29,7 @@ SOURCES = {
     "targets.hip": ["-ffp-contract=off"],
     "prep.hip": ["-ffp-contract=off"],
     "batchnorm.hip": ["-ffp-contract=off"],
+    "voxelize.hip": ["-ffp-contract=off"],
 }
 COMMON_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -392,6 +392,30 @@ def filter_per_class(pred_boxes, cls_prob, frame_w, frame_h, scale, thresh, nms_
     return dets, det_count
 
 
+def bev_voxelize(points, pc_range, voxel_size, z_shift, max_points, max_voxels, num_slices, num_meta,
+                 elongation_col=-1):
+    """Point cloud (N, F>=4) device tensor -> BEV map (gy, gx, num_slices+num_meta) and the device count of occupied
+    cells (frcnn_bev_voxelize; lib/roi_data_layer/minibatch.py:434-512)."""
+    import ctypes
+    lib = _hip.load()
+    _dev_f32(points, "points")
+    if points.dim() != 2 or points.shape[1] < 4 or points.shape[0] == 0:
+        raise _hip.HipError("bev_voxelize: points must be (N>0, F>=4), got %s" % (tuple(points.shape),))
+    rng, vs = _hip.float_array(pc_range), _hip.float_array(voxel_size)
+    grid = (ctypes.c_int * 3)()
+    _hip.check(lib.frcnn_bev_voxelize_grid(rng, vs, grid), "frcnn_bev_voxelize_grid")
+    gx, gy = int(grid[0]), int(grid[1])
+    bev = torch.empty((gy, gx, int(num_slices) + int(num_meta)), dtype=torch.float32, device=points.device)
+    count = torch.zeros((1,), dtype=torch.int32, device=points.device)
+    nbytes = lib.frcnn_bev_voxelize_ws_bytes(points.shape[0], rng, vs, int(max_voxels))
+    ws = _workspace(nbytes, points.device)
+    _hip.check(lib.frcnn_bev_voxelize(_ptr(points), points.shape[0], points.shape[1], rng, vs, float(z_shift),
+                                      int(max_points), int(max_voxels), int(num_slices), int(num_meta),
+                                      int(elongation_col), _ptr(bev), _ptr(count), _ptr(ws), nbytes, _stream()),
+               "frcnn_bev_voxelize")
+    return bev, count
+
+
 # ----------------------------------------------------------------------------------------------
 # training path
 # ----------------------------------------------------------------------------------------------

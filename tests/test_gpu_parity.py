@@ -1351,6 +1351,45 @@ def test_lidar_train_step_matches_oracle_autograd(hip):
     C.reset_cfg()
 
 
+def _point_cloud(n, seed, dense=4000):
+    rng = np.random.default_rng(seed)
+    dense = min(dense, n // 5)
+    pts = np.stack((rng.uniform(-2, 72, n), rng.uniform(-42, 42, n), rng.uniform(-3.2, 3.2, n), rng.uniform(0, 3, n),
+                    rng.uniform(0, 2, n)), 1).astype(np.float32)
+    pts[:dense, :3] = rng.normal([10, 0, -1], [0.08, 0.08, 0.3], (dense, 3))      # voxels holding > 32 points
+    pts[dense:dense + 50, 0] = 70.0                                                 # on the upper range boundary
+    pts[dense + 50:dense + 100, 2] = -3.0                                           # on the lower z boundary
+    return pts[rng.permutation(n)]
+
+
+@pytest.mark.parametrize("scale,n,max_voxels,elong", [(0.5, 30000, 25000, None), (1.0, 20000, 25000, 4),
+                                                       (0.5, 30000, 3000, 4), (0.25, 500, 25000, None)])
+def test_bev_voxelize_matches_oracle(hip, scale, n, max_voxels, elong):
+    """Device LiDAR input producer (lib/roi_data_layer/minibatch.py:232-235,434-512) against the literal restatement:
+    which cells are occupied, the height slices and the density channel exactly (first-32-points and first-N-voxels
+    rules, last-voxel-of-a-column rule), tanh(mean intensity/elongation) to rounding."""
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.roi_data_layer.minibatch import get_lidar_blob
+    C.reset_cfg()
+    C.cfg.NET_TYPE = "lidar"
+    C.cfg.LIDAR.MAX_NUM_VOXEL = max_voxels
+    pts = _point_cloud(n, seed=n + max_voxels)
+    info_ref, ref = O.get_lidar_blob(pts, scale, elongation=elong is not None, max_voxels=max_voxels)
+    infos, blob = get_lidar_blob(pts, scale, device=DEV, elongation=elong)
+    got = blob.cpu().numpy()
+    assert got.shape == ref.shape and infos[0] == info_ref.tolist()
+    np.testing.assert_array_equal(got != 0, ref != 0)
+    np.testing.assert_array_equal(got[..., :13], ref[..., :13])               # height slices + density
+    np.testing.assert_allclose(got[..., 13:], ref[..., 13:], rtol=2e-6, atol=1e-7)
+    if n >= 20000:
+        assert ref[..., 12].max() == 1.0                                       # the > 32 points rule is exercised
+    if max_voxels == 3000:
+        assert int((ref[..., :12] != 0).sum()) <= 3000                         # ... and the voxel cap
+    if elong is None:
+        assert (got[..., 14] == 0).all()
+    C.reset_cfg()
+
+
 @pytest.mark.parametrize("scale", [1.0, 0.5, 0.75, 1.3])
 def test_prep_im_for_blob_matches_oracle(hip, scale):
     """Device image producer (lib/utils/blob.py:32-54) vs the numpy restatement, plus known answers."""

@@ -150,3 +150,31 @@ def test_bbaa_graphics_gems_matches_reference_vectors():
     assert bbaa_graphics_gems(np.zeros((0, 7), np.float32)).shape == (0, 4)
     clipped = bbaa_graphics_gems(np.array([[5.0, 5.0, 0, 20.0, 8.0, 2.0, 0.3]], np.float32), 16, 12, clip=True)
     assert clipped.min() >= 0 and clipped[0, 2] <= 15 and clipped[0, 3] <= 11
+
+
+def test_oracle_voxel_generator_known_answers():
+    """oracle.points_to_voxel / get_lidar_blob on a hand-built cloud (spconv is absent: the restatement is checked
+    against answers worked out by hand from lib/roi_data_layer/minibatch.py:434-512)."""
+    import numpy as np
+    from oracle import frcnn_oracle as O
+    pts = np.array([
+        [0.05, -39.95, -2.9, 1.0, 0.5],    # cell (x0, y0, z0)
+        [0.06, -39.96, -2.7, 3.0, 0.5],    # same cell, higher
+        [0.05, -39.95, 0.30, 2.0, 1.5],    # same column, slice 6 -> created later: owns the meta channels
+        [69.99, 39.99, 2.99, 0.0, 0.0],    # last cell of the grid
+        [70.00, 0.0, 0.0, 9.0, 9.0],       # x == X_RANGE[1]: filtered
+        [5.0, 5.0, -3.01, 9.0, 9.0],       # below Z_RANGE[0]: filtered
+    ], np.float32)
+    info, blob = O.get_lidar_blob(pts, 0.5, elongation=True)
+    assert info.tolist() == [0, 350, 0, 400, 0, 12, 0.5] and blob.shape == (1, 400, 350, 15)
+    px = blob[0, 0, 0]
+    assert abs(px[0] - 0.3) < 1e-6                      # max(z+3) - 0*0.5 = 0.3 (second point)
+    assert abs(px[6] - 0.3) < 1e-6                      # 3.3 - 6*0.5
+    assert px[12] == 1 / 32                             # density of the voxel created last in the column
+    assert abs(px[13] - np.tanh(2.0)) < 1e-6 and abs(px[14] - np.tanh(1.5)) < 1e-6
+    last = blob[0, 399, 349]
+    assert abs(last[11] - (5.99 - 5.5)) < 1e-5 and last[12] == 1 / 32 and last[13] == 0.0
+    assert int((blob != 0).sum()) == 2 + 3 + 2          # two slices + 3 meta | one slice + density (intensity 0)
+    # voxel cap: with max_voxels = 1 only the first cell survives, and only its first max_points = 1 point
+    _, capped = O.get_lidar_blob(pts, 0.5, elongation=True, max_points=1, max_voxels=1)
+    assert int((capped != 0).sum()) == 4 and abs(capped[0, 0, 0, 0] - 0.1) < 1e-6 and capped[0, 0, 0, 12] == 1.0
