@@ -117,6 +117,30 @@ def roi_align_timing(net, steps):
             "algorithmic_bytes": bytes_}
 
 
+def nms_timing(net, steps):
+    """HIP-event timing of the RPN NMS (bit-matrix + scan launches) on the last frame's sorted proposals: achieved
+    bytes = boxes read + the suppression bit-matrix written by the mask kernel and read back by the scan."""
+    from faster_rcnn_pytorch_multimodal_amd import ops
+    p = net._predictions
+    order = p["rpn_order"]
+    n = int(order.numel())
+    boxes = ops.gather_rows(p["rpn_proposals"], order, None)
+    ops.nms_sorted(boxes, 0.7, 300)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        ops.nms_sorted(boxes, 0.7, 300)
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / steps
+    words = (n + 63) // 64
+    bytes_ = n * 16 + 2 * n * words * 8
+    return {"bound": "hbm", "kernel": "nms_mask_kernel + nms_scan_kernel (%d boxes)" % n, "achieved": bytes_ / us / 1e3,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_ / us / 1e3 / HBM_PEAK_GBS, "us_per_launch": us,
+            "algorithmic_bytes": bytes_, "note": "latency-bound: the greedy scan is a serial chain over the kept boxes"}
+
+
 def cpu_baseline(sd, frames, info):
     """The CPU oracle (PyTorch-CPU restatement of the reference path) on this host: 1 warm-up + len(frames)
     timed frames of the same workload."""
@@ -203,12 +227,24 @@ def pmc_traffic(kernel):
         return None
 
 
+def pmc_mfma_util():
+    """MfmaUtil (percent of SIMD cycles with the matrix pipe busy, duration-weighted over the conv launches of the
+    roofline frames) from the committed PMC pass; None when the file has no such pass."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)["kernels"]["conv_igemm"]["mfma"]["mfma_util_percent"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--plans", default=None, help="JSON file of tuned conv plans: loaded when it exists (profiler runs "
+                    "then use exactly the kernels of the timed run), written after warm-up otherwise")
     ap.add_argument("--streams", type=int, default=4,
                     help="frames in flight per GPU: frame i is replayed on HIP stream i %% streams, so the small "
                          "layers of one frame fill the CUs the other leaves idle")
@@ -241,6 +277,12 @@ def main():
     frames_host = [synthetic_frame(rank + world * i) for i in range(n_resident)]
     frames = [torch.from_numpy(f).to(device) for f in frames_host]
     n_streams = max(1, args.streams)
+    from faster_rcnn_pytorch_multimodal_amd import ops as _ops
+    plans_loaded = False
+    if args.plans and os.path.exists(args.plans):
+        with open(args.plans) as f:
+            _ops.import_conv_plans(json.load(f))
+        plans_loaded = True
     runners = [FrameRunner(net, H, W, C, info, THRESH, MAX_DETS, use_graph=not args.no_graph) for _ in range(n_streams)]
     streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
     rec = [torch.zeros((NUM_CLASSES, MAX_DETS, 5), device=device) for _ in range(n_streams)]
@@ -271,6 +313,9 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    if args.plans and not plans_loaded and rank == 0:
+        with open(args.plans, "w") as f:
+            json.dump(_ops.export_conv_plans(), f)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -295,6 +340,7 @@ def main():
         roofline = {"bound": "mfma", "kernel": "conv_igemm_f32 (all instantiations, %d launches/frame)"
                     % round(conv["launches_per_frame"]), "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic("conv_igemm"),
+                    "mfma_util_pmc_percent": pmc_mfma_util(),
                     "flops_per_frame": conv["flops_per_frame"], "kernel_ms_per_frame": conv["ms_per_frame"],
                     "event_pair_overhead_us": conv["event_pair_overhead_us"],
                     "avg_launch_us": 1e3 * conv["ms_per_frame"] / conv["launches_per_frame"]}
@@ -313,6 +359,7 @@ def main():
                        "launch": "eager" if args.no_graph else "hipGraph replay", "frames_in_flight": n_streams},
             "roofline": roofline,
             "roofline_roi_align": roi_align_timing(net, 20),
+            "roofline_nms": nms_timing(net, 20),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], _ = cpu_baseline(sd, frames_host[:args.cpu_frames], info)

@@ -24,6 +24,8 @@ PROTOTYPES = {
     "frcnn_conv2d_set_staging": (c_int, [c_int]),
     "frcnn_conv2d_set_autotune": (c_int, [c_int]),
     "frcnn_conv2d_clear_plans": (c_int, []),
+    "frcnn_conv2d_export_plans": (c_int, [POINTER(c_int), c_int]),
+    "frcnn_conv2d_import_plans": (c_int, [POINTER(c_int), c_int]),
     "frcnn_conv2d_transpose_filter": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "frcnn_conv2d_bwd_data_ws_bytes": (c_size_t, [c_int] * 9),
     "frcnn_conv2d_bwd_data": (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P]),

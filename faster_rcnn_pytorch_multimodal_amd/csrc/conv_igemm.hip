@@ -691,6 +691,36 @@ extern "C" int frcnn_conv2d_clear_plans(void) {
   return FRCNN_OK;
 }
 
+// Plan table as plain ints, 13 per entry: the 10-int shape key, then tile index, splits, steps per split.
+extern "C" int frcnn_conv2d_export_plans(int* out, int capacity_entries) {
+  std::lock_guard<std::mutex> lock(g_plan_mutex);
+  int n = 0;
+  for (const auto& kv : g_plan_cache) {
+    if (out && n < capacity_entries) {
+      for (int i = 0; i < 10; ++i) out[n * 13 + i] = kv.first[i];
+      out[n * 13 + 10] = kv.second.cfg;
+      out[n * 13 + 11] = kv.second.splits;
+      out[n * 13 + 12] = kv.second.steps_per_split;
+    }
+    ++n;
+  }
+  return n;   // entries in the cache (may exceed capacity_entries: call again with a larger buffer)
+}
+
+extern "C" int frcnn_conv2d_import_plans(const int* in, int entries) {
+  FRCNN_REQUIRE(in && entries >= 0, "conv2d_import_plans: null table");
+  std::lock_guard<std::mutex> lock(g_plan_mutex);
+  for (int e = 0; e < entries; ++e) {
+    const int* row = in + e * 13;
+    FRCNN_REQUIRE(row[10] >= 0 && row[10] < kNumTiles && row[11] >= 1 && row[11] <= 64 && row[12] >= 1,
+                  "conv2d_import_plans: entry %d is not a valid plan (tile %d, splits %d)", e, row[10], row[11]);
+    ShapeKey key;
+    for (int i = 0; i < 10; ++i) key[i] = row[i];
+    g_plan_cache[key] = Plan{row[10], row[11], row[12]};
+  }
+  return FRCNN_OK;
+}
+
 namespace {
 // launch one plan: main kernel + the split-K second pass
 int launch_plan(ConvParams p, const Plan& pl, long M, int k, const float* scale, const float* shift,

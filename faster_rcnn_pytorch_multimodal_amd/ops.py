@@ -44,6 +44,26 @@ def set_conv_autotune(enable):
     _hip.check(_hip.load().frcnn_conv2d_set_autotune(int(bool(enable))), "frcnn_conv2d_set_autotune")
 
 
+def export_conv_plans():
+    """The tuned convolution plans as a list of 13-int rows (frcnn_conv2d_export_plans)."""
+    import ctypes
+    lib = _hip.load()
+    n = lib.frcnn_conv2d_export_plans(None, 0)
+    buf = (ctypes.c_int * (13 * max(n, 1)))()
+    n = min(n, lib.frcnn_conv2d_export_plans(buf, n))
+    return [[int(buf[13 * e + i]) for i in range(13)] for e in range(n)]
+
+
+def import_conv_plans(rows):
+    """Install plans saved by export_conv_plans (e.g. to profile exactly the kernels a timed run used)."""
+    import ctypes
+    flat = [int(v) for row in rows for v in row]
+    if len(flat) % 13:
+        raise _hip.HipError("import_conv_plans: rows must have 13 ints")
+    buf = (ctypes.c_int * max(len(flat), 1))(*flat)
+    _hip.check(_hip.load().frcnn_conv2d_import_plans(buf, len(flat) // 13), "frcnn_conv2d_import_plans")
+
+
 def conv_out_hw(h, w, r, s, stride, pad):
     return (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
 

@@ -80,6 +80,12 @@ int frcnn_conv2d_set_tile(int tm, int tn);
  * analytic model picks).  frcnn_conv2d_clear_plans forgets the cache. */
 int frcnn_conv2d_set_autotune(int enable);
 int frcnn_conv2d_clear_plans(void);
+/* The plan cache as a table of 13 ints per entry (shape key n,h,w,c,k,r,s,stride,pad,out_stride; tile index, splits,
+ * K-steps per split), so that a tuned table can be saved and replayed (e.g. under a profiler, whose instrumentation
+ * would otherwise perturb the tuning).  export returns the number of cached entries (fills at most capacity_entries);
+ * import validates and inserts. */
+int frcnn_conv2d_export_plans(int* out, int capacity_entries);
+int frcnn_conv2d_import_plans(const int* in, int entries);
 
 /* Tuning / test hook: 1 (default) stages the 8-wave tiles with LDS-DMA (global_load_lds) when C % 32 == 0,
  * 0 uses the register-staged kernel everywhere.  Results are bit-identical for split_k = 1. */

@@ -1124,6 +1124,38 @@ def test_batchnorm_batch_statistics_fwd_bwd(hip, rows, c, relu, res):
         assert dres is None
 
 
+def test_conv_plan_autotune_export_import(hip):
+    """frcnn_conv2d_set_autotune / _export_plans / _import_plans: the tuned plan of a shape is cached, survives an
+    export -> clear -> import round trip, gives the same result as the analytic plan (to split-K summation order), and a
+    malformed table is refused."""
+    from faster_rcnn_pytorch_multimodal_amd import _hip, ops
+    lib = _hip.load()
+    lib.frcnn_conv2d_clear_plans()
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(1, 38, 63, 256, generator=g).to(DEV)
+    w = (torch.randn(256, 3, 3, 256, generator=g) * 0.05).to(DEV)
+    base = ops.conv2d_nhwc(x, w, stride=1, pad=1)
+    ops.set_conv_autotune(True)
+    try:
+        tuned = ops.conv2d_nhwc(x, w, stride=1, pad=1)
+    finally:
+        ops.set_conv_autotune(False)
+    plans = ops.export_conv_plans()
+    assert len(plans) == 1 and plans[0][:10] == [1, 38, 63, 256, 256, 3, 3, 1, 1, 1] and plans[0][11] >= 1
+    np.testing.assert_allclose(tuned.cpu().numpy(), base.cpu().numpy(), rtol=0, atol=2e-5 * float(base.abs().max()))
+    lib.frcnn_conv2d_clear_plans()
+    assert ops.export_conv_plans() == []
+    ops.import_conv_plans(plans)
+    assert ops.export_conv_plans() == plans
+    again = ops.conv2d_nhwc(x, w, stride=1, pad=1)
+    assert torch.equal(again, tuned)                       # same plan -> bit-identical
+    bad = [list(plans[0])]
+    bad[0][10] = 99
+    with pytest.raises(_hip.HipError):
+        ops.import_conv_plans(bad)
+    lib.frcnn_conv2d_clear_plans()
+
+
 def test_solver_loop_on_device(hip, tmp_path):
     """model/train_val.SolverWrapper (lib/model/train_val.py:296-503) driving the HIP network: gradients of every
     trainable filter accumulate inside the flat bucket (views, no copies), the optimizer steps every batch_size

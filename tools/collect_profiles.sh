@@ -1,6 +1,7 @@
 #!/bin/bash
 # End-of-round evidence on a GPU box (run through gpurun): headline bench, kernel-trace stats of the same command,
-# and the two PMC passes (one counter per run, never combined with other trace domains).
+# and the PMC passes (one counter per run, never combined with other trace domains).  The first run saves its tuned
+# conv plans; the profiler runs load them, so they measure exactly the kernels that were timed.
 #   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r1z'
 set -e -o pipefail
 TAG=${1:-r1z}
@@ -9,11 +10,12 @@ O=$R/gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
-python3 $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+rm -f $O/${TAG}_plans.json
+python3 $R/bench.py --plans $O/${TAG}_plans.json > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 echo "bench done"; cut -c1-300 $O/${TAG}_bench.json
-rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof -o ${TAG} -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/${TAG}_prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof -o ${TAG} -- python3 $R/bench.py --plans $O/${TAG}_plans.json --steps 30 --warmup 5 --no-cpu-baseline > $O/${TAG}_prof.log 2>&1
 echo "kernel trace done"
-for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/${TAG}_pmc_$C -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-graph --streams 1 --no-cpu-baseline > $O/${TAG}_$C.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE MfmaUtil; do
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/${TAG}_pmc_$C -o pmc -- python3 $R/bench.py --plans $O/${TAG}_plans.json --steps 3 --warmup 1 --no-graph --streams 1 --no-cpu-baseline > $O/${TAG}_$C.log 2>&1
   echo "$C done"
 done

@@ -4,7 +4,8 @@ traffic file bench.py reads (profiles/r01_pmc_traffic.json).
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_FETCH_SIZE -o pmc -- python3 bench.py ...
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_WRITE_SIZE -o pmc -- python3 bench.py ...
-    python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE "<command>" > profiles/r01_pmc_traffic.json
+    python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE [--mfma=gpurun_out/pmc_MfmaUtil] \
+        "<command>" > profiles/r01_pmc_traffic.json
 
 Both counters are reported in KB.  FETCH_SIZE is doubled: gfx950 counts half of the wide (16 B per lane) streaming
 reads these kernels issue (MI355X_MICROARCH.md, HBM / rocprofv3 section).
@@ -13,6 +14,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 # family -> substring of the kernel name (all template instances of the conv kernel count as one family, like
@@ -47,7 +49,35 @@ def per_kernel(directory, counter):
     return acc
 
 
-def main(fetch_dir, write_dir, command=""):
+def mfma_util(directory):
+    """Duration-weighted MfmaUtil (rocprofv3 derived counter: SQ_VALU_MFMA_BUSY_CYCLES summed over the SIMDs /
+    (GRBM_GUI_ACTIVE x SIMD count)) of the conv launches of the roofline frames, plus the per-instantiation averages."""
+    paths = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
+    if not paths:
+        return None
+    rows = []
+    with open(paths[0], newline="") as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] == "MfmaUtil" and "conv_igemm" in row["Kernel_Name"]:
+                rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"], float(row["Counter_Value"]),
+                             int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+    rows.sort()
+    rows = rows[-LAST["conv_igemm"]:]
+    if not rows:
+        return None
+    total = sum(r[3] for r in rows)
+    by = {}
+    for _, name, val, dur in rows:
+        m = re.search(r"conv_igemm\w*<[^>]*>", name)
+        short = m.group(0) if m else name
+        n, sv, sd = by.get(short, (0, 0.0, 0))
+        by[short] = (n + 1, sv + val * dur, sd + dur)
+    return {"launches": len(rows), "mfma_util_percent": sum(r[2] * r[3] for r in rows) / total,
+            "by_kernel": {k: {"launches": n, "mfma_util_percent": sv / sd, "time_share": sd / total}
+                          for k, (n, sv, sd) in sorted(by.items())}}
+
+
+def main(fetch_dir, write_dir, command="", mfma_dir=None):
     fetch = per_kernel(fetch_dir, "FETCH_SIZE")
     write = per_kernel(write_dir, "WRITE_SIZE")
     out = {"command": command + " (one counter per pass)",
@@ -64,8 +94,14 @@ def main(fetch_dir, write_dir, command=""):
         wb = kbw * 1024.0 / nw
         out["kernels"][fam] = {"launches": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
                                "traffic_bytes_per_launch": fb + wb}
+    if mfma_dir:
+        util = mfma_util(mfma_dir)
+        if util:
+            out["kernels"].setdefault("conv_igemm", {})["mfma"] = util
     print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], " ".join(sys.argv[3:]))
+    args = [a for a in sys.argv[1:] if not a.startswith("--mfma=")]
+    mfma = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--mfma=")]
+    main(args[0], args[1], " ".join(args[2:]), mfma[0] if mfma else None)
