@@ -178,3 +178,36 @@ def test_oracle_voxel_generator_known_answers():
     # voxel cap: with max_voxels = 1 only the first cell survives, and only its first max_points = 1 point
     _, capped = O.get_lidar_blob(pts, 0.5, elongation=True, max_points=1, max_voxels=1)
     assert int((capped != 0).sum()) == 4 and abs(capped[0, 0, 0, 0] - 0.1) < 1e-6 and capped[0, 0, 0, 12] == 1.0
+
+
+def test_voc_eval_matches_reference_vectors(tmp_path):
+    """datasets/voc_eval.voc_eval_arrays + voc_ap against the reference's voc_eval on a synthetic 6-frame set
+    (tests/golden/eval.npz, generated by tests/golden/make_golden_eval.py), then the detections file format."""
+    import os
+    import numpy as np
+    from faster_rcnn_pytorch_multimodal_amd.datasets import voc_eval as V
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eval.npz"))
+    frames = [str(f) for f in z["frames"]]
+    recs = {f: {"bbox": z["gt_box_" + f], "difficult": z["gt_diff_" + f]} for f in frames}
+    ids = [str(f) for f in z["det_frame"]]
+    for tag, (thr, m07) in {"iou50": (0.5, False), "iou70": (0.7, False), "iou50_07": (0.5, True)}.items():
+        rec, prec, ap = V.voc_eval_arrays(ids, z["det_score"], z["det_box"], recs, ovthresh=thr, use_07_metric=m07)
+        np.testing.assert_array_equal(rec, z["rec_" + tag])
+        np.testing.assert_array_equal(prec, z["prec_" + tag])
+        assert ap == z["ap_" + tag][0]
+    assert 0.3 < z["ap_iou70"][0] < z["ap_iou50"][0] < 1.0                      # the case is not degenerate
+    # results files (lib/datasets/db.py:305-367): the exact text of one row, and a write -> read round trip
+    dets = [np.array([[10.04, 20.06, 110.96, 220.0, 0.98765, 0.5]]), np.zeros((0, 6)),
+            np.array([[1, 2, 3, 4, 0.5, 0.25], [5, 6, 7, 8, 0.125, 0.75]], dtype=np.float64)]
+    path = str(tmp_path / "det_car.txt")
+    V.write_image_results_file(dets, ["a", "b", "c"], path)
+    lines = open(path).read().splitlines()
+    assert lines[0] == "0 a 0.988 10.0 20.1 111.0 220.0 0.5000000000" and len(lines) == 3 and lines[1].startswith("2 c 0.500 ")
+    idx, tok, score, box, extra = V.read_results_file(path)
+    assert idx.tolist() == [0, 2, 2] and tok == ["a", "c", "c"] and box.shape == (3, 4) and extra.shape == (3, 1)
+    lid = [np.array([[1.5, -2.25, 0.5, 4.7, 2.1, 1.8, 0.31, 0.9]])]
+    lpath = str(tmp_path / "det_lidar.txt")
+    V.write_lidar_results_file(lid, ["t0"], lpath)
+    assert open(lpath).read() == "0 t0 0.900 1.500 -2.250 0.500 4.700 2.100 1.800 0.31000\n"
+    _, _, s, b, _ = V.read_results_file(lpath, num_box_values=7)
+    assert s.tolist() == [0.9] and b.shape == (1, 7)
