@@ -92,33 +92,35 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const float* __restric
 // dropped when EITHER coordinate is outside [-1, size] — so a bin's average is
 //     out[ph][pw] = 1/count * sum_y Wy[ph][y] * ( sum_x Wx[pw][x] * F[y][x] )
 // with Wy / Wx the per-axis weights of a bin's samples accumulated per feature row / column.  One workgroup =
-// (RoI, 32-channel slice): it builds Wx, Wy in LDS, walks every feature row of the RoI window ONCE accumulating the
-// seven per-column-bin row sums T[y][pw] (LDS), then combines rows into the 49 bins.  Each window pixel is read
-// about once instead of up to 4*gh*gw times per bin: the generic kernel is bound by the 64 B/clk/CU vector-L1
-// path (3.6 GB of L1 traffic for 300 RoIs), this one moves ~10x less.  The summation order differs from the
-// library kernel the oracle follows (agreement ~1e-6 relative, well inside the 1e-4 bar).
-// Workgroup b handles slice b % nslices, so an XCD (b % 8) only touches 1/8 of the channels (L2 locality).
-// RoIs whose window is taller than the LDS budget fall back to the direct per-bin loop inside the same kernel.
+// (RoI, CC-channel slice): it builds Wx, Wy in LDS, then walks the RoI window in chunks of RCH feature rows: the seven
+// per-column-bin row sums T[y][pw] of the chunk go to LDS, and every thread adds the chunk's rows into the bins it
+// owns (accumulators stay in registers across chunks).  Each window pixel is read about once instead of up to
+// 4*gh*gw times per bin (the generic kernel is bound by the 64 B/clk/CU vector-L1 path), and the LDS footprint is
+// RCH*P*CC*4 bytes whatever the window height: the op is a chain of short dependent phases, so what matters is how
+// many workgroups a CU can keep in flight (8 at ~17 KB each), not the work of one.
+// The summation order differs from the library kernel the oracle follows (agreement ~1e-6 relative, well inside the
+// 1e-4 bar).  Workgroup b handles slice b % nslices, so an XCD (b % 8) only touches 1/8 of the channels (L2 locality).
 // ------------------------------------------------------------------------------------------------
-constexpr int SEP_CC = 32;        // channels per workgroup
-constexpr int SEP_CL = SEP_CC / 4;
-
+template <int CC, int RCH>
 __global__ __launch_bounds__(256) void roi_align_fwd_sep(const float* __restrict__ feat, int H, int W, int C,
                                                         const float* __restrict__ rois,
                                                         const int* __restrict__ roi_count, int num_rois, int P,
                                                         float spatial_scale, int sampling_ratio,
-                                                        const int* __restrict__ level_of_roi, int level, int hcap,
+                                                        const int* __restrict__ level_of_roi, int level,
                                                         float* __restrict__ out) {
+  constexpr int CL = CC / 4;          // float4 per pixel of the slice
+  constexpr int MAXJ = 4;             // bins*CL / 256 rounded up, for P = 7: 392/256 -> 2 (CC 32), 784/256 -> 4 (CC 64)
   extern __shared__ __attribute__((aligned(16))) float sep_smem[];
-  const int nslices = C / SEP_CC;
+  const int nslices = C / CC;
   const int r = blockIdx.x / nslices, slice = blockIdx.x - r * nslices;
   if (level_of_roi && level_of_roi[r] != level) return;
   const int t = threadIdx.x;
   const int live = roi_count ? min(*roi_count, num_rois) : num_rois;
   const int C4 = C >> 2;
-  float4* ob = reinterpret_cast<float4*>(out) + (size_t)r * P * P * C4 + slice * SEP_CL;
+  const int items = P * P * CL;
+  float4* ob = reinterpret_cast<float4*>(out) + (size_t)r * P * P * C4 + slice * CL;
   if (r >= live) {
-    for (int i = t; i < P * P * SEP_CL; i += 256) ob[(size_t)(i / SEP_CL) * C4 + (i % SEP_CL)] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = t; i < items; i += 256) ob[(size_t)(i / CL) * C4 + (i % CL)] = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
   const float* roi = rois + (size_t)r * 5;
@@ -130,9 +132,9 @@ __global__ __launch_bounds__(256) void roi_align_fwd_sep(const float* __restrict
   const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)P);
   const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)P);
   const float count = (float)(grid_h * grid_w);
-  const float4* fb = reinterpret_cast<const float4*>(feat) + (size_t)b * H * W * C4 + slice * SEP_CL;
+  const float4* fb = reinterpret_cast<const float4*>(feat) + (size_t)b * H * W * C4 + slice * CL;
 
-  // LDS: Wx[P][W], Wy[P][H], per-bin ranges, then T[rows][P][SEP_CL] float4
+  // LDS: Wx[P][W], Wy[P][H], per-bin ranges, then T[RCH][P][CL] float4
   float* Wx = sep_smem;
   float* Wy = Wx + P * W;
   int* rng = reinterpret_cast<int*>(Wy + P * H);   // xlo[P], xhi[P], ylo[P], yhi[P]
@@ -175,68 +177,81 @@ __global__ __launch_bounds__(256) void roi_align_fwd_sep(const float* __restrict
   __syncthreads();
   int y0 = H, y1 = -1;
   for (int ph = 0; ph < P; ++ph) { y0 = min(y0, rng[2 * P + ph]); y1 = max(y1, rng[3 * P + ph]); }
-  const int rows = y1 - y0 + 1;   // <= 0: no valid sample at all
-  if (rows > hcap) {
-    // window taller than the LDS budget: direct per-bin evaluation (same maths as the generic kernel)
-    for (int i = t; i < P * P * SEP_CL; i += 256) {
-      const int c4 = i % SEP_CL, bin = i / SEP_CL;
-      const int ph = bin / P, pw = bin - ph * P;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int iy = 0; iy < grid_h; ++iy) {
-        int yl, yh;
-        float wyl, wyh;
-        if (!axis_sample(roi_start_h, bin_size_h, ph, iy, grid_h, H, yl, yh, wyl, wyh)) continue;
-        for (int ix = 0; ix < grid_w; ++ix) {
-          int xl, xh;
-          float wxl, wxh;
-          if (!axis_sample(roi_start_w, bin_size_w, pw, ix, grid_w, W, xl, xh, wxl, wxh)) continue;
-          const float4 v1 = fb[((size_t)yl * W + xl) * C4 + c4], v2 = fb[((size_t)yl * W + xh) * C4 + c4];
-          const float4 v3 = fb[((size_t)yh * W + xl) * C4 + c4], v4 = fb[((size_t)yh * W + xh) * C4 + c4];
-          const float w1 = wyl * wxl, w2 = wyl * wxh, w3 = wyh * wxl, w4 = wyh * wxh;
-          acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
-          acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
-          acc.z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
-          acc.w += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
-        }
+  // the bins this thread owns: item = t + 256*j -> (bin, c4)
+  float4 acc[MAXJ];
+  int a_pw[MAXJ], a_c4[MAXJ], a_yl[MAXJ], a_yh[MAXJ];
+  const float* a_wr[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int i = min(t + 256 * j, items - 1);
+    const int bin = i / CL, ph = bin / P;
+    a_c4[j] = i % CL;
+    a_pw[j] = bin - ph * P;
+    a_yl[j] = rng[2 * P + ph];
+    a_yh[j] = rng[3 * P + ph];
+    a_wr[j] = Wy + ph * H;
+  }
+  for (int ys = y0; ys <= y1; ys += RCH) {      // y1 < y0: no valid sample at all -> zeros
+    const int rows = min(RCH, y1 - ys + 1);
+    // phase 1: T[y - ys][pw][c4] = sum_x Wx[pw][x] * F[y][x]; item = (row, pw, c4)
+    for (int i = t; i < rows * P * CL; i += 256) {
+      const int c4 = i % CL, pw = (i / CL) % P, yr = i / (CL * P);
+      const float4* frow = fb + (size_t)(ys + yr) * W * C4 + c4;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int xl = rng[pw], xh = rng[P + pw];
+      const float* wr = Wx + pw * W;
+      for (int x = xl; x <= xh; ++x) {
+        const float wgt = wr[x];
+        const float4 v = frow[(size_t)x * C4];
+        a.x += wgt * v.x; a.y += wgt * v.y; a.z += wgt * v.z; a.w += wgt * v.w;
       }
-      ob[(size_t)bin * C4 + c4] = make_float4(acc.x / count, acc.y / count, acc.z / count, acc.w / count);
+      T[(yr * P + pw) * CL + c4] = a;
     }
-    return;
-  }
-  // phase 1: T[y - y0][pw][c4] = sum_x Wx[pw][x] * F[y][x]; item = (row, pw, c4)
-  for (int i = t; i < rows * P * SEP_CL; i += 256) {
-    const int c4 = i % SEP_CL, pw = (i / SEP_CL) % P, yr = i / (SEP_CL * P);
-    const float4* frow = fb + (size_t)(y0 + yr) * W * C4 + c4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int xl = rng[pw], xh = rng[P + pw];
-    const float* wr = Wx + pw * W;
-    for (int x = xl; x <= xh; ++x) {
-      const float wgt = wr[x];
-      const float4 v = frow[(size_t)x * C4];
-      acc.x += wgt * v.x; acc.y += wgt * v.y; acc.z += wgt * v.z; acc.w += wgt * v.w;
+    __syncthreads();
+    // phase 2: acc[ph][pw] += sum_{y in chunk} Wy[ph][y] * T[y][pw]
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      if (t + 256 * j >= items) continue;
+      const int lo = max(a_yl[j], ys), hi = min(a_yh[j], ys + rows - 1);
+      for (int y = lo; y <= hi; ++y) {
+        const float wgt = a_wr[j][y];
+        const float4 v = T[((y - ys) * P + a_pw[j]) * CL + a_c4[j]];
+        acc[j].x += wgt * v.x; acc[j].y += wgt * v.y; acc[j].z += wgt * v.z; acc[j].w += wgt * v.w;
+      }
     }
-    T[(yr * P + pw) * SEP_CL + c4] = acc;
+    __syncthreads();
   }
-  __syncthreads();
-  // phase 2: out[ph][pw] = 1/count * sum_y Wy[ph][y] * T[y][pw]
-  for (int i = t; i < P * P * SEP_CL; i += 256) {
-    const int c4 = i % SEP_CL, bin = i / SEP_CL;
-    const int ph = bin / P, pw = bin - ph * P;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int yl = rng[2 * P + ph], yh = rng[3 * P + ph];
-    const float* wr = Wy + ph * H;
-    for (int y = yl; y <= yh; ++y) {
-      const float wgt = wr[y];
-      const float4 v = T[((y - y0) * P + pw) * SEP_CL + c4];
-      acc.x += wgt * v.x; acc.y += wgt * v.y; acc.z += wgt * v.z; acc.w += wgt * v.w;
-    }
-    ob[(size_t)bin * C4 + c4] = make_float4(acc.x / count, acc.y / count, acc.z / count, acc.w / count);
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int i = t + 256 * j;
+    if (i >= items) continue;
+    ob[(size_t)(i / CL) * C4 + a_c4[j]] =
+        make_float4(acc[j].x / count, acc[j].y / count, acc[j].z / count, acc[j].w / count);
   }
+}
+
+template <int CC, int RCH>
+int launch_sep(const float* feat, int h, int w, int c, const float* rois, const int* roi_count, int num_rois, int pooled,
+               float spatial_scale, int sampling_ratio, const int* level_of_roi, int level, float* out,
+               hipStream_t stream) {
+  const size_t tables = ((size_t)pooled * (w + h) + 4 * pooled + 3) & ~(size_t)3;
+  const size_t lds = tables * 4 + (size_t)RCH * pooled * CC * 4;
+  static size_t configured = 0;
+  if (lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_fwd_sep<CC, RCH>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return frcnn::fail(FRCNN_ERR_LAUNCH, "roi_align_fwd: set LDS size: %s", hipGetErrorString(e));
+    configured = lds;
+  }
+  hipLaunchKernelGGL((roi_align_fwd_sep<CC, RCH>), dim3((unsigned)(num_rois * (c / CC))), dim3(256), lds, stream, feat, h,
+                     w, c, rois, roi_count, num_rois, pooled, spatial_scale, sampling_ratio, level_of_roi, level, out);
+  return frcnn::check_launch("roi_align_fwd_sep");
 }
 
 }  // namespace
 
-// tuning hook: 0 = automatic, 1 = generic, 2 = generic with XCD channel slices, 3 = separable
+// tuning hook: 0 = automatic, 1 = generic, 2 = generic with XCD channel slices, 3..6 = separable <32,12> <64,8> <64,16> <32,24>
 static int g_roi_variant = 0;
 extern "C" int frcnn_roi_align_set_variant(int v) {
   g_roi_variant = v;
@@ -248,24 +263,22 @@ extern "C" int frcnn_roi_align_fwd(const float* feat, int h, int w, int c, const
                                    const int* level_of_roi, int level, float* out, void* stream_) {
   FRCNN_REQUIRE(feat && rois && out && h > 0 && w > 0 && c > 0 && c % 4 == 0 && num_rois > 0 && pooled > 0,
                 "roi_align_fwd: bad arguments (c%%4==0)");
-  if ((g_roi_variant == 0 || g_roi_variant == 3) && c % SEP_CC == 0 && pooled <= 16 &&
-      (size_t)pooled * (w + h) * 4 < 48 * 1024) {
-    // separable kernel: LDS = weight tables + T rows; windows taller than hcap take the in-kernel direct path
-    const size_t tables = ((size_t)pooled * (w + h) + 4 * pooled + 3) & ~(size_t)3;
-    const int hcap = std::min(std::min(h, 48), (int)((96 * 1024 - tables * 4) / ((size_t)pooled * SEP_CC * 4)));
-    const size_t lds = tables * 4 + (size_t)hcap * pooled * SEP_CC * 4;
-    static size_t configured = 0;
-    if (lds > configured) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_fwd_sep),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return frcnn::fail(FRCNN_ERR_LAUNCH, "roi_align_fwd: set LDS size: %s", hipGetErrorString(e));
-      configured = lds;
-    }
-    hipLaunchKernelGGL(roi_align_fwd_sep, dim3((unsigned)(num_rois * (c / SEP_CC))), dim3(256), lds,
-                       static_cast<hipStream_t>(stream_), feat, h, w, c, rois, roi_count, num_rois, pooled, spatial_scale,
-                       sampling_ratio, level_of_roi, level, hcap, out);
-    return frcnn::check_launch("roi_align_fwd_sep");
-  }
+  // separable kernel: needs the 7x7-style item count to fit the per-thread bin ownership (pooled*pooled*CC/4 <= 1024)
+  // and the weight tables to fit in LDS next to the row chunk
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const bool sep_ok = pooled <= 8 && (size_t)pooled * (w + h) * 4 < 48 * 1024;
+  if (sep_ok && c % 64 == 0 && g_roi_variant == 4)
+    return launch_sep<64, 8>(feat, h, w, c, rois, roi_count, num_rois, pooled, spatial_scale, sampling_ratio, level_of_roi,
+                             level, out, stream);
+  if (sep_ok && c % 64 == 0 && (g_roi_variant == 0 || g_roi_variant == 5))   // measured best (round 1)
+    return launch_sep<64, 16>(feat, h, w, c, rois, roi_count, num_rois, pooled, spatial_scale, sampling_ratio,
+                              level_of_roi, level, out, stream);
+  if (sep_ok && c % 32 == 0 && (g_roi_variant == 0 || g_roi_variant == 3))
+    return launch_sep<32, 12>(feat, h, w, c, rois, roi_count, num_rois, pooled, spatial_scale, sampling_ratio,
+                              level_of_roi, level, out, stream);
+  if (sep_ok && c % 32 == 0 && g_roi_variant == 6)
+    return launch_sep<32, 24>(feat, h, w, c, rois, roi_count, num_rois, pooled, spatial_scale, sampling_ratio,
+                              level_of_roi, level, out, stream);
   const size_t total = (size_t)num_rois * pooled * pooled * (c / 4);
   if (g_roi_variant != 1 && c % 32 == 0) {   // 8 channel slices of c/8 channels, one per XCD; grid = multiple of 8
     const size_t per_slice_blocks = std::min<size_t>((total / 8 + 255) / 256, (size_t)1 << 17);

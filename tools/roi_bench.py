@@ -16,6 +16,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--variants", default="1,2,3")
+    ap.add_argument("--typical", action="store_true", help="also time seeded boxes of 32..320 px (what a trained RPN "
+                    "proposes) and a plain 60 MB fill (the write floor of the op)")
     args = ap.parse_args()
     import bench
     from faster_rcnn_pytorch_multimodal_amd import _hip, ops
@@ -43,6 +45,32 @@ def main():
         torch.cuda.synchronize()
         print("variant %d: %.1f us" % (v, 1e3 * e0.elapsed_time(e1) / args.reps))
     lib.frcnn_roi_align_set_variant(0)
+    if args.typical:
+        def timed(fn):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(args.reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return 1e3 * e0.elapsed_time(e1) / args.reps
+        g = torch.Generator().manual_seed(0)
+        wh = torch.rand(300, 2, generator=g) * 288 + 32
+        xy = torch.rand(300, 2, generator=g) * (torch.tensor([float(bench.W), float(bench.H)]) - wh - 1)
+        typ = torch.cat((torch.zeros(300, 1), xy, xy + wh), 1).cuda().contiguous()
+        out = torch.empty((300, 7, 7, feat.shape[-1]), device="cuda")
+        us_fill = timed(lambda: out.fill_(1.0))
+        bytes_ = feat.numel() * 4 + out.numel() * 4 + typ.numel() * 4
+        print("60.2 MB fill: %.1f us = %.0f GB/s" % (us_fill, out.numel() * 4 / us_fill / 1e3))
+        for v in [0] + [int(x) for x in args.variants.split(",")]:
+            lib.frcnn_roi_align_set_variant(v)
+            us_typ = timed(lambda: ops.roi_align_nhwc(feat, typ, 7, 1.0 / 16.0, 0))
+            print("typical boxes (32..320 px), variant %d: %.1f us = %.0f GB/s (%.1f %% of 8 TB/s)"
+                  % (v, us_typ, bytes_ / us_typ / 1e3, bytes_ / us_typ / 1e3 / 80.0))
+        lib.frcnn_roi_align_set_variant(0)
 
 
 if __name__ == "__main__":
