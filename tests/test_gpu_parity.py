@@ -317,8 +317,37 @@ def test_roi_align_matches_oracle(hip, sampling, c):
     assert torch.equal(got2[:10], got[:10]) and (got2[10:] == 0).all()
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+def test_roi_align_every_kernel_variant(hip, variant):
+    """frcnn_roi_align_set_variant: generic (1, 2) and separable <CC,RCH> (3-6) kernels all agree with the oracle, incl.
+    windows spanning several row chunks, RoIs without any valid sample and a device-side RoI count."""
+    from faster_rcnn_pytorch_multimodal_amd import _hip
+    ops = _ops()
+    lib = _hip.load()
+    g = torch.Generator().manual_seed(40 + variant)
+    h, w, c = 75, 40, 256
+    feat = torch.randn(1, c, h, w, generator=g)
+    rois = torch.cat((torch.zeros(40, 1), _rand_boxes(40, g, extent=(640, 1200), max_wh=600)), 1)
+    rois[0, 1:] = torch.tensor([0., 0, 639, 1199])           # whole map: 75 rows = 5 chunks of 16
+    rois[1, 1:] = torch.tensor([300., 300, 300, 300])
+    rois[2, 1:] = torch.tensor([-50., 1150, 700, 1300])      # mostly outside
+    rois[3, 1:] = torch.tensor([700., 1300, 800, 1400])      # entirely outside: no valid sample
+    ref = O.roi_align(feat, rois, 7, 1 / 16.0, 0)
+    nhwc = feat.permute(0, 2, 3, 1).contiguous().to(DEV)
+    lib.frcnn_roi_align_set_variant(variant)
+    try:
+        got = ops.roi_align_nhwc(nhwc, rois.to(DEV), 7, 1 / 16.0, 0)
+        cnt = torch.tensor([9], dtype=torch.int32, device=DEV)
+        got2 = ops.roi_align_nhwc(nhwc, rois.to(DEV), 7, 1 / 16.0, 0, roi_count=cnt)
+    finally:
+        lib.frcnn_roi_align_set_variant(0)
+    _close_feat(got.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), "roi_align variant %d" % variant, frac=2e-6)
+    assert torch.equal(got2[:9], got[:9]) and (got2[9:] == 0).all()
+    assert (got[3] == 0).all()
+
+
 def test_roi_align_tall_window_fallback(hip):
-    """Windows taller than the separable kernel's LDS budget (48 feature rows) take its in-kernel direct path."""
+    """Windows taller than one row chunk of the separable kernel (16 feature rows) accumulate over several chunks."""
     ops = _ops()
     g = torch.Generator().manual_seed(5)
     feat = torch.randn(1, 32, 120, 12, generator=g)
