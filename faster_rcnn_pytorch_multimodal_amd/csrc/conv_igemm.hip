@@ -770,22 +770,31 @@ bool tune_plan(const ConvParams& p, long M, int k, const float* scale, const flo
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess) return false;
   if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return false; }
+  // two passes over the candidates, each keeps its best time: a one-off disturbance (clock ramp, a neighbour stream)
+  // can then neither crown a slow plan nor bury the fast one
+  const std::vector<Plan> cands = tune_candidates(M, k, p.ksteps, allow_split);
+  std::vector<float> best_of(cands.size(), 1e30f);
+  for (int pass = 0; pass < 2; ++pass) {
+    for (size_t ci = 0; ci < cands.size(); ++ci) {
+      const Plan& pl = cands[ci];
+      const size_t need = pl.splits > 1 ? (size_t)pl.splits * M * k * sizeof(float) : 0;
+      if (need > ws_bytes || (need > 0 && !ws)) continue;
+      if (pass == 0 && launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, stream) != FRCNN_OK) continue;   // warm-up
+      (void)hipEventRecord(e0, stream);
+      const int reps = 3;
+      bool ok = true;
+      for (int i = 0; i < reps && ok; ++i) ok = launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, stream) == FRCNN_OK;
+      (void)hipEventRecord(e1, stream);
+      if (hipEventSynchronize(e1) != hipSuccess || !ok) continue;
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
+      best_of[ci] = std::min(best_of[ci], ms);
+    }
+  }
   float best_ms = 1e30f;
   bool found = false;
-  for (const Plan& pl : tune_candidates(M, k, p.ksteps, allow_split)) {
-    const size_t need = pl.splits > 1 ? (size_t)pl.splits * M * k * sizeof(float) : 0;
-    if (need > ws_bytes || (need > 0 && !ws)) continue;
-    if (launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, stream) != FRCNN_OK) continue;   // warm-up
-    (void)hipEventRecord(e0, stream);
-    const int reps = 3;
-    bool ok = true;
-    for (int i = 0; i < reps && ok; ++i) ok = launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, stream) == FRCNN_OK;
-    (void)hipEventRecord(e1, stream);
-    if (hipEventSynchronize(e1) != hipSuccess || !ok) continue;
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
-    if (ms < best_ms) { best_ms = ms; *best = pl; found = true; }
-  }
+  for (size_t ci = 0; ci < cands.size(); ++ci)
+    if (best_of[ci] < best_ms) { best_ms = best_of[ci]; *best = cands[ci]; found = true; }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return found;

@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--staging", type=int, default=1, help="1 = LDS-DMA for the 8-wave tiles, 0 = register staging")
     ap.add_argument("--mode", default="fwd", choices=["fwd", "dgrad", "wgrad"])
     ap.add_argument("--fpn", action="store_true", help="use the trainable convolutions of the FPN train step instead")
+    ap.add_argument("--batch", type=int, default=1, help="frames per launch (n is multiplied; us/frame is per frame)")
+    ap.add_argument("--autotune", action="store_true", help="time every (tile, split-K) candidate first")
     args = ap.parse_args()
     from faster_rcnn_pytorch_multimodal_amd import _hip, ops
     lib = _hip.load()
@@ -85,9 +87,11 @@ def main():
     tot_us = tot_fl = 0.0
     print("%-24s %6s %9s %9s %8s" % ("shape", "calls", "us/call", "TFLOP/s", "us/frame"))
     shapes = FPN_TRAIN_SHAPES if args.fpn else SHAPES
+    ops.set_conv_autotune(args.autotune)
     for name, n, h, w, c, k, r, stride, pad, res, calls in shapes:
         if args.only and args.only not in name:
             continue
+        n *= args.batch
         x = torch.randn((n, h, w, c), generator=g).to(dev)
         wt = (torch.randn((k, r, r, c), generator=g) * 0.05).to(dev)
         sc = torch.rand((k,), generator=g).to(dev) + 0.5
@@ -117,9 +121,9 @@ def main():
         torch.cuda.synchronize()
         us = 1e3 * e0.elapsed_time(e1) / args.reps
         fl = 2.0 * n * ho * wo * k * r * r * c
-        tot_us += us * calls
-        tot_fl += fl * calls
-        print("%-24s %6d %9.1f %9.1f %8.1f" % (name, calls, us, fl / us / 1e6, us * calls))
+        tot_us += us * calls / args.batch
+        tot_fl += fl * calls / args.batch
+        print("%-24s %6d %9.1f %9.1f %8.1f" % (name, calls, us, fl / us / 1e6, us * calls / args.batch))
     print("%-24s %6s %9s %9.1f %8.1f" % ("TOTAL", "", "", tot_fl / tot_us / 1e6, tot_us))
 
 
