@@ -76,6 +76,10 @@ PROTOTYPES = {
     "frcnn_det_loss": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_float, c_float, _P, _P, _P, _P]),
     "frcnn_det_loss_lidar": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, POINTER(c_float), c_int, c_float, c_float, _P,
                                      _P, _P, _P]),
+    "frcnn_det_loss_aleatoric": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, POINTER(c_float), c_int, c_float,
+                                         c_float, _P, _P, _P, _P, _P]),
+    "frcnn_mc_bbox_var": (c_int, [_P, c_int, c_int64, _P, _P]),
+    "frcnn_mc_cls_stats": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P]),
     "frcnn_bbox_overlaps": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, _P]),
     "frcnn_anchor_target_layer_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "frcnn_anchor_target_layer": (c_int, [_P, c_int, _P, c_int, POINTER(c_float), c_int, c_float, c_float, c_float,

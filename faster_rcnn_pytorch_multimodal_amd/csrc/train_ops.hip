@@ -345,8 +345,9 @@ struct DetLossOpt {
 __global__ __launch_bounds__(256) void det_loss_kernel(const float* __restrict__ cls_score, const float* __restrict__ labels,
                                                       int R, int K, const float* __restrict__ bbox_pred,
                                                       const float* __restrict__ targets, const float* __restrict__ inside,
-                                                      const float* __restrict__ outside, int E, DetLossOpt opt, float g_ce,
-                                                      float g_box,
+                                                      const float* __restrict__ outside, int E, DetLossOpt opt,
+                                                      const float* __restrict__ bbox_var, float* __restrict__ dvar,
+                                                      float g_ce, float g_box,
                                                       float* __restrict__ losses, float* __restrict__ dcls,
                                                       float* __restrict__ dbox) {
   __shared__ float red[4];
@@ -374,6 +375,15 @@ __global__ __launch_bounds__(256) void det_loss_kernel(const float* __restrict__
         diff = sinf(diff);
       }
       const float we = e < 8 ? opt.w[e] : 1.f;
+      if (bbox_var) {
+        // aleatoric attenuation (loss_utils.py:82-85): (0.5 * loss * exp(-s) + 0.5 * s) * inside, s = predicted log-variance
+        const float sv = bbox_var[o], ev = expf(-sv);
+        const float l = huber1(diff) * we;
+        rowsum += outside[o] * ((0.5f * l * ev + 0.5f * sv) * inside[o]);
+        if (dbox) dbox[o] = g_box / (float)R * outside[o] * inside[o] * (0.5f * ev) * (huber1_grad(diff) * we) * chain;
+        if (dvar) dvar[o] = g_box / (float)R * outside[o] * inside[o] * (0.5f - 0.5f * l * ev);
+        continue;
+      }
       rowsum += outside[o] * (huber1(diff) * we);
       if (dbox) dbox[o] = g_box / (float)R * outside[o] * (huber1_grad(diff) * we) * chain;
     }
@@ -478,13 +488,14 @@ extern "C" int frcnn_rpn_loss(const float* rpn, int ld, int num_anchors, int hw,
 namespace {
 int launch_det_loss(const float* cls_score, const float* labels, int num_rois, int num_classes, const float* bbox_pred,
                     const float* targets, const float* inside, const float* outside, int bbox_elem, DetLossOpt opt,
-                    float grad_ce, float grad_box, float* losses, float* dcls, float* dbox, void* stream_) {
+                    float grad_ce, float grad_box, float* losses, float* dcls, float* dbox, void* stream_,
+                    const float* bbox_var = nullptr, float* dvar = nullptr) {
   FRCNN_REQUIRE(cls_score && labels && bbox_pred && targets && inside && outside && losses && num_rois > 0 &&
                     num_rois <= 4096 && num_classes > 1 && bbox_elem > 0,
                 "det_loss: bad arguments (num_rois <= 4096)");
   hipLaunchKernelGGL(det_loss_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream_), cls_score, labels, num_rois,
-                     num_classes, bbox_pred, targets, inside, outside, bbox_elem, opt, grad_ce, grad_box, losses, dcls,
-                     dbox);
+                     num_classes, bbox_pred, targets, inside, outside, bbox_elem, opt, bbox_var, dvar, grad_ce, grad_box,
+                     losses, dcls, dbox);
   return check_launch("det_loss_kernel");
 }
 }  // namespace
@@ -509,4 +520,90 @@ extern "C" int frcnn_det_loss_lidar(const float* cls_score, const float* labels,
   opt.sin_elem = ry_sin ? 6 : -1;
   return launch_det_loss(cls_score, labels, num_rois, num_classes, bbox_pred, targets, inside, outside, 7, opt, grad_ce,
                          grad_box, losses, dcls, dbox, stream_);
+}
+
+extern "C" int frcnn_det_loss_aleatoric(const float* cls_score, const float* labels, int num_rois, int num_classes,
+                                        const float* bbox_pred, const float* bbox_var, const float* targets,
+                                        const float* inside, const float* outside, int bbox_elem,
+                                        const float* reg_loss_weight_host, int ry_sin, float grad_ce, float grad_box,
+                                        float* losses, float* dcls, float* dbox, float* dvar, void* stream_) {
+  FRCNN_REQUIRE(bbox_var, "det_loss_aleatoric: null bbox_var");
+  DetLossOpt opt;
+  for (int e = 0; e < 8; ++e) opt.w[e] = (reg_loss_weight_host && e < bbox_elem) ? reg_loss_weight_host[e] : 1.f;
+  opt.sin_elem = (ry_sin && bbox_elem == 7) ? 6 : -1;
+  return launch_det_loss(cls_score, labels, num_rois, num_classes, bbox_pred, targets, inside, outside, bbox_elem, opt,
+                         grad_ce, grad_box, losses, dcls, dbox, stream_, bbox_var, dvar);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Statistics of T stochastic forward passes (MC-dropout / logit sampling), lib/utils/loss_utils.py:114-141:
+//   bbox variance  (sum x^2 - (sum x)^2 / T) / (T - 1), clamped at 0             (compute_bbox_var)
+//   entropy of the mean softmax (log2) and the mutual information H(mean p) - mean H(p)
+//                                                        (categorical_entropy / categorical_mutual_information)
+// One thread per output element / RoI; T and K are small (10 samples, a few classes).
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void mc_bbox_var_kernel(const float* __restrict__ samples, int T, size_t n,
+                                                         float* __restrict__ var) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f, q = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const float v = samples[(size_t)t * n + i];
+      s += v;
+      q += v * v;
+    }
+    float r = q + -(s * s) / (float)T;
+    r = r / (float)(T - 1);
+    var[i] = r > 0.f ? r : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void mc_cls_stats_kernel(const float* __restrict__ scores, int T, int N, int K,
+                                                          float* __restrict__ mean_prob, float* __restrict__ entropy,
+                                                          float* __restrict__ mutual_info) {
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    float plogp = 0.f;                       // sum over samples of sum_k p log2 p
+    for (int k = 0; k < K; ++k) mean_prob[(size_t)n * K + k] = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const float* s = scores + ((size_t)t * N + n) * K;
+      float m = s[0];
+      for (int k = 1; k < K; ++k) m = fmaxf(m, s[k]);
+      float den = 0.f;
+      for (int k = 0; k < K; ++k) den += expf(s[k] - m);
+      float acc = 0.f;
+      for (int k = 0; k < K; ++k) {
+        const float p = expf(s[k] - m) / den;
+        mean_prob[(size_t)n * K + k] += p;
+        acc += p * log2f(p);
+      }
+      plogp += acc;
+    }
+    float h = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float p = mean_prob[(size_t)n * K + k] / (float)T;
+      mean_prob[(size_t)n * K + k] = p;
+      h += p * log2f(p);
+    }
+    entropy[n] = -h;
+    mutual_info[n] = plogp / (float)T + -h;
+  }
+}
+}  // namespace
+
+extern "C" int frcnn_mc_bbox_var(const float* samples, int num_samples, int64_t elems, float* var, void* stream_) {
+  FRCNN_REQUIRE(samples && var && num_samples > 1 && elems > 0, "mc_bbox_var: bad arguments (at least 2 samples)");
+  hipLaunchKernelGGL(mc_bbox_var_kernel, dim3(grid_for((size_t)elems)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     samples, num_samples, (size_t)elems, var);
+  return check_launch("mc_bbox_var_kernel");
+}
+
+extern "C" int frcnn_mc_cls_stats(const float* cls_score_samples, int num_samples, int num_rois, int num_classes,
+                                  float* mean_prob, float* entropy, float* mutual_info, void* stream_) {
+  FRCNN_REQUIRE(cls_score_samples && mean_prob && entropy && mutual_info && num_samples > 0 && num_rois > 0 &&
+                    num_classes > 1,
+                "mc_cls_stats: bad arguments");
+  hipLaunchKernelGGL(mc_cls_stats_kernel, dim3(grid_for((size_t)num_rois)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), cls_score_samples, num_samples, num_rois, num_classes, mean_prob,
+                     entropy, mutual_info);
+  return check_launch("mc_cls_stats_kernel");
 }

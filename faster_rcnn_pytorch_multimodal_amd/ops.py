@@ -586,6 +586,49 @@ def det_loss(cls_score, labels, bbox_pred, targets, inside, outside, bbox_elem=4
     return losses, dcls, dbox
 
 
+def det_loss_aleatoric(cls_score, labels, bbox_pred, bbox_var, targets, inside, outside, bbox_elem=4, weights=None,
+                       ry_sin=False, grad_ce=1.0, grad_box=1.0):
+    """Detection losses with the aleatoric attenuation (loss_utils.py:82-85).  Returns (losses (2,), dcls, dbox, dvar)."""
+    lib = _hip.load()
+    for nm, t in (("cls_score", cls_score), ("labels", labels), ("bbox_pred", bbox_pred), ("bbox_var", bbox_var),
+                  ("targets", targets), ("inside", inside), ("outside", outside)):
+        _dev_f32(t, nm)
+    r, k = cls_score.shape
+    if bbox_pred.shape != (r, bbox_elem * k) or bbox_var.shape != bbox_pred.shape:
+        raise _hip.HipError("det_loss_aleatoric: bbox_pred / bbox_var must be (R, %d*K)" % bbox_elem)
+    losses = torch.empty((2,), dtype=torch.float32, device=cls_score.device)
+    dcls, dbox, dvar = torch.empty_like(cls_score), torch.empty_like(bbox_pred), torch.empty_like(bbox_var)
+    w = _hip.float_array([float(v) for v in weights]) if weights is not None else None
+    _hip.check(lib.frcnn_det_loss_aleatoric(_ptr(cls_score), _ptr(labels), r, k, _ptr(bbox_pred), _ptr(bbox_var),
+                                            _ptr(targets), _ptr(inside), _ptr(outside), int(bbox_elem), w,
+                                            int(bool(ry_sin)), float(grad_ce), float(grad_box), _ptr(losses), _ptr(dcls),
+                                            _ptr(dbox), _ptr(dvar), _stream()), "frcnn_det_loss_aleatoric")
+    return losses, dcls, dbox, dvar
+
+
+def mc_bbox_var(samples):
+    """(T, ...) stack of stochastic passes -> unbiased variance over T, clamped at 0 (compute_bbox_var)."""
+    lib = _hip.load()
+    _dev_f32(samples, "samples")
+    t = samples.shape[0]
+    out = torch.empty(samples.shape[1:], dtype=torch.float32, device=samples.device)
+    _hip.check(lib.frcnn_mc_bbox_var(_ptr(samples), t, out.numel(), _ptr(out), _stream()), "frcnn_mc_bbox_var")
+    return out
+
+
+def mc_cls_stats(cls_score_samples):
+    """(T, N, K) logits -> (mean softmax (N,K), entropy (N,), mutual information (N,)), log base 2."""
+    lib = _hip.load()
+    _dev_f32(cls_score_samples, "cls_score_samples")
+    t, n, k = cls_score_samples.shape
+    dev = cls_score_samples.device
+    mean_prob = torch.empty((n, k), dtype=torch.float32, device=dev)
+    entropy, mi = torch.empty((n,), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev)
+    _hip.check(lib.frcnn_mc_cls_stats(_ptr(cls_score_samples), t, n, k, _ptr(mean_prob), _ptr(entropy), _ptr(mi),
+                                      _stream()), "frcnn_mc_cls_stats")
+    return mean_prob, entropy, mi
+
+
 def bbox_overlaps(boxes, query_boxes):
     """IoU (+1 convention) between boxes (N, >=4) and query_boxes (K, >=4) -> (N, K)."""
     lib = _hip.load()

@@ -356,6 +356,24 @@ int frcnn_det_loss_lidar(const float* cls_score, const float* labels, int num_ro
                          const float* reg_loss_weight_host, int ry_sin, float grad_ce, float grad_box, float* losses,
                          float* dcls, float* dbox, void* stream);
 
+/* Uncertainty pieces whose arithmetic IS in the reference snapshot (lib/utils/loss_utils.py; the heads that would feed
+ * them live in the missing lib/nets/network.py and are not rebuilt - DESIGN.md section 2, row f-3):
+ *  - frcnn_det_loss with the aleatoric attenuation of loss_utils.py:82-85: bbox_var = predicted log-variance s,
+ *    per-element loss (0.5*huber*exp(-s) + 0.5*s)*inside; dvar receives d(loss)/ds.  bbox_elem 4 or 7
+ *    (7: sin(ry) + reg_loss_weight_host as in frcnn_det_loss_lidar).
+ *  - frcnn_mc_bbox_var: samples (T, elems) -> unbiased variance over the T stochastic passes, clamped at 0
+ *    (compute_bbox_var, loss_utils.py:114-120).
+ *  - frcnn_mc_cls_stats: cls_score samples (T, num_rois, K) -> mean softmax (num_rois,K), its entropy in bits and the
+ *    mutual information H(mean p) - mean H(p) (loss_utils.py:122-141). */
+int frcnn_det_loss_aleatoric(const float* cls_score, const float* labels, int num_rois, int num_classes,
+                             const float* bbox_pred, const float* bbox_var, const float* targets, const float* inside,
+                             const float* outside, int bbox_elem, const float* reg_loss_weight_host, int ry_sin,
+                             float grad_ce, float grad_box, float* losses, float* dcls, float* dbox, float* dvar,
+                             void* stream);
+int frcnn_mc_bbox_var(const float* samples, int num_samples, int64_t elems, float* var, void* stream);
+int frcnn_mc_cls_stats(const float* cls_score_samples, int num_samples, int num_rois, int num_classes,
+                       float* mean_prob, float* entropy, float* mutual_info, void* stream);
+
 /* LiDAR form (filter_predictions.py:55-62,67, db_type 'lidar'): no clamp, NMS on the yaw-less BEV rectangle
  * xc -+ l/2, yc -+ w/2 of the 7-DoF boxes, dets (K, max_out, 8) [xc,yc,zc,l,w,h,ry,score].
  * Workspace: frcnn_filter_per_class_ws_bytes. */

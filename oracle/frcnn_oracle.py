@@ -766,8 +766,9 @@ def huber_loss(pred, targets, delta=1.0, sin_en=False):
     return 0.5 * torch.pow(diff, 2) * small + delta * (a - 0.5 * delta) * (1.0 - small)
 
 
-def smooth_l1_loss(stage, bbox_pred, bbox_targets, inside_w, outside_w, dim=(1,), net_type="image"):
-    """loss_utils.py:39-101 with the aleatoric branch off (cfg.UC.* default False)."""
+def smooth_l1_loss(stage, bbox_pred, bbox_targets, inside_w, outside_w, dim=(1,), net_type="image", bbox_var=None):
+    """loss_utils.py:39-101; ``bbox_var`` (predicted log-variance) switches the aleatoric branch on (:82-85, the
+    cfg.UC.EN_BBOX_ALEATORIC / EN_RPN_BBOX_ALEATORIC case), default off like the reference's config."""
     pred = bbox_pred * inside_w
     tgt = bbox_targets * inside_w
     if net_type == "lidar" and stage == "DET":
@@ -776,10 +777,33 @@ def smooth_l1_loss(stage, bbox_pred, bbox_targets, inside_w, outside_w, dim=(1,)
         loss = (loss * loss.new_tensor(LIDAR_REG_LOSS_WEIGHT)).reshape(pred.shape)
     else:
         loss = huber_loss(pred, tgt)
+    if bbox_var is not None:
+        loss = (0.5 * loss * torch.exp(-bbox_var) + 0.5 * bbox_var) * inside_w
     loss = outside_w * loss
     for i in sorted(dim, reverse=True):
         loss = loss.sum(i)
     return loss.mean()
+
+
+def compute_bbox_var(bbox_samples):
+    """loss_utils.py:114-120: unbiased variance over the T stochastic passes, clamped at 0."""
+    n = bbox_samples.shape[0]
+    mean_sq = torch.pow(torch.sum(bbox_samples, dim=0), 2)
+    var = torch.sum(torch.pow(bbox_samples, 2), dim=0)
+    var = var + (-mean_sq / n)
+    return (var / (n - 1)).clamp_min(0.0)
+
+
+def categorical_entropy(cls_prob):
+    """loss_utils.py:122-130 (bits)."""
+    return -torch.sum(cls_prob * torch.log2(cls_prob), dim=1)
+
+
+def categorical_mutual_information(cls_score):
+    """loss_utils.py:133-141: cls_score (T,N,C) logits -> H(mean softmax) - mean H(softmax)."""
+    prob = F.softmax(cls_score, dim=2)
+    total = categorical_entropy(torch.mean(prob, dim=0))
+    return torch.mean(torch.sum(prob * torch.log2(prob), dim=2), dim=0) + total
 
 
 # ----------------------------------------------------------------------------------------------

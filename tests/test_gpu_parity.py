@@ -958,6 +958,30 @@ def test_det_loss_lidar_against_reference_golden(hip, golden_dir):
     assert float(l2[1]) != float(losses[1])
 
 
+def test_uncertainty_statistics_and_aleatoric_loss_against_reference_golden(hip, golden_dir):
+    """frcnn_mc_bbox_var / frcnn_mc_cls_stats / frcnn_det_loss_aleatoric against the reference's own outputs
+    (lib/utils/loss_utils.py:82-85,114-141, tests/golden/lidar_train.npz)."""
+    ops = _ops()
+    z = np.load(os.path.join(golden_dir, "lidar_train.npz"))
+    var = ops.mc_bbox_var(torch.from_numpy(z["mc_bbox_samples"]).to(DEV))
+    np.testing.assert_allclose(var.cpu().numpy(), z["mc_bbox_var"], rtol=2e-6, atol=1e-7)
+    assert (ops.mc_bbox_var(torch.ones(5, 3, 4, device=DEV)) == 0).all()          # clamped, never negative
+    mean_prob, ent, mi = ops.mc_cls_stats(torch.from_numpy(z["mc_cls_samples"]).to(DEV))
+    np.testing.assert_allclose(mean_prob.cpu().numpy(), torch.softmax(torch.from_numpy(z["mc_cls_samples"]), 2).mean(0).numpy(),
+                               rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(ent.cpu().numpy(), z["mc_entropy"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(mi.cpu().numpy(), z["mc_mutual_info"], rtol=1e-5, atol=3e-6)
+    p, t, v, iw, ow = (torch.from_numpy(a).to(DEV).contiguous() for a in z["sl1_al_in"])
+    r, cols = p.shape
+    k = cols // 4
+    cls = torch.randn(r, k, generator=torch.Generator().manual_seed(2)).to(DEV)
+    labels = (torch.arange(r) % k).float().to(DEV)
+    losses, _, dbox, dvar = ops.det_loss_aleatoric(cls, labels, p, v, t, iw, ow, bbox_elem=4)
+    assert abs(float(losses[1]) - z["sl1_al"][0]) <= 2e-6 * max(1.0, abs(z["sl1_al"][0]))
+    np.testing.assert_allclose(dbox.cpu().numpy(), z["sl1_al_dpred"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(dvar.cpu().numpy(), z["sl1_al_dvar"], rtol=1e-5, atol=1e-8)
+
+
 def test_proposal_target_layer_sampling_properties(hip):
     ops = _ops()
     g = torch.Generator().manual_seed(8)

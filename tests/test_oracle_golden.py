@@ -236,3 +236,21 @@ def test_losses_match_reference(golden_dir):
     np.testing.assert_array_equal(O.huber_loss(p, t, sin_en=True).numpy(), z["huber_sin"])
     p, t, iw, ow = (torch.from_numpy(a) for a in z["sl1_lidar_in"])
     assert abs(O.smooth_l1_loss("DET", p, t, iw, ow, net_type="lidar").item() - z["sl1_lidar"][0]) <= 1e-7
+
+
+def test_uncertainty_statistics_and_aleatoric_loss_match_reference(golden_dir):
+    """loss_utils.py:82-85,114-141 (imported reference -> lidar_train.npz): MC variance / entropy / mutual information
+    and the aleatoric smooth-L1 with its gradients w.r.t. the prediction and the log-variance."""
+    z = _lt(golden_dir)
+    np.testing.assert_array_equal(O.compute_bbox_var(torch.from_numpy(z["mc_bbox_samples"])).numpy(), z["mc_bbox_var"])
+    cls = torch.from_numpy(z["mc_cls_samples"])
+    np.testing.assert_array_equal(O.categorical_mutual_information(cls).numpy(), z["mc_mutual_info"])
+    np.testing.assert_array_equal(O.categorical_entropy(torch.softmax(cls, 2).mean(0)).numpy(), z["mc_entropy"])
+    p, t, v, iw, ow = (torch.from_numpy(a) for a in z["sl1_al_in"])
+    p.requires_grad_(True)
+    v.requires_grad_(True)
+    loss = O.smooth_l1_loss("DET", p, t, iw, ow, bbox_var=v)
+    assert abs(loss.item() - z["sl1_al"][0]) <= 1e-7
+    loss.backward()
+    np.testing.assert_array_equal(p.grad.numpy(), z["sl1_al_dpred"])
+    np.testing.assert_array_equal(v.grad.numpy(), z["sl1_al_dvar"])
