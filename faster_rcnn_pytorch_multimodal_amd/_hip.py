@@ -5,7 +5,7 @@ built by ``faster_rcnn_pytorch_multimodal_amd.build.build()`` (``__graft_entry__
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint8, c_uint32, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint32, c_void_p
 
 from .build import LIB_PATH
 

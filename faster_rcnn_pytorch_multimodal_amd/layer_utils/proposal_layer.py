@@ -7,7 +7,6 @@ No min-size filter (the reference has none).  Sizes that depend on the data stay
 """
 import collections
 
-import torch
 
 from .. import ops
 from ..model.config import cfg

@@ -10,8 +10,6 @@ LiDAR (NET_TYPE 'lidar', :142-154,239-243): overlaps on the BEV rectangles, ``li
 the 8-column ``true_gt_boxes`` and each RoI's 3-D anchor, normalised by cfg.TRAIN.LIDAR.BBOX_NORMALIZE_*, 7-of-7K
 layout; the sampled rows' 3-D anchors are returned as well.
 """
-import torch
-
 from .. import ops
 from ..model.config import cfg
 from .anchor_target_layer import _draw_seed

@@ -6,7 +6,6 @@ gathered afterwards (``frcnn_sort_topk_desc`` in the canonical order score desc 
 the selected values are identical to selecting first and decoding after.  With fewer anchors than RPN_TOP_N the
 reference samples indices WITH replacement from numpy's global RNG (:32-37); that draw happens on the host here too.
 """
-import numpy as np
 import numpy.random as npr
 import torch
 

@@ -7,6 +7,8 @@ non-HIP execution path in this package.
 
 Layouts: activations NHWC ``(N, H, W, C)`` contiguous fp32, filters KRSC ``(K, R, S, C)`` contiguous fp32.
 """
+import ctypes
+
 import torch
 
 from . import _hip
@@ -46,7 +48,6 @@ def set_conv_autotune(enable):
 
 def export_conv_plans():
     """The tuned convolution plans as a list of 13-int rows (frcnn_conv2d_export_plans)."""
-    import ctypes
     lib = _hip.load()
     n = lib.frcnn_conv2d_export_plans(None, 0)
     buf = (ctypes.c_int * (13 * max(n, 1)))()
@@ -56,7 +57,6 @@ def export_conv_plans():
 
 def import_conv_plans(rows):
     """Install plans saved by export_conv_plans (e.g. to profile exactly the kernels a timed run used)."""
-    import ctypes
     flat = [int(v) for row in rows for v in row]
     if len(flat) % 13:
         raise _hip.HipError("import_conv_plans: rows must have 13 ints")
@@ -416,7 +416,6 @@ def bev_voxelize(points, pc_range, voxel_size, z_shift, max_points, max_voxels, 
                  elongation_col=-1):
     """Point cloud (N, F>=4) device tensor -> BEV map (gy, gx, num_slices+num_meta) and the device count of occupied
     cells (frcnn_bev_voxelize; lib/roi_data_layer/minibatch.py:434-512)."""
-    import ctypes
     lib = _hip.load()
     _dev_f32(points, "points")
     if points.dim() != 2 or points.shape[1] < 4 or points.shape[0] == 0:
