@@ -59,6 +59,22 @@ def lidar_forward(steps, streams=4):
                        "detections_last_frame": outs[0][1].cpu().tolist()}}
 
 
+def _timed_train_windows(net, blobs, opt, steps, windows=3):
+    """8 untimed steps (allocator / clocks settle after the plan tuning), then `windows` timed windows of `steps`
+    train steps each (pseudo batch of 16, train_val.py:379); returns the losses of the last window and the MEDIAN
+    window time, so that a one-off stall does not decide the number."""
+    for i in range(8):
+        net.train_step(blobs, opt, update_weights=False)
+    times, losses = [], []
+    for _ in range(windows):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        losses = [net.train_step(blobs, opt, update_weights=(i % 16 == 15)) for i in range(steps)]
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    return losses, sorted(times)[len(times) // 2]
+
+
 def fpn_train(steps, autotune=True):
     from faster_rcnn_pytorch_multimodal_amd import ops
     from faster_rcnn_pytorch_multimodal_amd.model import config as C
@@ -99,13 +115,7 @@ def fpn_train(steps, autotune=True):
     torch.cuda.synchronize()
     fwd_flops = sum(s["flops"] for s, _, _ in ops.PROFILE)
     ops.PROFILE = None
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    losses = []
-    for i in range(steps):
-        losses.append(net.train_step(blobs, opt, update_weights=(i % 16 == 15)))       # pseudo batch of 16 (train_val.py:379)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    losses, dt = _timed_train_windows(net, blobs, opt, steps)
     C.reset_cfg()
     return {"metric": "train steps/sec res101+FPN Faster-RCNN 1000x600 forward+backward", "value": steps / dt,
             "unit": "steps/s", "ms_per_step": 1e3 * dt / steps, "n_gpus": 1, "steps": steps, "dtype": "f32",
@@ -155,11 +165,7 @@ def lidar_train(steps):
         torch.cuda.synchronize()
         ops.set_conv_autotune(False)
     opt.zero_grad()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    losses = [net.train_step(blobs, opt, update_weights=(i % 16 == 15)) for i in range(steps)]
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    losses, dt = _timed_train_windows(net, blobs, opt, steps)
     C.reset_cfg()
     return {"metric": "train steps/sec res101 LiDAR-BEV Faster-RCNN 400x350x15 forward+backward", "value": steps / dt,
             "unit": "steps/s", "ms_per_step": 1e3 * dt / steps, "n_gpus": 1, "steps": steps, "dtype": "f32",
