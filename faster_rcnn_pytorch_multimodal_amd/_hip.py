@@ -113,6 +113,10 @@ def load():
         raise ImportError(
             "libfrcnn_hip.so is not built (%s). Run `python -m faster_rcnn_pytorch_multimodal_amd.build` "
             "or __graft_entry__.build(); this package has no non-HIP execution path." % LIB_PATH)
+    # torch ships its own libamdhip64: it must be in the process BEFORE this library is opened, so that both resolve
+    # to ONE HIP runtime (two runtimes = two device contexts: torch's pointers would mean nothing to the kernels and
+    # the second runtime reports "no ROCm-capable device").
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
