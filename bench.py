@@ -262,12 +262,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; this package has no CPU execution path")
-    torch.cuda.set_device(local_rank)
-    device = "cuda:%d" % local_rank
+    # FRCNN_BENCH_BACKEND=gloo is a REHEARSAL of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share
+    # devices, the collated record goes through the host); the judged multi-GPU run uses the default: RCCL.
+    backend = os.environ.get("FRCNN_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = "cuda:%d" % dev_index
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
+    gather_dev = device if backend == "nccl" else "cpu"
 
     from faster_rcnn_pytorch_multimodal_amd.model.frame_graph import FrameRunner
     net, sd = build_net(device)
@@ -288,7 +296,7 @@ def main():
     rec = [torch.zeros((NUM_CLASSES, MAX_DETS, 5), device=device) for _ in range(n_streams)]
     cnt = [torch.zeros((NUM_CLASSES,), dtype=torch.int32, device=device) for _ in range(n_streams)]
     from faster_rcnn_pytorch_multimodal_amd.model import collate
-    gathered = [torch.zeros((world, collate.record_numel(NUM_CLASSES, MAX_DETS)), device=device)
+    gathered = [torch.zeros((world, collate.record_numel(NUM_CLASSES, MAX_DETS)), device=gather_dev)
                 for _ in range(n_streams)] if world > 1 else None
     records = [torch.zeros(collate.record_numel(NUM_CLASSES, MAX_DETS), device=device) for _ in range(n_streams)]
     for st in streams:
@@ -300,7 +308,8 @@ def main():
             dets, counts = runners[k].run(frames[i % n_resident])
             if world > 1:
                 # eval collate: one fixed-size record per rank (detections + counts), all-gathered over xGMI
-                collate.gather_records(collate.pack_record(dets, counts, records[k]), gathered[k])
+                record = collate.pack_record(dets, counts, records[k])
+                collate.gather_records(record if backend == "nccl" else record.cpu(), gathered[k])
             else:
                 rec[k].copy_(dets, non_blocking=True)
                 cnt[k].copy_(counts, non_blocking=True)
@@ -328,7 +337,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     del host
