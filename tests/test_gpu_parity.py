@@ -413,6 +413,50 @@ def test_filter_per_class_matches_oracle(hip, thresh, max_dets):
     assert counts[0] == 0
 
 
+def test_empty_and_degenerate_inputs(hip):
+    """Edge cases the frame loop can meet: no score above the threshold, zero live RoIs, a single proposal surviving
+    NMS, a point cloud entirely outside the grid, fewer candidates than top-n with every score tied."""
+    from faster_rcnn_pytorch_multimodal_amd.layer_utils.proposal_layer import proposal_layer
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.roi_data_layer.minibatch import get_lidar_blob
+    from faster_rcnn_pytorch_multimodal_amd.utils.filter_predictions import filter_device
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    info = np.array([0, 1000, 0, 600, 0, 0, 1.0], np.float32)
+    # 1. nothing passes the score threshold -> zero detections in every class, detections buffer stays zero
+    prob = torch.full((50, 3), 0.2)
+    boxes = torch.cat([_rand_boxes(50, g) for _ in range(3)], 1).contiguous()
+    dets, counts = filter_device(None, prob.to(DEV), boxes.to(DEV), info, 0.5, 100, 50)
+    assert counts.cpu().tolist() == [0, 0, 0] and (dets == 0).all()
+    # 2. zero live RoIs (device-side count 0): RoIAlign writes zeros, the filter finds nothing
+    feat = torch.randn(1, 38, 63, 64, generator=g).to(DEV)
+    rois = torch.cat((torch.zeros(20, 1), _rand_boxes(20, g)), 1).to(DEV)
+    zero = torch.zeros(1, dtype=torch.int32, device=DEV)
+    assert (ops.roi_align_nhwc(feat, rois, 7, 1 / 16.0, 0, roi_count=zero) == 0).all()
+    dets, counts = filter_device(zero, torch.full((50, 3), 0.9).to(DEV), boxes.to(DEV), info, 0.5, 100, 50)
+    assert counts.cpu().tolist() == [0, 0, 0]
+    # 3. every anchor decodes to the same box: NMS keeps exactly one, the other rows of the blob are zero padding
+    a, h, w = 25, 4, 5
+    anchors = torch.tensor([[100., 100, 199, 179]]).repeat(h * w * a, 1)
+    prob_map = torch.rand(1, h, w, 2 * a, generator=g)
+    deltas = torch.zeros(1, h, w, 4 * a)
+    C.reset_cfg()
+    blob, scores, _ = proposal_layer(prob_map.to(DEV), deltas.to(DEV), info, "TEST", anchors.to(DEV), None, a)
+    # zero deltas decode to [x1, y1, x1 + w, y1 + h] with w = x2 - x1 + 1: the reference's codec has no "-1" (:102-105)
+    want = O.clip_boxes(O.bbox_transform_inv(anchors[:1], torch.zeros(1, 4)), info)
+    assert blob.shape == (1, 5) and torch.equal(blob[0, 1:].cpu(), want[0]) and want[0].tolist() == [100., 100, 200, 180]
+    assert float(scores[0]) == float(prob_map[..., a:].max())
+    # 4. all scores tied and fewer candidates than top-n: order = index order, count = n
+    order, sorted_scores, count = ops.sort_topk_desc(torch.full((37,), 0.5).to(DEV), 6000)
+    assert count.item() == 37 and order.cpu().tolist() == list(range(37))
+    # 5. a point cloud entirely outside the range: all-zero blob of the right shape
+    C.cfg.NET_TYPE = "lidar"
+    pts = np.array([[-5.0, 0, 0, 1], [80.0, 0, 0, 1], [10.0, 50.0, 0, 1], [10.0, 0, 9.0, 1]], np.float32)
+    infos, blob = get_lidar_blob(pts, 0.5, device=DEV)
+    assert tuple(blob.shape) == (1, 400, 350, 15) and (blob == 0).all()
+    C.reset_cfg()
+
+
 # ------------------------------------------------------------------------------------------------
 # backbone against the reference's golden stage outputs, and the whole detector against the oracle
 # ------------------------------------------------------------------------------------------------

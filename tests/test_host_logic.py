@@ -211,3 +211,21 @@ def test_voc_eval_matches_reference_vectors(tmp_path):
     assert open(lpath).read() == "0 t0 0.900 1.500 -2.250 0.500 4.700 2.100 1.800 0.31000\n"
     _, _, s, b, _ = V.read_results_file(lpath, num_box_values=7)
     assert s.tolist() == [0.9] and b.shape == (1, 7)
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """include/frcnn_hip.h is valid C99 and libfrcnn_hip.so is usable without Python, C++ or torch: a C program built
+    with gcc dlopens the library, resolves every declared symbol and calls the GPU-free entry points."""
+    import os
+    import shutil
+    import subprocess
+    from faster_rcnn_pytorch_multimodal_amd import _hip
+    from faster_rcnn_pytorch_multimodal_amd.build import LIB_PATH
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_check")
+    subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c_abi", "abi_check.c"), "-o", exe, "-ldl"], check=True)
+    out = subprocess.run([exe, LIB_PATH] + sorted(_hip.PROTOTYPES), check=True, capture_output=True, text=True)
+    assert "abi ok" in out.stdout and ("%d symbols" % len(_hip.PROTOTYPES)) in out.stdout
