@@ -20,6 +20,11 @@ inline int check_launch(const char* what) {
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// frcnn_conv2d_set_autotune state (conv_igemm.hip), shared with the filter-gradient kernel's own plan cache
+// (conv_wgrad.hip), which frcnn_conv2d_clear_plans empties as well.
+bool autotune_enabled();
+void clear_wgrad_plans();
+
 }  // namespace frcnn
 
 #define FRCNN_REQUIRE(cond, ...)                                   \

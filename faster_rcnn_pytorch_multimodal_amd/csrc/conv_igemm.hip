@@ -685,9 +685,14 @@ extern "C" int frcnn_conv2d_set_autotune(int enable) {
   return FRCNN_OK;
 }
 
+bool frcnn::autotune_enabled() { return g_autotune != 0; }
+
 extern "C" int frcnn_conv2d_clear_plans(void) {
-  std::lock_guard<std::mutex> lock(g_plan_mutex);
-  g_plan_cache.clear();
+  {
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    g_plan_cache.clear();
+  }
+  frcnn::clear_wgrad_plans();
   return FRCNN_OK;
 }
 

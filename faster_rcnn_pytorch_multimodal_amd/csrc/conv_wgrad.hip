@@ -15,14 +15,23 @@
 // so the result is deterministic.
 #include "common.h"
 
+#include <algorithm>
+#include <array>
+#include <map>
+#include <mutex>
+#include <vector>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BR = 32;    // pixels per reduction step
-constexpr int BT = 128;   // tile edge (k rows x q columns)
 constexpr int NUM_CU = 256;
+// tile edge BT = 64 * TI (k rows x q columns), 2 x 2 waves each owning TI x TI MFMA tiles of 32 x 32:
+//   TI = 2: 128 x 128, the arithmetic-intensity choice for large pixel counts;
+//   TI = 1: 64 x 64, four times as many tiles -> fewer pixel splits (less slab traffic, longer K loops) when the
+//           filter is small and the pixel count short (layer3 / layer4 of one frame: M = 2394 / 608).
 
 struct WgradParams {
   const float* x;
@@ -34,7 +43,12 @@ struct WgradParams {
   int tiles_k, tiles_q;
 };
 
+template <int TI>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const WgradParams p) {
+  constexpr int BT = 64 * TI;
+  constexpr int CH = BT / 4;            // 16-byte chunks per staged pixel row
+  constexpr int RP = 256 / CH;          // pixel rows staged per pass
+  constexpr int NP = BR / RP;           // passes per reduction step
   __shared__ __attribute__((aligned(16))) float As[2][BR][BT];  // dy tile   [pixel][k]
   __shared__ __attribute__((aligned(16))) float Bs[2][BR][BT];  // x tile    [pixel][q]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -44,8 +58,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const WgradParams p) {
   const int step_begin = blockIdx.z * p.steps_per_split;
   const int step_end = min(step_begin + p.steps_per_split, p.steps);
 
-  // staging: thread t moves 16-byte chunk (t & 31) of pixel rows (t >> 5) + 8*i, i < 4
-  const int ch = t & 31, prow = t >> 5;
+  // staging: thread t moves 16-byte chunk (t % CH) of pixel rows (t / CH) + RP*i, i < NP
+  const int ch = t % CH, prow = t / CH;
   const int ka = k0 + ch * 4;            // first of this thread's 4 output channels
   const bool ka_ok = ka < p.K;           // K % 4 == 0: a chunk is all in or all out
   const int qb = q0 + ch * 4;            // first of this thread's 4 filter elements
@@ -54,11 +68,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const WgradParams p) {
   const int cb = qb - tap * p.C;
   const int tr = tap / p.S, ts = tap - tr * p.S;
 
-  f32x4 ra[4], rb[4];
+  f32x4 ra[NP], rb[NP];
   auto load_tiles = [&](int step) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = step * BR + prow + 8 * i;
+    for (int i = 0; i < NP; ++i) {
+      const int m = step * BR + prow + RP * i;
       const bool m_ok = m < p.M;
       ra[i] = (m_ok && ka_ok) ? *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.K + ka) : f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -75,17 +89,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const WgradParams p) {
   };
   auto store_tiles = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<f32x4*>(&As[buf][prow + 8 * i][ch * 4]) = ra[i];
-      *reinterpret_cast<f32x4*>(&Bs[buf][prow + 8 * i][ch * 4]) = rb[i];
+    for (int i = 0; i < NP; ++i) {
+      *reinterpret_cast<f32x4*>(&As[buf][prow + RP * i][ch * 4]) = ra[i];
+      *reinterpret_cast<f32x4*>(&Bs[buf][prow + RP * i][ch * 4]) = rb[i];
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TI][TI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -101,15 +115,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const WgradParams p) {
     if (more) load_tiles(step + 1);
 #pragma unroll
     for (int kk = 0; kk < BR / 2; ++kk) {
-      float a[2], b[2];
+      float a[TI], b[TI];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = As[cur][2 * kk + lh][(wr * 2 + i) * 32 + l31];
+      for (int i = 0; i < TI; ++i) a[i] = As[cur][2 * kk + lh][(wr * TI + i) * 32 + l31];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Bs[cur][2 * kk + lh][(wc * 2 + j) * 32 + l31];
+      for (int j = 0; j < TI; ++j) b[j] = Bs[cur][2 * kk + lh][(wc * TI + j) * 32 + l31];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (more) store_tiles(cur ^ 1);
     __syncthreads();
@@ -119,14 +133,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const WgradParams p) {
   // D: column (lane & 31) = q, row (r&3) + 8*(r>>2) + 4*(lane>>5) = k
   float* out = p.out + (size_t)blockIdx.z * p.K * p.Q;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int q = q0 + (wc * 2 + j) * 32 + l31;
+  for (int j = 0; j < TI; ++j) {
+    const int q = q0 + (wc * TI + j) * 32 + l31;
     if (q >= p.Q) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int k = k0 + (wr * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int k = k0 + (wr * TI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (k < p.K) out[(size_t)k * p.Q + q] = acc[i][j][r];
       }
   }
@@ -170,15 +184,18 @@ __global__ __launch_bounds__(256) void bias_grad_final_kernel(const float* __res
   db[k] = s;
 }
 
-int choose_splits(int tiles, int steps) {
+// Pixel splits for a given tile count: estimated cycles of the slowest CU (two workgroups per CU share the SIMDs)
+// plus the reduction pass.  ti scales the per-step MFMA work (TI*TI tiles per wave).
+int choose_splits(int tiles, int steps, int ti) {
   int best = 1;
   double best_t = 1e300;
+  const double step_cyc = 2.0 * 1024.0 * ti * ti;
   for (int sp = 1; sp <= 64; ++sp) {
     const int sps = (steps + sp - 1) / sp;
     const int real = (steps + sps - 1) / sps;
     if (real != sp) continue;
     const long rounds = ((long)tiles * real + 2 * NUM_CU - 1) / (2 * NUM_CU);  // two workgroups per CU
-    const double tcyc = rounds * (sps * 2.0 * 4096.0 + 6000.0) + (real > 1 ? real * 300.0 : 0.0);
+    const double tcyc = rounds * (sps * step_cyc + 6000.0) + (real > 1 ? real * 300.0 : 0.0);
     if (tcyc < best_t) {
       best_t = tcyc;
       best = real;
@@ -187,9 +204,111 @@ int choose_splits(int tiles, int steps) {
   return best;
 }
 
+struct WgradPlan {
+  int ti, splits;
+};
+inline int tiles_for(int k, int q, int ti) { return ((k + 64 * ti - 1) / (64 * ti)) * ((q + 64 * ti - 1) / (64 * ti)); }
+
+// Default plan: the 128 x 128 tile and the modelled split; in autotune mode (frcnn_conv2d_set_autotune, shared with the
+// forward kernel) the first call of a shape times both tile sizes around the modelled split and caches the fastest.
+typedef std::array<int, 9> WgradKey;
+std::map<WgradKey, WgradPlan> g_wgrad_plans;
+std::mutex g_wgrad_mutex;
+
+std::vector<WgradPlan> wgrad_candidates(int k, int q, int steps) {
+  std::vector<WgradPlan> out;
+  for (int ti = 2; ti >= 1; --ti) {
+    const int base = choose_splits(tiles_for(k, q, ti), steps, ti);
+    for (int sp : {base, std::max(1, base / 2), std::min(64, base * 2), 1}) {
+      const int sps = (steps + sp - 1) / sp;
+      const int real = (steps + sps - 1) / sps;
+      bool dup = false;
+      for (const WgradPlan& c : out) dup = dup || (c.ti == ti && c.splits == real);
+      if (!dup && (size_t)real * k * q * sizeof(float) <= ((size_t)1 << 28)) out.push_back(WgradPlan{ti, real});
+    }
+  }
+  return out;
+}
+
 bool wgrad_args_ok(int n, int h, int w, int c, int k, int r, int s, int stride, int pad) {
   return n > 0 && h > 0 && w > 0 && c > 0 && (c % 4) == 0 && k > 0 && (k % 4) == 0 && r > 0 && s > 0 && stride > 0 &&
          pad >= 0 && (h + 2 * pad - r) >= 0 && (w + 2 * pad - s) >= 0;
+}
+
+}  // namespace
+
+void frcnn::clear_wgrad_plans() {
+  std::lock_guard<std::mutex> lock(g_wgrad_mutex);
+  g_wgrad_plans.clear();
+}
+
+namespace {
+
+WgradKey wgrad_key(int n, int h, int w, int c, int k, int r, int s, int stride, int pad) {
+  return WgradKey{n, h, w, c, k, r, s, stride, pad};
+}
+
+bool lookup_wgrad(const WgradKey& key, WgradPlan* pl) {
+  std::lock_guard<std::mutex> lock(g_wgrad_mutex);
+  auto it = g_wgrad_plans.find(key);
+  if (it == g_wgrad_plans.end()) return false;
+  *pl = it->second;
+  return true;
+}
+
+size_t slab_bytes_of(const WgradPlan& pl, int k, int q) {
+  return pl.splits > 1 ? (size_t)pl.splits * k * q * sizeof(float) : 0;
+}
+
+// main kernel + the slab reduction of one plan
+int launch_wgrad(WgradParams p, const WgradPlan& pl, float* dw, void* ws, hipStream_t stream) {
+  const int bt = 64 * pl.ti;
+  p.tiles_k = (p.K + bt - 1) / bt;
+  p.tiles_q = (p.Q + bt - 1) / bt;
+  p.steps_per_split = (p.steps + pl.splits - 1) / pl.splits;
+  p.out = pl.splits > 1 ? static_cast<float*>(ws) : dw;
+  const dim3 grid(p.tiles_k * p.tiles_q, 1, pl.splits);
+  if (pl.ti == 2) hipLaunchKernelGGL(conv_wgrad_f32<2>, grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(conv_wgrad_f32<1>, grid, dim3(256), 0, stream, p);
+  int rc = frcnn::check_launch("conv_wgrad_f32");
+  if (rc != FRCNN_OK) return rc;
+  if (pl.splits > 1) {
+    const size_t n4 = (size_t)p.K * p.Q / 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0,
+                       stream, static_cast<const float*>(ws), pl.splits, n4, dw);
+    rc = frcnn::check_launch("wgrad_reduce_kernel");
+  }
+  return rc;
+}
+
+// Time every candidate twice on the caller's tensors (best-of), outside stream capture only.
+bool tune_wgrad(const WgradParams& p, float* dw, void* ws, size_t ws_avail, hipStream_t stream, WgradPlan* best) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess) return false;
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return false; }
+  const std::vector<WgradPlan> cands = wgrad_candidates(p.K, p.Q, p.steps);
+  std::vector<float> best_of(cands.size(), 1e30f);
+  for (int pass = 0; pass < 2; ++pass)
+    for (size_t ci = 0; ci < cands.size(); ++ci) {
+      if (slab_bytes_of(cands[ci], p.K, p.Q) > ws_avail) continue;
+      if (pass == 0 && launch_wgrad(p, cands[ci], dw, ws, stream) != FRCNN_OK) continue;   // warm-up
+      (void)hipEventRecord(e0, stream);
+      bool ok = true;
+      for (int i = 0; i < 3 && ok; ++i) ok = launch_wgrad(p, cands[ci], dw, ws, stream) == FRCNN_OK;
+      (void)hipEventRecord(e1, stream);
+      float ms = 0.f;
+      if (hipEventSynchronize(e1) != hipSuccess || !ok || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
+      best_of[ci] = std::min(best_of[ci], ms);
+    }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  float best_ms = 1e30f;
+  bool found = false;
+  for (size_t ci = 0; ci < cands.size(); ++ci)
+    if (best_of[ci] < best_ms) { best_ms = best_of[ci]; *best = cands[ci]; found = true; }
+  return found;
 }
 
 }  // namespace
@@ -200,10 +319,20 @@ extern "C" size_t frcnn_conv2d_bwd_weight_ws_bytes(int n, int h, int w, int c, i
   const int ho = (h + 2 * pad - r) / stride + 1, wo = (w + 2 * pad - s) / stride + 1;
   const long M = (long)n * ho * wo;
   const int q = r * s * c;
-  const int tiles = ((k + BT - 1) / BT) * ((q + BT - 1) / BT);
-  const int splits = choose_splits(tiles, (int)((M + BR - 1) / BR));
+  const int steps = (int)((M + BR - 1) / BR);
+  WgradPlan pl;
+  size_t slabs;
+  if (lookup_wgrad(wgrad_key(n, h, w, c, k, r, s, stride, pad), &pl)) {
+    slabs = slab_bytes_of(pl, k, q);
+  } else if (frcnn::autotune_enabled()) {      // room for the largest candidate of a shape that is about to be tuned
+    slabs = 0;
+    for (const WgradPlan& cand : wgrad_candidates(k, q, steps)) slabs = std::max(slabs, slab_bytes_of(cand, k, q));
+  } else {
+    pl = WgradPlan{2, choose_splits(tiles_for(k, q, 2), steps, 2)};
+    slabs = slab_bytes_of(pl, k, q);
+  }
   // slabs (when the pixel range is split) + the bias-gradient partials
-  return (splits > 1 ? (size_t)splits * k * q * sizeof(float) : 0) + (size_t)BIAS_GROUPS * k * sizeof(float);
+  return frcnn::align_up(slabs, 256) + (size_t)BIAS_GROUPS * k * sizeof(float);
 }
 
 extern "C" int frcnn_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, int n, int h, int w,
@@ -215,7 +344,7 @@ extern "C" int frcnn_conv2d_bwd_weight(const float* x, const float* dy, float* d
                 "conv2d_bwd_weight: bad shape n=%d h=%d w=%d c=%d k=%d r=%d s=%d stride=%d pad=%d (need c%%4==0, k%%4==0)",
                 n, h, w, c, k, r, s, stride, pad);
   WgradParams p;
-  p.x = x; p.dy = dy;
+  p.x = x; p.dy = dy; p.out = nullptr;
   p.H = h; p.W = w; p.C = c; p.K = k; p.R = r; p.S = s; p.stride = stride; p.pad = pad;
   p.Ho = (h + 2 * pad - r) / stride + 1;
   p.Wo = (w + 2 * pad - s) / stride + 1;
@@ -224,25 +353,24 @@ extern "C" int frcnn_conv2d_bwd_weight(const float* x, const float* dy, float* d
   p.M = (int)M;
   p.Q = r * s * c;
   p.steps = (p.M + BR - 1) / BR;
-  p.tiles_k = (k + BT - 1) / BT;
-  p.tiles_q = (p.Q + BT - 1) / BT;
-  const int splits = choose_splits(p.tiles_k * p.tiles_q, p.steps);
-  p.steps_per_split = (p.steps + splits - 1) / splits;
-  const size_t slab_bytes = splits > 1 ? (size_t)splits * k * p.Q * sizeof(float) : 0;
-  const size_t need = slab_bytes + (db ? (size_t)BIAS_GROUPS * k * sizeof(float) : 0);
+  p.steps_per_split = p.steps; p.tiles_k = p.tiles_q = 0;
+  const size_t bias_bytes = db ? (size_t)BIAS_GROUPS * k * sizeof(float) : 0;
+  const size_t slab_room = ws_bytes > bias_bytes ? ((ws_bytes - bias_bytes) / 256) * 256 : 0;   // slabs first, 256-aligned
+  const WgradKey key = wgrad_key(n, h, w, c, k, r, s, stride, pad);
+  WgradPlan pl;
+  bool have = lookup_wgrad(key, &pl);
+  if (!have && frcnn::autotune_enabled() && ws && tune_wgrad(p, dw, ws, slab_room, stream, &pl)) {
+    std::lock_guard<std::mutex> lock(g_wgrad_mutex);
+    g_wgrad_plans[key] = pl;
+    have = true;
+  }
+  if (!have) pl = WgradPlan{2, choose_splits(tiles_for(k, p.Q, 2), p.steps, 2)};
+  const size_t slab_bytes = frcnn::align_up(slab_bytes_of(pl, k, p.Q), 256);
+  const size_t need = slab_bytes + bias_bytes;
   if (need > 0 && (!ws || ws_bytes < need))
     return frcnn::fail(FRCNN_ERR_WS, "conv2d_bwd_weight: workspace %zu < %zu bytes", ws_bytes, need);
-  p.out = splits > 1 ? static_cast<float*>(ws) : dw;
-  hipLaunchKernelGGL(conv_wgrad_f32, dim3(p.tiles_k * p.tiles_q, 1, splits), dim3(256), 0, stream, p);
-  int rc = frcnn::check_launch("conv_wgrad_f32");
+  int rc = launch_wgrad(p, pl, dw, ws, stream);
   if (rc != FRCNN_OK) return rc;
-  if (splits > 1) {
-    const size_t n4 = (size_t)k * p.Q / 4;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0,
-                       stream, static_cast<const float*>(ws), splits, n4, dw);
-    rc = frcnn::check_launch("wgrad_reduce_kernel");
-    if (rc != FRCNN_OK) return rc;
-  }
   if (db) {
     float* partial = reinterpret_cast<float*>(static_cast<char*>(ws) + slab_bytes);
     hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((k + 63) / 64, BIAS_GROUPS), dim3(256), 0, stream, dy, p.M, k,

@@ -77,7 +77,8 @@ int frcnn_conv2d_set_tile(int tm, int tn);
  * OUTSIDE stream capture times every (tile, split-K) candidate on the caller's tensors with HIP events — this
  * synchronises with the host — and caches the fastest; later calls (also captured ones) reuse it.  While enabled,
  * frcnn_conv2d_fwd_ws_bytes returns room for the largest candidate of a not-yet-tuned shape.  Default: off (the
- * analytic model picks).  frcnn_conv2d_clear_plans forgets the cache. */
+ * analytic model picks).  frcnn_conv2d_bwd_weight follows the same switch with its own cache (tile 128x128 or 64x64 x
+ * pixel splits).  frcnn_conv2d_clear_plans forgets both caches. */
 int frcnn_conv2d_set_autotune(int enable);
 int frcnn_conv2d_clear_plans(void);
 /* The plan cache as a table of 13 ints per entry (shape key n,h,w,c,k,r,s,stride,pad,out_stride; tile index, splits,
