@@ -13,17 +13,18 @@ import numpy as np
 import torch
 
 
-def record_numel(num_classes, max_out):
-    return num_classes * max_out * 5 + num_classes
+def record_numel(num_classes, max_out, elem=5):
+    """elem = 5 image rows [x1,y1,x2,y2,score], 8 LiDAR rows [xc,yc,zc,l,w,h,ry,score]."""
+    return num_classes * max_out * elem + num_classes
 
 
 def pack_record(dets, counts, out=None):
-    """dets (K, max_out, 5) fp32, counts (K,) int -> (K*max_out*5 + K,) fp32 record (device-side, async)."""
-    k, m, _ = dets.shape
+    """dets (K, max_out, E) fp32, counts (K,) int -> (K*max_out*E + K,) fp32 record (device-side, async)."""
+    k, m, e = dets.shape
     if out is None:
-        out = torch.empty(record_numel(k, m), dtype=torch.float32, device=dets.device)
-    out[:k * m * 5].copy_(dets.reshape(-1))
-    out[k * m * 5:].copy_(counts)
+        out = torch.empty(record_numel(k, m, e), dtype=torch.float32, device=dets.device)
+    out[:k * m * e].copy_(dets.reshape(-1))
+    out[k * m * e:].copy_(counts)
     return out
 
 
@@ -37,16 +38,16 @@ def gather_records(record, gathered=None, group=None):
     return gathered
 
 
-def unpack_records(gathered, num_classes, max_out):
-    """(world, numel) host/device matrix -> list over ranks of per-class (n_j, 5) float32 arrays, i.e. the
+def unpack_records(gathered, num_classes, max_out, elem=5):
+    """(world, numel) host/device matrix -> list over ranks of per-class (n_j, elem) float32 arrays, i.e. the
     ``all_boxes[cls][frame]`` entries of lib/model/test.py:228 for the frames of this step."""
     g = gathered.detach().cpu().numpy()
     frames = []
-    split = num_classes * max_out * 5
+    split = num_classes * max_out * elem
     for r in range(g.shape[0]):
-        dets = g[r, :split].reshape(num_classes, max_out, 5)
+        dets = g[r, :split].reshape(num_classes, max_out, elem)
         counts = np.rint(g[r, split:]).astype(np.int64)
-        frames.append([dets[j, :counts[j]].copy() if j > 0 else np.empty((0, 5), np.float32)
+        frames.append([dets[j, :counts[j]].copy() if j > 0 else np.empty((0, elem), np.float32)
                        for j in range(num_classes)])
     return frames
 

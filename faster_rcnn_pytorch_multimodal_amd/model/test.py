@@ -2,9 +2,10 @@
 (the ``max_dets`` cut that test_net applies per class), for the image detector.
 
 ``frame_detect`` keeps the reference's call sequence (test_frame -> filter_and_draw_prep).
-``detect_frames`` is the throughput form used by bench.py and the 8-GPU eval collate: everything up to
+``detect_frame_device`` is the throughput form used by bench.py and the 8-GPU eval collate: everything up to
 the per-class, max_dets-limited detections stays on the device and a frame ends with ONE device->host
-copy of a fixed-size record.
+copy of a fixed-size record.  ``test_net`` is the eval loop of :138-257 over a caller-supplied frame source,
+sharded one frame per rank per step.
 """
 import numpy as np
 import torch
@@ -56,3 +57,66 @@ def bbox_voxel_grid_to_pc(bboxes, bev_extents, info):
     bboxes[:, 3] = bboxes[:, 3] * kx
     bboxes[:, 4] = bboxes[:, 4] * ky
     return bboxes
+
+
+def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=False, eval_det=False):
+    """Eval loop of lib/model/test.py:138-257 over a frame source, sharded one frame per rank per step when
+    torch.distributed is initialised (BASELINE.json configs[4]).
+
+    ``db`` is the caller's dataset adaptor (dataset classes are out of scope): ``num_classes``, ``num_frames(mode)``,
+    ``blobs_at(i, mode)`` -> {'data': (1,H,W,C) blob or None, 'info': 7-vector}, optional ``name_at(i, mode)``,
+    optional ``evaluate_detections(all_boxes, out_dir, mode)``.  Per frame everything stays on the device up to the
+    per-class, max_dets-limited record (``detect_frame_device``); ranks exchange the fixed-size records with ONE
+    all-gather per step (``collate.gather_records``), so every rank ends with the complete ``all_boxes``.
+    LiDAR detections are converted from the voxel grid to metres (:223-224).  Writes ``detections.pkl`` like the
+    reference (:246-248) plus the per-class text files of lib/datasets/db.py:305-367 (rank 0 only) and returns
+    ``all_boxes[cls][frame]`` (rows [box..., score])."""
+    import os
+    import pickle
+    import torch.distributed as dist
+    from ..datasets import voc_eval
+    from . import collate
+    if draw_det:
+        raise NotImplementedError("drawing is dataset tooling, outside the accelerated path")
+    np.random.seed(cfg.RNG_SEED)
+    num_images, k = db.num_frames(mode), db.num_classes
+    lidar = cfg.NET_TYPE == 'lidar'
+    elem = 8 if lidar else 5
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank = dist.get_rank() if distributed else 0
+    world = dist.get_world_size() if distributed else 1
+    all_boxes = [[np.empty(0) for _ in range(num_images)] for _ in range(k)]
+    mine = collate.shard_frames(num_images, rank, world)
+    steps = (num_images + world - 1) // world
+    dev = torch.device(net._device)
+    for s in range(steps):
+        dets = torch.zeros((k, max_dets, elem), dtype=torch.float32, device=dev)
+        counts = torch.zeros((k,), dtype=torch.int32, device=dev)
+        blobs = db.blobs_at(mine[s], mode) if s < len(mine) else None
+        if blobs is not None and blobs.get('data') is not None:
+            dets, counts = detect_frame_device(net, blobs['data'], blobs['info'], thresh, max_dets, max_dets)
+        if distributed:
+            rows = collate.unpack_records(collate.gather_records(collate.pack_record(dets, counts)), k, max_dets, elem)
+            frames_of_step = [(r, s * world + r) for r in range(world) if s * world + r < num_images]
+        else:
+            d, c = dets.cpu().numpy(), counts.cpu().numpy()
+            rows = [[d[j, :c[j]].copy() if j > 0 else np.empty((0, elem), np.float32) for j in range(k)]]
+            frames_of_step = [(0, mine[s])] if s < len(mine) else []
+        for r, i in frames_of_step:
+            info = db.blobs_at(i, mode)['info'] if lidar else None
+            for j in range(1, k):
+                cls_boxes = rows[r][j]
+                if lidar and cls_boxes.size:
+                    cls_boxes = bbox_voxel_grid_to_pc(cls_boxes, lidar_extents(), info)
+                all_boxes[j][i] = cls_boxes if cls_boxes.size else np.empty(0)
+    if rank == 0:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, 'detections.pkl'), 'wb') as f:
+            pickle.dump(all_boxes, f, pickle.HIGHEST_PROTOCOL)
+        names = [db.name_at(i, mode) if hasattr(db, 'name_at') else '%06d' % i for i in range(num_images)]
+        writer = voc_eval.write_lidar_results_file if lidar else voc_eval.write_image_results_file
+        for j in range(1, k):
+            writer(all_boxes[j], names, os.path.join(out_dir, 'det_%s_cls%d.txt' % (mode, j)))
+        if eval_det and hasattr(db, 'evaluate_detections'):
+            db.evaluate_detections(all_boxes, out_dir, mode)
+    return all_boxes

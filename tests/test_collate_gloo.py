@@ -65,3 +65,68 @@ def test_shard_frames_partition():
     for world in (1, 2, 3, 8):
         seen = sorted(i for r in range(world) for i in collate.shard_frames(11, r, world))
         assert seen == list(range(11))
+
+
+class _FakeDb:
+    """Frame source for model.test.test_net: 5 frames, frame 3 has no data (the reference skips such frames)."""
+    num_classes = K
+
+    def num_frames(self, mode):
+        return FRAMES
+
+    def blobs_at(self, i, mode):
+        return {"data": None if i == 3 else np.full((1, 4, 4, 3), float(i), np.float32),
+                "info": np.array([0, 4, 0, 4, 0, 0, 1.0], np.float32)}
+
+    def name_at(self, i, mode):
+        return "frame%02d" % i
+
+
+def _fake_detect(net, data, info, thresh, max_dets, max_out):
+    dets, counts = _fake_frame(int(data[0, 0, 0, 0]))
+    return torch.from_numpy(dets), torch.from_numpy(counts)
+
+
+def _test_net_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.model import test as T
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    C.reset_cfg()
+    C.cfg.NET_TYPE = "image"
+    T.detect_frame_device = _fake_detect               # the device path is covered by the -m gpu tests
+
+    class Net:
+        _device = "cpu"
+
+    all_boxes = T.test_net(Net(), _FakeDb(), os.path.join(out_dir, "eval"), max_dets=MAX_OUT, thresh=0.5)
+    torch.save(all_boxes, os.path.join(out_dir, "boxes%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_test_net_eval_loop_world2_gloo(tmp_path):
+    """model.test.test_net (lib/model/test.py:138-257) sharded over two ranks: every rank ends with the complete
+    all_boxes, the skipped frame stays empty, rank 0 writes detections.pkl and the per-class text files."""
+    import pickle
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_test_net_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [torch.load(os.path.join(str(tmp_path), "boxes%d.pt" % r), weights_only=False) for r in range(2)]
+    for frame in range(FRAMES):
+        dets, counts = _fake_frame(frame)
+        for j in range(1, K):
+            for r in range(2):
+                if frame == 3 or counts[j] == 0:
+                    assert got[r][j][frame].size == 0
+                else:
+                    np.testing.assert_array_equal(got[r][j][frame], dets[j, :counts[j]])
+    with open(tmp_path / "eval" / "detections.pkl", "rb") as f:
+        pk = pickle.load(f)
+    assert len(pk) == K and len(pk[1]) == FRAMES
+    lines = open(tmp_path / "eval" / "det_test_cls1.txt").read().splitlines()
+    assert len(lines) == sum(int(_fake_frame(i)[1][1]) for i in range(FRAMES) if i != 3)
+    assert all(l.split(" ")[1].startswith("frame") for l in lines)

@@ -1253,6 +1253,48 @@ def test_conv_plan_autotune_export_import(hip):
     lib.frcnn_conv2d_clear_plans()
 
 
+def test_test_net_eval_loop_on_device(hip, tmp_path):
+    """model.test.test_net (lib/model/test.py:138-257) with the real detector: every all_boxes[cls][frame] equals the
+    per-frame device detections, a frame without data stays empty, detections.pkl and the text results are written,
+    and scoring the detections against themselves with datasets.voc_eval gives AP = 1."""
+    import pickle
+    from faster_rcnn_pytorch_multimodal_amd.datasets import voc_eval
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.model.test import detect_frame_device, test_net
+    net, _ = _build_pair(seed=31)
+    net.eval()
+    info = np.array([0, 192, 0, 128, 0, 0, 1.0], np.float32)
+    frames = [(np.random.default_rng(i).standard_normal((1, 128, 192, 3)) * 50).astype(np.float32) for i in range(3)]
+
+    class Db:
+        num_classes = 2
+
+        def num_frames(self, mode):
+            return 4
+
+        def blobs_at(self, i, mode):
+            return {"data": frames[i] if i < 3 else None, "info": info}
+
+    all_boxes = test_net(net, Db(), str(tmp_path / "eval"), max_dets=100, thresh=0.05)
+    assert len(all_boxes) == 2 and len(all_boxes[1]) == 4 and all_boxes[1][3].size == 0
+    total = 0
+    for i in range(3):
+        dets, counts = detect_frame_device(net, frames[i], info, 0.05, 100, 100)
+        n = int(counts[1])
+        total += n
+        np.testing.assert_array_equal(all_boxes[1][i].reshape(-1, 5), dets[1, :n].cpu().numpy())
+    assert total > 0
+    with open(tmp_path / "eval" / "detections.pkl", "rb") as f:
+        assert len(pickle.load(f)[1]) == 4
+    idx, tok, score, box, _ = voc_eval.read_results_file(str(tmp_path / "eval" / "det_test_cls1.txt"))
+    assert len(idx) == total
+    recs = {"%06d" % i: {"bbox": np.round(all_boxes[1][i].reshape(-1, 5)[:, :4], 1), "difficult": np.zeros(len(all_boxes[1][i].reshape(-1, 5)))}
+            for i in range(4)}
+    rec, prec, ap = voc_eval.voc_eval_arrays(tok, score, box, recs, ovthresh=0.9)
+    assert ap > 0.5 and rec[-1] > 0.5            # identical boxes (up to the file's 0.1 px rounding); duplicates are fp
+    C.reset_cfg()
+
+
 def test_solver_loop_on_device(hip, tmp_path):
     """model/train_val.SolverWrapper (lib/model/train_val.py:296-503) driving the HIP network: gradients of every
     trainable filter accumulate inside the flat bucket (views, no copies), the optimizer steps every batch_size
