@@ -105,9 +105,18 @@ __device__ __forceinline__ int wave_nms_scan(const uint64_t* mask, int nb, int n
   const int lane = threadIdx.x & 63;
   uint64_t rm0 = 0, rm1 = 0, rm2 = 0, rm3 = 0;  // removed bits of words lane, lane+64, lane+128, lane+192
   int count = 0;
+  // The chain per 64-box chunk is: diagonal word of the 64 rows -> in-register greedy resolve -> rows of the kept boxes
+  // OR-ed into the removed set -> next chunk.  Two memory latencies per chunk would sit on that chain; the diagonal
+  // word of the NEXT chunk does not depend on anything computed here, so it is fetched one chunk ahead, and the rows
+  // of up to four kept boxes are requested together before any of them is consumed.
+  uint64_t d_next = (lane < n) ? mask[(size_t)lane * nb] : 0ull;
   for (int c = 0; c < nb && c * 64 < n && count < max_keep; ++c) {
     const int i = c * 64 + lane;
-    const uint64_t d = (i < n) ? mask[(size_t)i * nb + c] : 0ull;
+    const uint64_t d = d_next;
+    {
+      const int in = i + 64;
+      d_next = (c + 1 < nb && in < n) ? mask[(size_t)in * nb + (c + 1)] : 0ull;
+    }
     const int slot = c >> 6;
     const uint64_t mine = slot == 0 ? rm0 : slot == 1 ? rm1 : slot == 2 ? rm2 : rm3;
     const uint64_t rw = readlane_u64(mine, c & 63);
@@ -132,17 +141,28 @@ __device__ __forceinline__ int wave_nms_scan(const uint64_t* mask, int nb, int n
     if (count >= max_keep) break;
     uint64_t todo = kept;
     while (todo != 0) {
-      const int b = __builtin_ctzll(todo);
-      todo &= todo - 1ull;
-      const uint64_t* row = mask + (size_t)(c * 64 + b) * nb;
-      int w = lane;
-      if (w > c && w < nb) rm0 |= row[w];
-      w += 64;
-      if (w > c && w < nb) rm1 |= row[w];
-      w += 64;
-      if (w > c && w < nb) rm2 |= row[w];
-      w += 64;
-      if (w > c && w < nb) rm3 |= row[w];
+      const uint64_t* rows[4];
+      int nr = 0;
+      for (; nr < 4 && todo != 0; ++nr) {
+        rows[nr] = mask + (size_t)(c * 64 + __builtin_ctzll(todo)) * nb;
+        todo &= todo - 1ull;
+      }
+      for (int q = nr; q < 4; ++q) rows[q] = rows[0];      // duplicates: OR is idempotent
+      uint64_t v[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int w = lane + 64 * s4;
+          v[q][s4] = (w > c && w < nb) ? rows[q][w] : 0ull;
+        }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        rm0 |= v[q][0];
+        rm1 |= v[q][1];
+        rm2 |= v[q][2];
+        rm3 |= v[q][3];
+      }
     }
   }
   return count;
