@@ -221,6 +221,46 @@ class Network(nn.Module):
         p['rois_count'] = torch.full((1,), rois.shape[0], dtype=torch.int32, device=rois.device)
         return rois
 
+    # ------------------------------------------------------------------------------------------
+    # ancestor-named layer methods (the reconstructed method set of the missing network.py): thin
+    # reference-shaped calls into the same device layers the fused pipeline above uses
+    # ------------------------------------------------------------------------------------------
+    def _proposal_layer(self, rpn_cls_prob, rpn_bbox_pred):
+        """rpn_cls_prob (1,H,W,2A) fg half last, rpn_bbox_pred (1,H,W,4A) -> (rois (n,5), rpn_scores (n,1))."""
+        from ..layer_utils.proposal_layer import proposal_layer
+        rois, scores, a3 = proposal_layer(rpn_cls_prob, rpn_bbox_pred, self._info, self._mode, self._anchors,
+                                          self._anchors_3d, self._num_anchors)
+        if a3 is not None:
+            self._predictions['roi_anchors_3d'] = a3
+        return rois, scores
+
+    def _proposal_top_layer(self, rpn_cls_prob, rpn_bbox_pred):
+        from ..layer_utils.proposal_top_layer import proposal_top_layer
+        rois, scores, _ = proposal_top_layer(rpn_cls_prob, rpn_bbox_pred, self._info, self._anchors, self._num_anchors)
+        return rois, scores
+
+    def _anchor_target_layer(self, rpn_cls_score):
+        """rpn_cls_score (1,2A,H,W) only supplies the map size, as in the ancestor.  Fills self._anchor_targets."""
+        from ..layer_utils.anchor_target_layer import anchor_target_layer_torch
+        h, w = rpn_cls_score.shape[2], rpn_cls_score.shape[3]
+        out = anchor_target_layer_torch(self._gt_boxes, None, self._info, self._anchors, self._num_anchors, h, w)
+        self._anchor_targets = dict(zip(('rpn_labels', 'rpn_bbox_targets', 'rpn_bbox_inside_weights',
+                                         'rpn_bbox_outside_weights'), out))
+        return out[0]
+
+    def _proposal_target_layer(self, rois, roi_scores):
+        """Returns (rois, roi_scores) of the sampled rows; the targets go to self._proposal_targets."""
+        from ..layer_utils.proposal_target_layer import proposal_target_layer
+        lidar = cfg.NET_TYPE == 'lidar'
+        labels, rois_s, a3, scores_s, tgt, inw, outw = proposal_target_layer(
+            rois, roi_scores, self._predictions.get('roi_anchors_3d') if lidar else None, self._gt_boxes,
+            getattr(self, '_true_gt_boxes', None) if lidar else None, None, self._num_classes, self._bbox_elem())
+        self._proposal_targets = {'rois': rois_s, 'labels': labels.view(-1), 'targets': tgt, 'inside': inw, 'outside': outw}
+        if lidar:
+            self._proposal_targets['anchors_3d'] = a3
+            self._predictions['roi_anchors_3d'] = a3
+        return rois_s, scores_s
+
     def _pyramid_scales(self):
         """MultiScaleRoIAlign.infer_scale (lib/utils/torchpoolers.py:107-117): 2 ** round(log2(feat / image))."""
         img_h = float(self._image.shape[2])
@@ -242,6 +282,8 @@ class Network(nn.Module):
             pooled = ops.roi_align_nhwc(to_nhwc(bottom), rois, cfg.POOLING_SIZE, 1.0 / self._feat_stride,
                                         ROI_ALIGN_SAMPLING_RATIO, roi_count=self._predictions.get('rois_count'))
         return to_nchw_view(pooled)
+
+    _roi_align_layer = _crop_pool_layer   # ancestor name of the same step
 
     def _layer4(self, pool5_nhwc):
         return self.resnet.layer4(pool5_nhwc)

@@ -1295,6 +1295,36 @@ def test_test_net_eval_loop_on_device(hip, tmp_path):
     C.reset_cfg()
 
 
+def test_network_ancestor_named_layer_methods(hip):
+    """The method set reconstructed for the missing network.py also exists under the ancestor's
+    per-layer names; they must reproduce what the fused pipeline computed for the same frame."""
+    net, _ = _build_pair(seed=31)
+    net.eval()
+    data, info, gt, _, _ = _fpn_case()
+    _, _, _, rois, _ = net.test_frame(data, info)
+    p = net._predictions
+    a = net._num_anchors
+    rpn = p["rpn_out"]                                              # (1,H,W,ld): [A bg | A fg | 4A deltas | pad]
+    h, w = rpn.shape[1], rpn.shape[2]
+    logits = rpn[..., :2 * a]
+    prob = torch.softmax(torch.stack((logits[..., :a], logits[..., a:]), 0), 0)
+    rpn_cls_prob = torch.cat((prob[0], prob[1]), -1).contiguous()  # (1,H,W,2A), fg half last
+    rpn_bbox_pred = rpn[..., 2 * a:6 * a].contiguous()
+    net._mode = "TEST"
+    rois2, scores2 = net._proposal_layer(rpn_cls_prob, rpn_bbox_pred)
+    assert rois2.shape == rois.shape
+    np.testing.assert_allclose(rois2.cpu().numpy(), rois.cpu().numpy(), rtol=0, atol=1e-4)
+    top, top_scores = net._proposal_top_layer(rpn_cls_prob, rpn_bbox_pred)
+    assert top.shape == (5000, 5) and top_scores.shape[0] == 5000
+    net._gt_boxes = torch.from_numpy(gt).to(DEV)
+    labels = net._anchor_target_layer(rpn[..., :2 * a].permute(0, 3, 1, 2))
+    assert labels.shape == (1, a, h, w) and int((labels >= 0).sum()) == 256
+    net._mode = "TRAIN"
+    rois_s, scores_s = net._proposal_target_layer(p["rois"][:int(p["rois_count"])], p["roi_scores"][:int(p["rois_count"])])
+    assert rois_s.shape == (256, 5) and net._proposal_targets["targets"].shape == (256, 8)
+    assert net._roi_align_layer(net._act_summaries["conv"].permute(0, 3, 1, 2), rois_s).shape == (256, 1024, 7, 7)
+
+
 def test_solver_loop_on_device(hip, tmp_path):
     """model/train_val.SolverWrapper (lib/model/train_val.py:296-503) driving the HIP network: gradients of every
     trainable filter accumulate inside the flat bucket (views, no copies), the optimizer steps every batch_size
