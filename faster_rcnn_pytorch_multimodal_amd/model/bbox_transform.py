@@ -8,7 +8,9 @@ from .. import ops
 
 
 def bbox_transform_inv(boxes, deltas, scales=None):
-    """boxes (N,4+) , deltas (N,4K) -> (N,4K).  lib/model/bbox_transform.py:75-105."""
+    """boxes (N,4+) , deltas (N,4K) -> (N,4K).  lib/model/bbox_transform.py:75-105 (no boxes: ``deltas * 0``, :79-80)."""
+    if len(boxes) == 0:
+        return deltas.detach() * 0
     return ops.bbox_transform_inv(boxes.contiguous(), deltas.contiguous(), scales)
 
 
@@ -21,4 +23,6 @@ def lidar_3d_bbox_transform_inv(rois, boxes, deltas, scales=None):
     """rois (N,4) axis-aligned BEV RoIs, boxes (N,7) their 3-D anchors, deltas (N,7K) -> (N,7K)
     [xc,yc,zc,l,w,h,ry].  lib/model/bbox_transform.py:174-233 (the reference also divides the anchors' x,y,l,w
     by ``scales`` in place, :177-178, but never reads them afterwards; that side effect is not reproduced)."""
+    if len(boxes) == 0:                      # :181-182
+        return deltas.detach() * 0
     return ops.lidar_bbox_transform_inv(rois.contiguous(), boxes.contiguous(), deltas.contiguous(), scales)

@@ -449,6 +449,11 @@ def test_empty_and_degenerate_inputs(hip):
     # 4. all scores tied and fewer candidates than top-n: order = index order, count = n
     order, sorted_scores, count = ops.sort_topk_desc(torch.full((37,), 0.5).to(DEV), 6000)
     assert count.item() == 37 and order.cpu().tolist() == list(range(37))
+    # 4b. no boxes: the codec returns deltas * 0 like the reference (bbox_transform.py:79-80,181-182)
+    from faster_rcnn_pytorch_multimodal_amd.model.bbox_transform import bbox_transform_inv, lidar_3d_bbox_transform_inv
+    assert bbox_transform_inv(torch.zeros(0, 4, device=DEV), torch.zeros(0, 8, device=DEV)).shape == (0, 8)
+    assert lidar_3d_bbox_transform_inv(torch.zeros(0, 4, device=DEV), torch.zeros(0, 7, device=DEV),
+                                       torch.zeros(0, 14, device=DEV)).shape == (0, 14)
     # 5. a point cloud entirely outside the range: all-zero blob of the right shape
     C.cfg.NET_TYPE = "lidar"
     pts = np.array([[-5.0, 0, 0, 1], [80.0, 0, 0, 1], [10.0, 50.0, 0, 1], [10.0, 0, 9.0, 1]], np.float32)
