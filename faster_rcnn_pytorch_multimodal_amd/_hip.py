@@ -32,6 +32,7 @@ PROTOTYPES = {
     "frcnn_conv2d_bwd_weight_ws_bytes": (c_size_t, [c_int] * 9),
     "frcnn_conv2d_bwd_weight": (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
     "frcnn_maxpool3x3s2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "frcnn_maxpool3x3s2_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "frcnn_pad_channels": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
     "frcnn_prep_image_out_size": (c_int, [c_int, c_int, c_float, POINTER(c_int), POINTER(c_int)]),
     "frcnn_prep_image": (c_int, [_P, c_int, c_int, c_float, POINTER(c_double), POINTER(c_double), POINTER(c_int), c_int, _P,

@@ -1024,6 +1024,57 @@ extern "C" int frcnn_maxpool3x3s2_fwd(const float* x, float* y, int n, int h, in
   return frcnn::check_launch("maxpool3x3s2_nhwc");
 }
 
+// Backward of the 3x3/2 max-pool (autograd of nn.MaxPool2d in the trainable stem, cfg.RESNET.FIXED_BLOCKS == -1):
+// gather form, deterministic.  An input pixel lies in at most 2 x 2 windows; it receives dy of a window when it is that
+// window's FIRST maximum in row-major scan order (the index torch's forward stores).
+namespace {
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_nhwc(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ dx, int N, int H, int W, int C4, int Ho,
+                                                            int Wo) {
+  const size_t total = (size_t)N * H * W * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    size_t pix = i / C4;
+    const int w = (int)(pix % W);
+    pix /= W;
+    const int h = (int)(pix % H);
+    const int n = (int)(pix / H);
+    const f32x4 me = *reinterpret_cast<const f32x4*>(x + i * 4);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    for (int ho = max(0, (h - 1 + 1) / 2); ho <= min(Ho - 1, (h + 1) / 2); ++ho)
+      for (int wo = max(0, (w - 1 + 1) / 2); wo <= min(Wo - 1, (w + 1) / 2); ++wo) {
+        // is (h, w) the first maximum of window (ho, wo)?  earlier = strictly before in row-major order
+        bool first[4] = {true, true, true, true};
+        for (int dyy = 0; dyy < 3; ++dyy) {
+          const int hi = ho * 2 - 1 + dyy;
+          if ((unsigned)hi >= (unsigned)H) continue;
+          for (int dxx = 0; dxx < 3; ++dxx) {
+            const int wi = wo * 2 - 1 + dxx;
+            if ((unsigned)wi >= (unsigned)W || (hi == h && wi == w)) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + hi) * W + wi) * C4 * 4 + c4 * 4);
+            const bool earlier = hi < h || (hi == h && wi < w);
+            for (int e = 0; e < 4; ++e) first[e] = first[e] && (earlier ? v[e] < me[e] : v[e] <= me[e]);
+          }
+        }
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + ((((size_t)n * Ho + ho) * Wo + wo) * C4 + c4) * 4);
+        for (int e = 0; e < 4; ++e) g[e] += first[e] ? d[e] : 0.f;
+      }
+    *reinterpret_cast<f32x4*>(dx + i * 4) = g;
+  }
+}
+}  // namespace
+
+extern "C" int frcnn_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int n, int h, int w, int c,
+                                      void* stream_) {
+  FRCNN_REQUIRE(x && dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "maxpool3x3s2_bwd: bad arguments (c%%4==0)");
+  const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  const size_t total = (size_t)n * h * w * (c / 4);
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048 * 4);
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_nhwc, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), x, dy, dx, n, h,
+                     w, c / 4, ho, wo);
+  return frcnn::check_launch("maxpool3x3s2_bwd_nhwc");
+}
+
 extern "C" int frcnn_pad_channels(const float* x, float* y, int64_t pixels, int c, int c_pad, void* stream_) {
   FRCNN_REQUIRE(x && y && pixels > 0 && c > 0 && c_pad >= c, "pad_channels: bad arguments");
   const size_t total = (size_t)pixels * c_pad;

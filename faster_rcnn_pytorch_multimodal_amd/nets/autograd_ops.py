@@ -387,6 +387,24 @@ def bottleneck_train(x, block):
     return _BottleneckFn.apply(x, block, block.batchnorm_en, *weights)
 
 
+class _MaxPoolFn(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, 1) of the stem (lib/nets/resnet.py:156) when the stem trains (FIXED_BLOCKS == -1)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.maxpool3x3s2_nhwc(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool3x3s2_bwd(x, dy.contiguous())
+
+
+def maxpool_train(x):
+    return _MaxPoolFn.apply(x)
+
+
 class _UpsampleAddFn(torch.autograd.Function):
     """lib/nets/fpn.py:42-45."""
 

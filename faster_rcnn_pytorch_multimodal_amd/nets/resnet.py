@@ -59,6 +59,10 @@ class Stem(nn.Module):
         self.conv1, self.bn1, self.maxpool = conv1, bn1, maxpool
 
     def forward(self, x):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in list(self.conv1.parameters()) + list(self.bn1.parameters())):
+            # cfg.RESNET.FIXED_BLOCKS == -1: the stem trains too (conv1 filter, bn1 on batch statistics)
+            from .autograd_ops import conv_bn_act_train, maxpool_train
+            return maxpool_train(conv_bn_act_train(x, self.conv1, self.bn1, relu=True))
         return self.maxpool(conv_bn_act(x, self.conv1, self.bn1, relu=True))
 
 

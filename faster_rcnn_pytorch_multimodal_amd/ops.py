@@ -166,6 +166,18 @@ def maxpool3x3s2_nhwc(x):
     return out
 
 
+def maxpool3x3s2_bwd(x, dy):
+    """Backward of maxpool3x3s2_nhwc: x (N,H,W,C) the pooled input, dy (N,Ho,Wo,C) -> dx like x."""
+    lib = _hip.load()
+    _dev_f32(x, "x"); _dev_f32(dy, "dy")
+    n, h, w, c = x.shape
+    if tuple(dy.shape) != (n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c):
+        raise _hip.HipError("maxpool3x3s2_bwd: dy %s does not match x %s" % (tuple(dy.shape), tuple(x.shape)))
+    dx = torch.empty_like(x)
+    _hip.check(lib.frcnn_maxpool3x3s2_bwd(_ptr(x), _ptr(dy), _ptr(dx), n, h, w, c, _stream()), "frcnn_maxpool3x3s2_bwd")
+    return dx
+
+
 def pad_channels(x, c_pad):
     """(N,H,W,C) -> (N,H,W,c_pad) zero-padded channels."""
     lib = _hip.load()

@@ -94,6 +94,9 @@ int frcnn_conv2d_set_staging(int use_lds_dma);
 
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1)  (lib/nets/resnet.py:156), NHWC. */
 int frcnn_maxpool3x3s2_fwd(const float* x, float* y, int n, int h, int w, int c, void* stream);
+/* Its backward (trainable stem, cfg.RESNET.FIXED_BLOCKS == -1): dx (n,h,w,c) receives dy of every window whose first
+ * maximum (row-major scan, like the index torch stores) is that pixel; gather form, deterministic. */
+int frcnn_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int n, int h, int w, int c, void* stream);
 
 /* NHWC image/BEV blob (lib/roi_data_layer/minibatch.py:670 layout, (1,H,W,C)) -> NHWC with the channel
  * count padded with zeros to c_pad (multiple of 4) so the stem conv reads 16-byte pixels. */

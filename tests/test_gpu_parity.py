@@ -491,11 +491,13 @@ def test_resnet101_stages_against_reference_golden(hip, golden_dir):
         _close_feat(l4.mean(3).mean(2).numpy(), g[mode + "_layer4_mean"], mode + " layer4 mean", frac=3e-5)
 
 
-def _build_pair(seed=5, bn_mode="tame"):
+def _build_pair(seed=5, bn_mode="tame", fixed_blocks=None):
     from faster_rcnn_pytorch_multimodal_amd.model import config as C
     from faster_rcnn_pytorch_multimodal_amd.nets.imagenet import imagenet
     C.reset_cfg()
     C.cfg.NET_TYPE = "image"
+    if fixed_blocks is not None:
+        C.cfg.RESNET.FIXED_BLOCKS = fixed_blocks
     oracle = O.ImageNetOracle(num_classes=2)
     sd = O.seeded_state_dict(oracle, seed, bn_mode=bn_mode)
     oracle.load_state_dict(sd, strict=True)
@@ -773,6 +775,21 @@ def test_conv2d_backward_matches_autograd(hip, case):
 # ------------------------------------------------------------------------------------------------
 # other training-path kernels
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 37, 52, 8), (2, 8, 8, 64), (1, 1, 1, 4), (1, 300, 501, 4)])
+def test_maxpool3x3s2_bwd_matches_autograd(hip, shape):
+    """frcnn_maxpool3x3s2_bwd against torch-CPU autograd of F.max_pool2d(3, 2, 1), with ties (quantised values) so
+    the first-maximum rule is exercised."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randint(-3, 4, shape, generator=g).float()              # many ties inside every window
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    y = F.max_pool2d(xr, 3, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    got = ops.maxpool3x3s2_bwd(x.to(DEV), dy.permute(0, 2, 3, 1).contiguous().to(DEV))
+    np.testing.assert_allclose(got.cpu().numpy(), xr.grad.permute(0, 2, 3, 1).numpy(), rtol=0, atol=1e-6)
+
+
 def test_act_bwd(hip):
     ops = _ops()
     g = torch.Generator().manual_seed(2)
@@ -1593,6 +1610,73 @@ def test_bev_voxelize_matches_oracle(hip, scale, n, max_voxels, elong):
         assert int((ref[..., :12] != 0).sum()) <= 3000                         # ... and the voxel cap
     if elong is None:
         assert (got[..., 14] == 0).all()
+    C.reset_cfg()
+
+
+def _image_oracle_all_trainable(seed, dtype=torch.float32):
+    """ImageNetOracle configured like lib/nets/imagenet.py with cfg.RESNET.FIXED_BLOCKS == -1: conv1 stays frozen
+    (:96-99), every BatchNorm trains on batch statistics (:110-116,156-163), layer1..4 train."""
+    oracle = O.ImageNetOracle(num_classes=2)
+    oracle.load_state_dict(O.seeded_state_dict(oracle, seed, bn_mode="tame"), strict=True)
+    for p in oracle.parameters():
+        p.requires_grad = True
+    for p in oracle.resnet.conv1.parameters():
+        p.requires_grad = False
+    oracle.train()
+    if dtype == torch.float64:
+        oracle.double()
+    return oracle
+
+
+def test_image_train_step_all_blocks_trainable(hip):
+    """cfg.RESNET.FIXED_BLOCKS == -1 (lib/nets/imagenet.py:96-116,138-163): the stem's BatchNorm and every block train
+    with batch statistics, so the step needs the max-pool backward and the batch-norm kernels on all 104 BatchNorm
+    layers.  Losses against the fp32 oracle; the 321 parameter gradients against the fp64 oracle with the fp32
+    oracle's own distance as the yardstick (same criterion as the LiDAR step)."""
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    net, _ = _build_pair(seed=51, fixed_blocks=-1)
+    oracle = _image_oracle_all_trainable(51)
+    data, info, gt, rois, scores = _fpn_case()
+    gen = lambda: torch.Generator().manual_seed(3)
+    losses, d = oracle.train_forward(data, info, gt, generator=gen(), proposals=(rois, scores))
+    losses["total_loss"].backward()
+    net.train()
+    assert net.resnet.bn1.training and net.resnet.layer1[0].bn1.training and not net.resnet.conv1.weight.requires_grad
+    net._target_override = {
+        "anchor": tuple(d[k].contiguous().to(DEV) for k in ("anchor_labels", "anchor_targets", "anchor_inside", "anchor_outside")),
+        "proposal": {k: d[k].contiguous().to(DEV) for k in ("rois", "labels", "targets", "inside", "outside")}}
+    net.zero_grad()
+    net.forward(data, info, gt, None, mode="TRAIN")
+    got = {k: float(v.item()) for k, v in net._losses.items()}
+    for k, v in losses.items():
+        assert abs(got[k] - float(v.item())) <= 5e-4 * max(1.0, abs(float(v.item()))), (k, got[k], float(v.item()))
+    net.backward(net._losses["total_loss"])
+    o64 = _image_oracle_all_trainable(51, torch.float64)
+    torch.set_default_dtype(torch.float64)
+    try:
+        l64, _ = o64.train_forward(data.astype(np.float64), info, gt, generator=gen(), proposals=(rois.double(), scores.double()))
+    finally:
+        torch.set_default_dtype(torch.float32)
+    l64["total_loss"].backward()
+    own, ref32, ref64 = dict(net.named_parameters()), dict(oracle.named_parameters()), dict(o64.named_parameters())
+    noise, mine, checked = [], [], 0
+    for name, p64 in ref64.items():
+        if not p64.requires_grad or p64.grad is None:
+            assert own[name].grad is None or float(own[name].grad.abs().max()) == 0.0, name
+            continue
+        g64 = p64.grad.numpy()
+        base = np.sqrt((g64 ** 2).sum()) + 1e-30
+        noise.append(np.sqrt(((ref32[name].grad.numpy().astype(np.float64) - g64) ** 2).sum()) / base)
+        mine.append(np.sqrt(((own[name].grad.cpu().numpy().astype(np.float64) - g64) ** 2).sum()) / base)
+        checked += 1
+    noise, mine = np.sort(noise), np.sort(mine)
+    print("all-trainable image step: %d gradients; device median %.2e worst %.2e | fp32 oracle median %.2e worst %.2e"
+          % (checked, np.median(mine), mine[-1], np.median(noise), noise[-1]))
+    # 103 conv filters (conv1 frozen) + 104 BatchNorms x (weight, bias) + RPN 6 + heads 4
+    assert checked == 103 + 208 + 10 and np.median(mine) <= 1.5 * np.median(noise) + 1e-4
+    assert mine[-1] <= max(2.0 * noise[-1], 5e-3) and mine[-1] <= 0.1
+    np.testing.assert_allclose(net.resnet.bn1.running_mean.cpu().numpy(), oracle.resnet.bn1.running_mean.numpy(),
+                               rtol=2e-4, atol=1e-5)
     C.reset_cfg()
 
 
