@@ -68,6 +68,19 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   return base + (b >> 3);
 }
 
+// Logical tile -> (tile_m, tile_n).  Tiles are walked in column groups of RASTER_GN n-tiles (m fastest inside a
+// group): the tiles an XCD works on concurrently (a contiguous range of this order, see xcd_remap) then share at most
+// RASTER_GN filter column blocks, so the filter slice they re-read stays inside the XCD's 4 MB L2 instead of the whole
+// K x C filter cycling through it once per pixel row.
+constexpr int RASTER_GN = 8;
+__device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
+  const int per_group = RASTER_GN * tiles_m;
+  const int group = tile / per_group, within = tile - group * per_group;
+  const int gn = min(RASTER_GN, tiles_n - group * RASTER_GN);
+  tile_n = group * RASTER_GN + within % gn;
+  tile_m = within / gn;
+}
+
 // Epilogue shared by the conv kernels.  The MFMA operands are (weights, activations), so D has the PIXEL on the
 // lane (col = lane&31) and the CHANNEL in the registers: row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Registers
 // 4g..4g+3 are four consecutive channels -> every access is a 16-byte vector per lane, and all residual loads of a
@@ -164,7 +177,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
 
   const int ntiles = p.tiles_m * p.tiles_n;
   const int tile = xcd_remap(blockIdx.x, ntiles);
-  const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
+  int tile_m, tile_n;
+  tile_coords(tile, p.tiles_m, p.tiles_n, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int step_begin = blockIdx.z * p.steps_per_split;
@@ -334,7 +348,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_f32(const ConvParams p)
   const int wr = wave / WN, wc = wave % WN;
   const int ntiles = p.tiles_m * p.tiles_n;
   const int tile = xcd_remap(blockIdx.x, ntiles);
-  const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
+  int tile_m, tile_n;
+  tile_coords(tile, p.tiles_m, p.tiles_n, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int step_begin = blockIdx.z * p.steps_per_split;
   const int step_end = min(step_begin + p.steps_per_split, p.ksteps);
