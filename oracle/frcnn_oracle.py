@@ -7,12 +7,14 @@ mathild7/faster_rcnn_pytorch_multimodal.  Only ``tests/``, ``__graft_entry__.smo
 
 Pinning status:
   * pinned by golden vectors generated from the importable reference modules
-    (tests/golden/make_golden.py): generate_anchors / generate_anchors_pre, bbox_transform(_inv),
-    clip_boxes, ResNet-101 stage outputs, bbox_overlaps;
+    (tests/golden/make_golden.py, make_golden_lidar_train.py, make_golden_eval.py): generate_anchors /
+    generate_anchors_pre, bbox_transform(_inv), clip_boxes, ResNet-101 stage outputs, bbox_overlaps, the 3-D anchor
+    grid and bbaa_graphics_gems, the LiDAR codec, proposal_top_layer, anchor / proposal target layers (image and
+    LiDAR), huber / smooth-L1 (RPN, DET, LiDAR-DET, aleatoric), the MC statistics, voc_eval;
   * PARITY UNPINNED: nms and roi_align restate the documented semantics of torchvision==0.4.0
-    (req.txt:283), which is neither vendored in the reference nor installed here, and the reference has
-    no tests for them; the Network pipeline restates the RECONSTRUCTED contract of the missing
-    lib/nets/network.py.
+    (req.txt:283), prep_im_for_blob restates cv2.resize, points_to_voxel restates spconv's voxel generator - none
+    of them is vendored in the reference or installed here, and the reference has no tests for them; the Network
+    pipeline restates the RECONSTRUCTED contract of the missing lib/nets/network.py.
 
 Every function cites the reference file:line it follows (paths relative to the reference root).
 """
