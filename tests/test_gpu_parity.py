@@ -591,6 +591,29 @@ def test_full_size_frame_properties(hip):
     assert torch.equal(dets, dets2) and torch.equal(counts, counts2)
 
 
+def test_full_size_linearity_properties(hip):
+    """BASELINE-size operands, size-independent properties: the convolution (layer4 3x3 on 300 RoIs, 69 GFLOP) and
+    RoIAlign (300 x 7 x 7 x 1024) are linear in their input, and RoIAlign of a constant map is that constant
+    wherever the RoI lies inside the map."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(123)
+    x1 = torch.randn(300, 7, 7, 512, generator=g).to(DEV)
+    x2 = torch.randn(300, 7, 7, 512, generator=g).to(DEV)
+    w = (torch.randn(512, 3, 3, 512, generator=g) * 0.02).to(DEV)
+    y = ops.conv2d_nhwc((0.5 * x1 - 2.0 * x2).contiguous(), w, stride=1, pad=1)
+    y_lin = 0.5 * ops.conv2d_nhwc(x1, w, stride=1, pad=1) - 2.0 * ops.conv2d_nhwc(x2, w, stride=1, pad=1)
+    assert float((y - y_lin).abs().max()) <= 2e-5 * float(y_lin.abs().max())
+    f1 = torch.randn(1, 38, 63, 1024, generator=g).to(DEV)
+    f2 = torch.randn(1, 38, 63, 1024, generator=g).to(DEV)
+    rois = torch.cat((torch.zeros(300, 1), _rand_boxes(300, g)), 1).to(DEV)
+    r = ops.roi_align_nhwc((3.0 * f1 + f2).contiguous(), rois, 7, 1 / 16.0, 0)
+    r_lin = 3.0 * ops.roi_align_nhwc(f1, rois, 7, 1 / 16.0, 0) + ops.roi_align_nhwc(f2, rois, 7, 1 / 16.0, 0)
+    assert float((r - r_lin).abs().max()) <= 1e-5 * float(r_lin.abs().max())
+    inside = torch.tensor([[0., 100, 100, 500, 400], [0, 16, 16, 900, 560]]).to(DEV)
+    const = ops.roi_align_nhwc(torch.full((1, 38, 63, 64), 2.5, device=DEV), inside, 7, 1 / 16.0, 0)
+    np.testing.assert_allclose(const.cpu().numpy(), 2.5, rtol=0, atol=1e-5)
+
+
 # ------------------------------------------------------------------------------------------------
 # LiDAR-BEV variant (BASELINE config 3)
 # ------------------------------------------------------------------------------------------------
