@@ -556,6 +556,41 @@ def test_detector_stagewise_against_oracle(hip):
         float((cp[:min(len(cp), len(cp_r))].cpu() - cp_r[:min(len(cp), len(cp_r))]).abs().max())))
 
 
+@pytest.mark.parametrize("num_layers", [50, 152])
+def test_other_backbone_depths_against_oracle(hip, num_layers):
+    """imagenet(num_layers=50 / 152) (lib/nets/resnet.py:275-292, `--net res50 / res152` of the reference's CLIs): same
+    code path with other block counts; backbone features, proposal indices and detections against the oracle."""
+    from faster_rcnn_pytorch_multimodal_amd.layer_utils.proposal_layer import proposal_layer_device
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.nets.imagenet import imagenet
+    C.reset_cfg()
+    C.cfg.NET_TYPE = "image"
+    oracle = O.ImageNetOracle(num_classes=2, num_layers=num_layers)
+    sd = O.seeded_state_dict(oracle, 60 + num_layers, bn_mode="tame")
+    oracle.load_state_dict(sd, strict=True)
+    net = imagenet(num_layers=num_layers)
+    net.create_architecture(2, tag="default", anchor_scales=C.cfg.ANCHOR_SCALES, anchor_ratios=C.cfg.ANCHOR_RATIOS)
+    assert set(net.state_dict().keys()) == set(sd.keys())
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    net._device = DEV
+    net.to(DEV)
+    data = (np.random.default_rng(num_layers).standard_normal((1, 128, 192, 3)) * 50).astype(np.float32)
+    info = np.array([0, 192, 0, 128, 0, 0, 1.0], np.float32)
+    _, cp_ref, pb_ref, rois_ref, _ = oracle.test_frame(data, info)
+    d = oracle._dbg
+    _, cp, pb, rois, _ = net.test_frame(data, info)
+    _close_feat(net._act_summaries["conv"].cpu().permute(0, 3, 1, 2).numpy(), d["net_conv"].numpy(), "net_conv", 5e-5)
+    a = 25
+    res = proposal_layer_device(d["anchors"].to(DEV), info, a, 6000, 300, 0.7,
+                                rpn_cls_prob_fg=d["rpn_cls_prob"][..., a:].contiguous().view(-1).to(DEV),
+                                rpn_bbox_pred=d["rpn_bbox_pred"].reshape(-1, 4).contiguous().to(DEV))
+    n = int(res.count.item())
+    assert n == rois_ref.shape[0] and torch.equal(res.order[res.keep_idx[:n]].cpu(), d["order"][d["keep"]])
+    assert cp.shape == cp_ref.shape and pb.shape == pb_ref.shape
+    C.reset_cfg()
+
+
 def test_full_size_frame_properties(hip):
     """1000x600 (BASELINE config 2): size-independent properties of the device pipeline."""
     from faster_rcnn_pytorch_multimodal_amd import ops
