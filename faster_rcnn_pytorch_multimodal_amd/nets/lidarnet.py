@@ -6,6 +6,7 @@ input planes (12 height slices + density + intensity + elongation, lib/roi_data_
 without FPN ``_batchnorm_en`` is False, so layer4 runs WITHOUT BatchNorm (lib/nets/resnet.py:163-164,103-118);
 every BatchNorm is trainable by default (``set_bn_var``, lidarnet.py:110) and blocks are frozen only up to
 cfg.RESNET.FIXED_BLOCKS; boxes are 7-DoF [xc,yc,zc,l,w,h,ry] decoded from the RoI and its 3-D anchor.
+With cfg.USE_FPN the backbone is the p2..p5 pyramid of the image detector (lidarnet.py:31-40,136-146).
 The 15-channel blob is zero-padded to 16 channels on the device so the stem conv reads 16-byte pixels.
 """
 import torch
@@ -13,6 +14,7 @@ import torch.nn as nn
 
 from ..model.config import cfg
 from ..utils.init_utils import normal_init, set_bn_eval, set_bn_fix, set_bn_train, set_bn_var
+from .fpn import fpn
 from .imagenet import _Head
 from .network import Network
 
@@ -20,13 +22,24 @@ from .network import Network
 class lidarnet(Network):
     def __init__(self, num_layers=50):
         Network.__init__(self)
-        if cfg.USE_FPN or cfg.USE_LIDAR_FPN:
-            raise NotImplementedError("FPN LiDAR detector is not on the HIP path")
-        self._feat_stride = 16
-        self._fpn_en = False
-        self._net_conv_channels = 1024
-        self._roi_pooling_channels = 1024
-        self._batchnorm_en = False
+        if cfg.USE_FPN:
+            # lidarnet.py:31-40: same pyramid as the image detector (p2..p5, 256 channels, RPN on p2 at stride 4,
+            # multi-scale pooling, custom tail); layer4 is part of the backbone and keeps its BatchNorm
+            if cfg.POOLING_MODE == 'multiscale':
+                self._feat_stride = 4
+            self._fpn_en = True
+            self._batchnorm_en = True
+            self._net_conv_channels = 256
+            self._roi_pooling_channels = cfg.POOLING_SIZE * cfg.POOLING_SIZE * self._net_conv_channels
+        elif cfg.USE_LIDAR_FPN:
+            raise NotImplementedError("cfg.USE_LIDAR_FPN (stride-8, 1024-channel pyramid, lidarnet.py:41-46) is not on "
+                                      "the HIP path; cfg.USE_FPN is")
+        else:
+            self._feat_stride = 16
+            self._fpn_en = False
+            self._net_conv_channels = 1024
+            self._roi_pooling_channels = 1024
+            self._batchnorm_en = False
         self._fc7_channels = 2048
         self.inplanes = 64
         self._num_resnet_layers = num_layers
@@ -42,6 +55,11 @@ class lidarnet(Network):
     def init_weights(self):
         # lidarnet.py:70-102
         normal_init(self.rpn_net, 0, 0.01, cfg.TRAIN.TRUNCATED)
+        if cfg.USE_FPN:
+            self._fpn.init()
+        if cfg.ENABLE_CUSTOM_TAIL:
+            for m in (self.t_fc1, self.t_fc2, self.t_fc3):
+                normal_init(m, 0, 0.01, cfg.TRAIN.TRUNCATED)
         normal_init(self.rpn_cls_score_net, 0, 0.01, cfg.TRAIN.TRUNCATED)
         normal_init(self.rpn_bbox_pred_net, 0, 0.01, cfg.TRAIN.TRUNCATED)
         normal_init(self.cls_score_net, 0, 0.01, cfg.TRAIN.TRUNCATED)
@@ -65,7 +83,15 @@ class lidarnet(Network):
         if cfg.RESNET.FIXED_BLOCKS >= 0:
             for p in list(self.resnet.bn1.parameters()) + list(self.resnet.conv1.parameters()):
                 p.requires_grad = False
-        self._layers['head'] = _Head(self.resnet)
+        if cfg.USE_FPN:
+            # lidarnet.py:136-146
+            self._fpn = fpn(planes=self._net_conv_channels)
+            self._layers['fpn'] = self._fpn
+            self._layers['head'] = self.resnet.stem()
+            for i in (1, 2, 3, 4):
+                self._layers['layer%d' % i] = getattr(self.resnet, 'layer%d' % i)
+        else:
+            self._layers['head'] = _Head(self.resnet)
 
     def train(self, mode=True):
         nn.Module.train(self, mode)

@@ -1211,6 +1211,102 @@ class FpnNetOracle(nn.Module):
 
 
 # ----------------------------------------------------------------------------------------------
+# LiDAR detector on the FPN backbone — lib/nets/lidarnet.py:31-40,136-146 (cfg.USE_FPN with NET_TYPE 'lidar'):
+# the image pyramid of FpnNetOracle with the 15-plane stem, the 3-D anchor grid on p2 (stride 4) and the 7-DoF heads.
+# RECONSTRUCTED like the other Network-level restatements.
+# ----------------------------------------------------------------------------------------------
+class LidarFpnNetOracle(FpnNetOracle):
+    def __init__(self, num_classes=2):
+        nn.Module.__init__(self)
+        self._num_classes = num_classes
+        self._num_anchors = len(LIDAR_ANCHOR_SCALES) * len(LIDAR_ANCHOR_ANGLES)
+        self._feat_stride = 4
+        self.resnet = ResNet101(in_channels=LIDAR_NUM_CHANNEL, use_fpn=True)      # layer4 keeps its BatchNorm (:38)
+        self._fpn = FPN(256)
+        a = self._num_anchors
+        self.rpn_net = nn.Conv2d(256, RPN_CHANNELS, 3, padding=1)
+        self.rpn_cls_score_net = nn.Conv2d(RPN_CHANNELS, 2 * a, 1)
+        self.rpn_bbox_pred_net = nn.Conv2d(RPN_CHANNELS, 4 * a, 1)
+        self.cls_score_net = nn.Linear(2048, num_classes)
+        self.bbox_pred_net = nn.Linear(2048, num_classes * LIDAR_NUM_BBOX_ELEM)
+        self.t_fc1 = nn.Linear(POOLING_SIZE * POOLING_SIZE * 256, 2048)
+        self.t_fc2 = nn.Linear(2048, 2048)
+        self.t_fc3 = nn.Linear(2048, 2048)
+        self.eval()
+
+    set_trainable = _lidar_set_trainable
+    train_mode = _lidar_train_mode
+
+    def _rpn(self, p2, info):
+        a = self._num_anchors
+        h, w = p2.shape[2], p2.shape[3]
+        _, a3 = generate_anchors_3d(h, w, self._feat_stride, frame_scale=float(info[6]))
+        anchors = torch.from_numpy(bbaa_graphics_gems(a3))
+        rpn = F.relu(self.rpn_net(p2))
+        cls_score = self.rpn_cls_score_net(rpn)
+        bbox_pred = self.rpn_bbox_pred_net(rpn).permute(0, 2, 3, 1).contiguous()
+        return a3, anchors, cls_score, bbox_pred
+
+    @torch.no_grad()
+    def test_frame(self, data, info):
+        image = torch.from_numpy(np.ascontiguousarray(data)).permute(0, 3, 1, 2).contiguous()
+        pyr = self.pyramid(image)
+        a = self._num_anchors
+        a3, anchors, cls_score, bbox_pred = self._rpn(pyr[0], info)
+        h, w = pyr[0].shape[2:]
+        prob = F.softmax(cls_score.view(1, 2, a * h, w), dim=1).view(1, 2 * a, h, w).permute(0, 2, 3, 1).contiguous()
+        rois, scores, dbg = proposal_layer(prob, bbox_pred, info, anchors, a, return_debug=True)
+        roi_a3 = torch.from_numpy(a3)[dbg["order"]][dbg["keep"]]
+        pool5, levels = self.pool(pyr, rois, image.shape[2:])
+        fc7 = self.tail(pool5)
+        cls_score_d, det_box = self.cls_score_net(fc7), self.bbox_pred_net(fc7)
+        cls_prob = F.softmax(cls_score_d, dim=1)
+        stds = torch.tensor(LIDAR_BBOX_NORMALIZE_STDS).repeat(self._num_classes).unsqueeze(0)
+        means = torch.tensor(LIDAR_BBOX_NORMALIZE_MEANS).repeat(self._num_classes).unsqueeze(0)
+        pred_boxes = lidar_3d_bbox_transform_inv(rois[:, 1:5], roi_a3, det_box.mul(stds).add(means), float(info[6]))
+        self._dbg = {"anchors": anchors, "anchors_3d": torch.from_numpy(a3), "roi_anchors_3d": roi_a3,
+                     "rpn_cls_prob": prob, "rpn_bbox_pred": bbox_pred, "pyramid": pyr, "pool5": pool5, "fc7": fc7,
+                     "levels": levels, "bbox_pred": det_box, **dbg}
+        return cls_score_d, cls_prob, pred_boxes, rois, {}
+
+    def train_forward(self, data, info, true_gt_boxes, generator=None, pre_nms=12000, post_nms=2000, proposals=None):
+        """TRAIN forward; ``proposals=(rois (N,5), scores (N,1), anchors_3d (N,7))`` replaces the proposal_layer output."""
+        image = torch.from_numpy(np.ascontiguousarray(data)).permute(0, 3, 1, 2).contiguous()
+        tgt3 = torch.as_tensor(true_gt_boxes, dtype=torch.float32)
+        gt = torch.cat((torch.from_numpy(bbaa_graphics_gems(tgt3[:, :7].numpy())), tgt3[:, 7:8]), 1)
+        pyr = self.pyramid(image)
+        a = self._num_anchors
+        a3, anchors, cls_score, bbox_pred = self._rpn(pyr[0], info)
+        h, w = pyr[0].shape[2:]
+        with torch.no_grad():
+            prob = F.softmax(cls_score.view(1, 2, a * h, w), dim=1).view(1, 2 * a, h, w).permute(0, 2, 3, 1).contiguous()
+            rois, scores, dbg = proposal_layer(prob, bbox_pred, info, anchors, a, pre_nms, post_nms, TEST_RPN_NMS_THRESH,
+                                               return_debug=True)
+            roi_a3 = torch.from_numpy(a3)[dbg["order"]][dbg["keep"]]
+            if proposals is not None:
+                rois, scores, roi_a3 = proposals
+            lab, tgt, inw, outw = anchor_target_layer(gt, info, anchors, a, h, w, generator=generator)
+            pl, prois, pa3, _, ptgt, pin, pout = proposal_target_layer(rois, scores, roi_a3, gt, tgt3, self._num_classes,
+                                                                       7, net_type="lidar", generator=generator)
+        logits = torch.stack((cls_score[0, :a].permute(1, 2, 0).reshape(-1), cls_score[0, a:].permute(1, 2, 0).reshape(-1)), 1)
+        labels_hwa = lab[0].permute(1, 2, 0).reshape(-1)
+        sel = labels_hwa >= 0
+        rpn_ce = F.cross_entropy(logits[sel], labels_hwa[sel].long())
+        rpn_box = smooth_l1_loss("RPN", bbox_pred, tgt, inw, outw, dim=(1, 2, 3))
+        pool5, levels = self.pool(pyr, prois, image.shape[2:])
+        fc7 = self.tail(pool5)
+        det_cls, det_box = self.cls_score_net(fc7), self.bbox_pred_net(fc7)
+        ce = F.cross_entropy(det_cls, pl.view(-1).long())
+        box = smooth_l1_loss("DET", det_box, ptgt, pin, pout, net_type="lidar")
+        losses = {"rpn_cross_entropy": rpn_ce, "rpn_loss_box": rpn_box, "cross_entropy": ce, "loss_box": box,
+                  "total_loss": rpn_ce + rpn_box + ce + box}
+        dbg = {"anchor_labels": labels_hwa, "anchor_targets": tgt.reshape(-1, 4), "anchor_inside": inw.reshape(-1, 4),
+               "anchor_outside": outw.reshape(-1, 4), "rois": prois, "anchors_3d": pa3, "labels": pl.view(-1),
+               "targets": ptgt, "inside": pin, "outside": pout, "levels": levels, "pyramid": pyr, "gt_aabb": gt}
+        return losses, dbg
+
+
+# ----------------------------------------------------------------------------------------------
 # prep_im_for_blob — lib/utils/blob.py:32-54.  cv2.resize(INTER_LINEAR) is restated from its documented
 # semantics (cv2 is neither vendored nor installed here: PARITY UNPINNED): dsize = round-half-even(size*scale),
 # source coordinate (dst+0.5)/scale - 0.5 in fp32, clamped taps, horizontal blend then vertical.

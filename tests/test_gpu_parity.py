@@ -748,6 +748,121 @@ def test_lidar_detector_stagewise_against_oracle(hip):
     C.reset_cfg()
 
 
+def _build_lidar_fpn_pair(seed=19):
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.nets.lidarnet import lidarnet
+    C.reset_cfg()
+    C.cfg.NET_TYPE = "lidar"
+    C.cfg.USE_FPN = True
+    C.cfg.POOLING_MODE = "multiscale"
+    C.cfg.ENABLE_CUSTOM_TAIL = True
+    oracle = O.LidarFpnNetOracle(num_classes=2)
+    sd = O.seeded_state_dict(oracle, seed, bn_mode="tame")
+    oracle.load_state_dict(sd, strict=True)
+    net = lidarnet(num_layers=101)
+    net.create_architecture(2, tag="default", anchor_scales=C.cfg.LIDAR.ANCHOR_SCALES[0],
+                            anchor_ratios=C.cfg.LIDAR.ANCHOR_ANGLES)
+    assert set(net.state_dict().keys()) == set(sd.keys())
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    net._device = DEV
+    net.to(DEV)
+    return net, oracle
+
+
+def test_lidar_fpn_detector_stagewise_against_oracle(hip):
+    """cfg.USE_FPN with the LiDAR detector (lib/nets/lidarnet.py:31-40,136-146): pyramid, 3-D anchors on p2 (stride 4),
+    proposal indices on the oracle's RPN outputs, multi-level pooling, custom tail and 7-DoF decode."""
+    from faster_rcnn_pytorch_multimodal_amd import ops
+    from faster_rcnn_pytorch_multimodal_amd.layer_utils.proposal_layer import proposal_layer
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    net, oracle = _build_lidar_fpn_pair()
+    data = _bev_blob(208, 176, 5)
+    info = np.array([0, 176, 0, 208, 0, 12, 0.5], np.float32)
+    cs_r, cp_r, pb_r, rois_r, _ = oracle.test_frame(data, info)
+    d = oracle._dbg
+    cs, cp, pb, rois, _ = net.test_frame(data, info)
+    assert net._feat_stride == 4 and pb.shape[1] == 14 and net.resnet.conv1.weight.shape[1] == 15
+    for lvl, (mine, ref) in enumerate(zip(net._pyramid, d["pyramid"])):
+        _close_feat(mine.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), "p%d" % (lvl + 2), 1e-4)
+    np.testing.assert_array_equal(net._anchors_3d.cpu().numpy(), d["anchors_3d"].numpy())
+    np.testing.assert_array_equal(net._anchors.cpu().numpy(), d["anchors"].numpy())
+    blob, scores, a3 = proposal_layer(d["rpn_cls_prob"].to(DEV), d["rpn_bbox_pred"].to(DEV), info, "TEST",
+                                      d["anchors"].to(DEV), d["anchors_3d"].to(DEV), 2)
+    assert blob.shape[0] == rois_r.shape[0]
+    np.testing.assert_allclose(blob.cpu().numpy(), rois_r.numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_array_equal(a3.cpu().numpy(), d["roi_anchors_3d"].numpy())
+    # pooling + tail + decode on the oracle's pyramid / rois / anchors
+    with torch.no_grad():
+        net._pyramid = [f.permute(0, 2, 3, 1).contiguous().to(DEV) for f in d["pyramid"]]
+        net._frame_scale = 0.5
+        net._predictions = {"roi_anchors_3d": d["roi_anchors_3d"].contiguous().to(DEV), "rois": rois_r.contiguous().to(DEV)}
+        pooled = net._crop_pool_layer(None, rois_r.contiguous().to(DEV))
+        np.testing.assert_array_equal(net._predictions["roi_levels"].cpu().numpy(), d["levels"].numpy())
+        _close_feat(pooled.cpu().numpy(), d["pool5"].numpy(), "pool5", 2e-5)
+        fc7 = net._head_to_tail(pooled)
+        _close_feat(fc7.cpu().numpy(), d["fc7"].numpy(), "fc7", 5e-5)
+        cls_prob, bbox_pred = net._region_classification(fc7)
+    np.testing.assert_allclose(cls_prob.cpu().numpy(), cp_r.numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(net._predictions["pred_boxes"].cpu().numpy(), pb_r.numpy(), rtol=1e-4, atol=2e-3)
+    C.reset_cfg()
+
+
+def test_lidar_fpn_train_step_matches_oracle_autograd(hip):
+    """LiDAR detector on the FPN backbone, FIXED_BLOCKS = 1: layer2..4 BatchNorm on batch statistics (layer4 is part of
+    the backbone here and keeps its BatchNorm), pyramid + multi-level RoIAlign backward, 7-element targets and the
+    sin(ry) loss.  Losses vs the fp32 oracle, gradients vs the fp64 oracle with the fp32 oracle's distance as yardstick."""
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    net, oracle = _build_lidar_fpn_pair(seed=43)
+    oracle.set_trainable(1)
+    oracle.train_mode(1)
+    data, info, gt, rois, scores, roi_a3 = _lidar_train_case(oracle)
+    gen = lambda: torch.Generator().manual_seed(3)
+    losses, d = oracle.train_forward(data, info, gt, generator=gen(), proposals=(rois, scores, roi_a3))
+    losses["total_loss"].backward()
+    assert int((d["labels"] > 0).sum()) >= 20
+    net.train()
+    assert net.resnet.layer4[0].bn1.training and net.resnet.layer2[0].bn1.training and not net.resnet.layer1[0].bn1.training
+    net._target_override = {
+        "anchor": tuple(d[k].contiguous().to(DEV) for k in ("anchor_labels", "anchor_targets", "anchor_inside", "anchor_outside")),
+        "proposal": {k: d[k].contiguous().to(DEV) for k in ("rois", "labels", "targets", "inside", "outside", "anchors_3d")}}
+    net.zero_grad()
+    net.forward(data, info, gt, None, mode="TRAIN")
+    got = {k: float(v.item()) for k, v in net._losses.items()}
+    for k, v in losses.items():
+        assert abs(got[k] - float(v.item())) <= 5e-4 * max(1.0, abs(float(v.item()))), (k, got[k], float(v.item()))
+    net.backward(net._losses["total_loss"])
+    o64 = O.LidarFpnNetOracle(num_classes=2)
+    o64.load_state_dict(O.seeded_state_dict(o64, 43, bn_mode="tame"), strict=True)
+    o64.set_trainable(1)
+    o64.train_mode(1)
+    o64.double()
+    torch.set_default_dtype(torch.float64)
+    try:
+        l64, _ = o64.train_forward(data.astype(np.float64), info, gt, generator=gen(),
+                                   proposals=(rois.double(), scores.double(), roi_a3.double()))
+    finally:
+        torch.set_default_dtype(torch.float32)
+    l64["total_loss"].backward()
+    own, ref32 = dict(net.named_parameters()), dict(oracle.named_parameters())
+    noise, mine = [], []
+    for name, p64 in o64.named_parameters():
+        if not p64.requires_grad or p64.grad is None:
+            assert own[name].grad is None or float(own[name].grad.abs().max()) == 0.0, name
+            continue
+        g64 = p64.grad.numpy()
+        base = np.sqrt((g64 ** 2).sum()) + 1e-30
+        noise.append(np.sqrt(((ref32[name].grad.numpy().astype(np.float64) - g64) ** 2).sum()) / base)
+        mine.append(np.sqrt(((own[name].grad.cpu().numpy().astype(np.float64) - g64) ** 2).sum()) / base)
+    noise, mine = np.sort(noise), np.sort(mine)
+    print("lidar fpn step: %d gradients; device median %.2e worst %.2e | fp32 oracle median %.2e worst %.2e"
+          % (len(mine), np.median(mine), mine[-1], np.median(noise), noise[-1]))
+    # layer2..4: 93 filters + 93 BatchNorms x 2; FPN 12; RPN 6; heads 4; tail 6
+    assert len(mine) == 93 + 186 + 12 + 6 + 4 + 6
+    assert np.median(mine) <= 1.5 * np.median(noise) + 1e-4 and mine[-1] <= max(2.0 * noise[-1], 5e-3) and mine[-1] <= 0.1
+    C.reset_cfg()
+
+
 @pytest.mark.parametrize("thresh,max_dets", [(0.1, 100), (0.5, 30)])
 def test_filter_per_class_lidar_matches_oracle(hip, thresh, max_dets):
     ops = _ops()
