@@ -10,6 +10,8 @@ LiDAR (NET_TYPE 'lidar', :142-154,239-243): overlaps on the BEV rectangles, ``li
 the 8-column ``true_gt_boxes`` and each RoI's 3-D anchor, normalised by cfg.TRAIN.LIDAR.BBOX_NORMALIZE_*, 7-of-7K
 layout; the sampled rows' 3-D anchors are returned as well.
 """
+import torch
+
 from .. import ops
 from ..model.config import cfg
 from .anchor_target_layer import _draw_seed
@@ -17,9 +19,22 @@ from .anchor_target_layer import _draw_seed
 
 def proposal_target_layer_device(rpn_rois, rpn_scores, gt_boxes, num_classes, roi_count=None, seed=None,
                                  anchors_3d=None, true_gt_boxes=None):
-    if cfg.TRAIN.USE_GT or cfg.TRAIN.IGNORE_DC:
-        raise NotImplementedError("TRAIN.USE_GT / TRAIN.IGNORE_DC are not on the HIP path")
+    if cfg.TRAIN.IGNORE_DC:
+        raise NotImplementedError("TRAIN.IGNORE_DC is not on the HIP path")
     scores = None if rpn_scores is None else rpn_scores.contiguous().view(-1)
+    if cfg.TRAIN.USE_GT:
+        # proposal_target_layer.py:31-37: the gt boxes join the candidates (score 0; LiDAR: the 3-D gt box is its own
+        # "anchor").  They go in FRONT of the proposals so that the device-side count of live rows still describes a
+        # prefix; the sampling is random, so the position of a candidate carries no meaning.
+        g = gt_boxes.shape[0]
+        gt_rois = torch.cat((gt_boxes.new_zeros(g, 1), gt_boxes[:, :4]), 1)
+        rpn_rois = torch.cat((gt_rois, rpn_rois), 0)
+        if scores is not None:
+            scores = torch.cat((scores.new_zeros(g), scores), 0)
+        if roi_count is not None:
+            roi_count = (roi_count.to(torch.int32) + g).to(torch.int32)
+        if anchors_3d is not None:
+            anchors_3d = torch.cat((true_gt_boxes[:, :7], anchors_3d), 0)
     if anchors_3d is not None:
         return ops.proposal_target_layer(rpn_rois.contiguous(), scores, gt_boxes[:, :5].contiguous(), num_classes,
                                          cfg.TRAIN.ROI_BATCH_SIZE, cfg.TRAIN.FG_FRACTION, cfg.TRAIN.FG_THRESH,

@@ -1221,6 +1221,33 @@ def test_uncertainty_statistics_and_aleatoric_loss_against_reference_golden(hip,
     np.testing.assert_allclose(dvar.cpu().numpy(), z["sl1_al_dvar"], rtol=1e-5, atol=1e-8)
 
 
+def test_proposal_target_layer_use_gt(hip):
+    """cfg.TRAIN.USE_GT (proposal_target_layer.py:31-37): the gt boxes join the candidates.  With proposals that all
+    miss the objects the only foreground rows are the gt boxes themselves, with zero regression targets."""
+    from faster_rcnn_pytorch_multimodal_amd.layer_utils.proposal_target_layer import proposal_target_layer_device
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    C.reset_cfg()
+    C.cfg.NET_TYPE = "image"
+    C.cfg.TRAIN.USE_GT = True
+    gt = torch.tensor([[100., 100, 299, 259, 1], [500, 300, 699, 499, 1], [50, 400, 149, 549, 1]]).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    far = _rand_boxes(400, g, extent=(1000, 90), max_wh=40)            # a strip above every object
+    rois = torch.cat((torch.zeros(400, 1), far), 1).to(DEV)
+    rois[350:] = 0                                                      # padding rows beyond the live count
+    count = torch.tensor([350], dtype=torch.int32, device=DEV)
+    out = proposal_target_layer_device(rois, torch.rand(400, 1, generator=g).to(DEV), gt, 2, roi_count=count, seed=9)
+    lab = out["labels"].cpu()
+    assert int((lab > 0).sum()) == 3 and (lab[:3] == 1).all()
+    fg = out["rois"][:3, 1:].cpu()
+    assert sorted(map(tuple, fg.tolist())) == sorted(map(tuple, gt[:, :4].cpu().tolist()))
+    assert float(out["targets"][:3].abs().max()) <= 1e-5                # a gt box regresses onto itself
+    assert (out["rois"][3:, 1:].cpu()[:, 3] <= 131).all()              # background rows come from the live strip rows
+    C.cfg.TRAIN.USE_GT = False
+    out2 = proposal_target_layer_device(rois, None, gt, 2, roi_count=count, seed=9)
+    assert int((out2["labels"] > 0).sum()) == 0
+    C.reset_cfg()
+
+
 def test_proposal_target_layer_sampling_properties(hip):
     ops = _ops()
     g = torch.Generator().manual_seed(8)
