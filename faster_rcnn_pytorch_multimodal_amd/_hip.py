@@ -87,10 +87,10 @@ PROTOTYPES = {
                                           c_uint32, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "frcnn_proposal_target_layer": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_float, c_float, c_float,
                                             c_float, POINTER(c_float), POINTER(c_float), c_uint32, _P, _P, _P, _P, _P,
-                                            _P, _P, _P, _P]),
+                                            _P, _P, _P, _P, _P]),
     "frcnn_proposal_target_layer_lidar": (c_int, [_P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_float, c_float,
                                                   c_float, c_float, POINTER(c_float), POINTER(c_float), c_uint32, _P, _P,
-                                                  _P, _P, _P, _P, _P, _P, _P, _P]),
+                                                  _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "frcnn_filter_per_class_ws_bytes": (c_size_t, [c_int, c_int]),
     "frcnn_filter_per_class": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int,
                                        c_int, _P, _P, _P, c_size_t, _P]),

@@ -202,6 +202,7 @@ __device__ __forceinline__ void encode_box_lidar(const float* roi, const float* 
 template <int E>
 __global__ __launch_bounds__(PTL_THREADS) void ptl_kernel(const float* __restrict__ rois, const float* __restrict__ scores,
                                                          const int* __restrict__ roi_count, int num_rois,
+                                                         const unsigned char* __restrict__ skip,
                                                          const float* __restrict__ anchors3d,
                                                          const float* __restrict__ true_gt,
                                                          float* __restrict__ out_anchors3d,
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(PTL_THREADS) void ptl_kernel(const float* __restric
   for (int i = t; i < npad; i += PTL_THREADS) { kfg[i] = ~0ull; kbg[i] = ~0ull; }
   __syncthreads();
   for (int i = t; i < R; i += PTL_THREADS) {
+    if (skip && skip[i]) continue;       // TRAIN.IGNORE_DC: proposals inside a don't-care region are no candidates (:182-187)
     const float* b = rois + (size_t)i * 5 + 1;
     float best = -1.f;
     int arg = 0;
@@ -411,7 +413,8 @@ extern "C" int frcnn_anchor_target_layer(const float* anchors, int n, const floa
 
 namespace {
 template <int E>
-int launch_ptl(const float* rois, const float* roi_scores, const int* roi_count, int num_rois, const float* anchors3d,
+int launch_ptl(const float* rois, const float* roi_scores, const int* roi_count, int num_rois,
+               const unsigned char* skip, const float* anchors3d,
                const float* true_gt, float* out_anchors3d, const float* gt_boxes, int num_gt, int num_classes,
                int rois_per_frame, float fg_fraction, float fg_thresh, float bg_thresh_hi, float bg_thresh_lo,
                const float* means_host, const float* stds_host, uint32_t seed, float* labels, float* out_rois,
@@ -430,7 +433,7 @@ int launch_ptl(const float* rois, const float* roi_scores, const int* roi_count,
   }
   const int fg_quota = (int)lrintf(fg_fraction * (float)rois_per_frame);   // int(round(...)) (:44-45)
   hipLaunchKernelGGL(ptl_kernel<E>, dim3(1), dim3(PTL_THREADS), lds, static_cast<hipStream_t>(stream_), rois, roi_scores,
-                     roi_count, num_rois, anchors3d, true_gt, out_anchors3d, gt_boxes, num_gt, num_classes,
+                     roi_count, num_rois, skip, anchors3d, true_gt, out_anchors3d, gt_boxes, num_gt, num_classes,
                      rois_per_frame, fg_quota, fg_thresh, bg_thresh_hi, bg_thresh_lo, norm, seed, npad, labels, out_rois,
                      out_scores, targets, inside, outside, gt_assignment, counts);
   return check_launch("ptl_kernel");
@@ -443,12 +446,12 @@ extern "C" int frcnn_proposal_target_layer(const float* rois, const float* roi_s
                                            float bg_thresh_lo, const float* means_host, const float* stds_host,
                                            uint32_t seed, float* labels, float* out_rois, float* out_scores,
                                            float* targets, float* inside, float* outside, int* gt_assignment,
-                                           int* counts, void* stream_) {
+                                           int* counts, const unsigned char* skip_mask, void* stream_) {
   FRCNN_REQUIRE(rois && gt_boxes && means_host && stds_host && labels && out_rois && out_scores && targets && inside &&
                     outside && gt_assignment && counts && num_rois > 0 && num_rois <= 4096 && num_gt > 0 &&
                     num_classes > 1 && rois_per_frame > 0,
                 "proposal_target_layer: bad arguments (num_rois <= 4096, at least one gt box)");
-  return launch_ptl<4>(rois, roi_scores, roi_count, num_rois, nullptr, nullptr, nullptr, gt_boxes, num_gt, num_classes,
+  return launch_ptl<4>(rois, roi_scores, roi_count, num_rois, skip_mask, nullptr, nullptr, nullptr, gt_boxes, num_gt, num_classes,
                        rois_per_frame, fg_fraction, fg_thresh, bg_thresh_hi, bg_thresh_lo, means_host, stds_host, seed,
                        labels, out_rois, out_scores, targets, inside, outside, gt_assignment, counts, stream_);
 }
@@ -460,12 +463,13 @@ extern "C" int frcnn_proposal_target_layer_lidar(const float* rois, const float*
                                                  float bg_thresh_hi, float bg_thresh_lo, const float* means_host,
                                                  const float* stds_host, uint32_t seed, float* labels, float* out_rois,
                                                  float* out_scores, float* out_anchors3d, float* targets, float* inside,
-                                                 float* outside, int* gt_assignment, int* counts, void* stream_) {
+                                                 float* outside, int* gt_assignment, int* counts,
+                                                 const unsigned char* skip_mask, void* stream_) {
   FRCNN_REQUIRE(rois && anchors3d && gt_boxes && true_gt_boxes && means_host && stds_host && labels && out_rois &&
                     out_scores && out_anchors3d && targets && inside && outside && gt_assignment && counts &&
                     num_rois > 0 && num_rois <= 4096 && num_gt > 0 && num_classes > 1 && rois_per_frame > 0,
                 "proposal_target_layer_lidar: bad arguments (num_rois <= 4096, at least one gt box)");
-  return launch_ptl<7>(rois, roi_scores, roi_count, num_rois, anchors3d, true_gt_boxes, out_anchors3d, gt_boxes, num_gt,
+  return launch_ptl<7>(rois, roi_scores, roi_count, num_rois, skip_mask, anchors3d, true_gt_boxes, out_anchors3d, gt_boxes, num_gt,
                        num_classes, rois_per_frame, fg_fraction, fg_thresh, bg_thresh_hi, bg_thresh_lo, means_host,
                        stds_host, seed, labels, out_rois, out_scores, targets, inside, outside, gt_assignment, counts,
                        stream_);

@@ -18,9 +18,7 @@ from .anchor_target_layer import _draw_seed
 
 
 def proposal_target_layer_device(rpn_rois, rpn_scores, gt_boxes, num_classes, roi_count=None, seed=None,
-                                 anchors_3d=None, true_gt_boxes=None):
-    if cfg.TRAIN.IGNORE_DC:
-        raise NotImplementedError("TRAIN.IGNORE_DC is not on the HIP path")
+                                 anchors_3d=None, true_gt_boxes=None, gt_boxes_dc=None):
     scores = None if rpn_scores is None else rpn_scores.contiguous().view(-1)
     if cfg.TRAIN.USE_GT:
         # proposal_target_layer.py:31-37: the gt boxes join the candidates (score 0; LiDAR: the 3-D gt box is its own
@@ -35,18 +33,25 @@ def proposal_target_layer_device(rpn_rois, rpn_scores, gt_boxes, num_classes, ro
             roi_count = (roi_count.to(torch.int32) + g).to(torch.int32)
         if anchors_3d is not None:
             anchors_3d = torch.cat((true_gt_boxes[:, :7], anchors_3d), 0)
+    skip = None
+    if cfg.TRAIN.IGNORE_DC and gt_boxes_dc is not None and len(gt_boxes_dc) > 0:
+        # proposal_target_layer.py:180-187: proposals whose best overlap with a don't-care box reaches DC_THRESH are
+        # dropped before sampling (the mask is applied inside the sampling kernel: no compaction, no host sync)
+        dc = gt_boxes_dc[:, :4].contiguous()
+        skip = (ops.bbox_overlaps(rpn_rois[:, 1:5].contiguous(), dc).max(1)[0] >= cfg.TRAIN.DC_THRESH).to(torch.uint8)
     if anchors_3d is not None:
         return ops.proposal_target_layer(rpn_rois.contiguous(), scores, gt_boxes[:, :5].contiguous(), num_classes,
                                          cfg.TRAIN.ROI_BATCH_SIZE, cfg.TRAIN.FG_FRACTION, cfg.TRAIN.FG_THRESH,
                                          cfg.TRAIN.BG_THRESH_HI, cfg.TRAIN.BG_THRESH_LO,
                                          cfg.TRAIN.LIDAR.BBOX_NORMALIZE_MEANS, cfg.TRAIN.LIDAR.BBOX_NORMALIZE_STDS,
                                          _draw_seed() if seed is None else seed, roi_count=roi_count,
-                                         anchors_3d=anchors_3d.contiguous(), true_gt_boxes=true_gt_boxes.contiguous())
+                                         anchors_3d=anchors_3d.contiguous(), true_gt_boxes=true_gt_boxes.contiguous(),
+                                         skip_mask=skip)
     return ops.proposal_target_layer(rpn_rois.contiguous(), scores, gt_boxes[:, :5].contiguous(), num_classes,
                                      cfg.TRAIN.ROI_BATCH_SIZE, cfg.TRAIN.FG_FRACTION, cfg.TRAIN.FG_THRESH,
                                      cfg.TRAIN.BG_THRESH_HI, cfg.TRAIN.BG_THRESH_LO,
                                      cfg.TRAIN.IMAGE.BBOX_NORMALIZE_MEANS, cfg.TRAIN.IMAGE.BBOX_NORMALIZE_STDS,
-                                     _draw_seed() if seed is None else seed, roi_count=roi_count)
+                                     _draw_seed() if seed is None else seed, roi_count=roi_count, skip_mask=skip)
 
 
 def proposal_target_layer(rpn_rois, rpn_scores, anchors_3d, gt_boxes, true_gt_boxes, gt_boxes_dc, _num_classes,

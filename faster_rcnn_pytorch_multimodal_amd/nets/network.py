@@ -364,10 +364,11 @@ class Network(nn.Module):
                 if cfg.NET_TYPE == 'lidar':
                     self._proposal_targets = proposal_target_layer_device(
                         p['rois'], p['roi_scores'], self._gt_boxes, self._num_classes, roi_count=p['rois_count'],
-                        anchors_3d=p['roi_anchors_3d'], true_gt_boxes=self._true_gt_boxes)
+                        anchors_3d=p['roi_anchors_3d'], true_gt_boxes=self._true_gt_boxes, gt_boxes_dc=self._gt_boxes_dc)
                 else:
                     self._proposal_targets = proposal_target_layer_device(p['rois'], p['roi_scores'], self._gt_boxes,
-                                                                          self._num_classes, roi_count=p['rois_count'])
+                                                                          self._num_classes, roi_count=p['rois_count'],
+                                                                          gt_boxes_dc=self._gt_boxes_dc)
         if 'anchors_3d' in self._proposal_targets:
             self._predictions['roi_anchors_3d'] = self._proposal_targets['anchors_3d']   # follows the sampled rows
         self._predictions['rois_sampled'] = self._proposal_targets['rois']
@@ -404,6 +405,7 @@ class Network(nn.Module):
         self._image = to_nchw_view(ops.pad_channels(image.contiguous(), pad4(image.shape[-1])))
         self._mode = mode
         self._predictions = {}
+        self._gt_boxes_dc = None
         if mode == 'TEST':
             with torch.no_grad():
                 return self._predict()
@@ -421,6 +423,14 @@ class Network(nn.Module):
             gt = aabb
         self._gt_boxes = (torch.from_numpy(np.ascontiguousarray(gt)) if isinstance(gt, np.ndarray) else gt).to(
             dev, dtype=torch.float32)
+        # don't-care boxes (minibatch.py:168-176,215-220): only read when cfg.TRAIN.IGNORE_DC.  The anchor target layer's
+        # IGNORE_DC branch is a no-op in the reference (it writes -1 into labels that are still all -1,
+        # anchor_target_layer.py:58-64), so only the proposal sampling uses them.
+        self._gt_boxes_dc = None
+        if cfg.TRAIN.IGNORE_DC and gt_boxes_dc is not None and len(gt_boxes_dc) > 0:
+            dc = gt_boxes_dc if isinstance(gt_boxes_dc, torch.Tensor) else torch.from_numpy(
+                np.ascontiguousarray(np.asarray(gt_boxes_dc, dtype=np.float32)))
+            self._gt_boxes_dc = dc.to(dev, dtype=torch.float32)
         out = self._predict()
         self._add_losses()
         return out

@@ -673,7 +673,7 @@ def anchor_target_layer(anchors, gt_boxes, info, rpn_batchsize, fg_fraction, neg
 
 
 def proposal_target_layer(rois, roi_scores, gt_boxes, num_classes, rois_per_frame, fg_fraction, fg_thresh, bg_hi, bg_lo,
-                          means, stds, seed, roi_count=None, anchors_3d=None, true_gt_boxes=None):
+                          means, stds, seed, roi_count=None, anchors_3d=None, true_gt_boxes=None, skip_mask=None):
     """Returns dict(labels (R,), rois (R,5), scores (R,), targets/inside/outside (R,4K), assign int32 (R,), counts int32 (4,)).
     With ``anchors_3d`` (num_rois,7) and ``true_gt_boxes`` (G,8) the LiDAR form: 7K-wide targets and ``anchors_3d`` (R,7)."""
     lib = _hip.load()
@@ -682,6 +682,9 @@ def proposal_target_layer(rois, roi_scores, gt_boxes, num_classes, rois_per_fram
         _dev_f32(roi_scores, "roi_scores")
     dev = rois.device
     r = int(rois_per_frame)
+    if skip_mask is not None and (not skip_mask.is_cuda or skip_mask.dtype != torch.uint8 or
+                                  skip_mask.numel() != rois.shape[0] or not skip_mask.is_contiguous()):
+        raise _hip.HipError("proposal_target_layer: skip_mask must be a contiguous uint8 device tensor of num_rois bytes")
     if anchors_3d is not None:
         _dev_f32(anchors_3d, "anchors_3d"); _dev_f32(true_gt_boxes, "true_gt_boxes")
         if anchors_3d.shape != (rois.shape[0], 7) or true_gt_boxes.shape != (gt_boxes.shape[0], 8) or gt_boxes.shape[1] != 5:
@@ -702,7 +705,8 @@ def proposal_target_layer(rois, roi_scores, gt_boxes, num_classes, rois_per_fram
             _ptr(true_gt_boxes), gt_boxes.shape[0], int(num_classes), r, float(fg_fraction), float(fg_thresh), float(bg_hi),
             float(bg_lo), _hip.float_array(means), _hip.float_array(stds), int(seed) & 0xFFFFFFFF, _ptr(out["labels"]),
             _ptr(out["rois"]), _ptr(out["scores"]), _ptr(out["anchors_3d"]), _ptr(out["targets"]), _ptr(out["inside"]),
-            _ptr(out["outside"]), _ptr(out["assign"]), _ptr(out["counts"]), _stream()), "frcnn_proposal_target_layer_lidar")
+            _ptr(out["outside"]), _ptr(out["assign"]), _ptr(out["counts"]), _ptr(skip_mask), _stream()),
+            "frcnn_proposal_target_layer_lidar")
         return out
     out = {"labels": torch.empty((r,), dtype=torch.float32, device=dev),
            "rois": torch.empty((r, 5), dtype=torch.float32, device=dev),
@@ -717,7 +721,7 @@ def proposal_target_layer(rois, roi_scores, gt_boxes, num_classes, rois_per_fram
         r, float(fg_fraction), float(fg_thresh), float(bg_hi), float(bg_lo), _hip.float_array(means),
         _hip.float_array(stds), int(seed) & 0xFFFFFFFF, _ptr(out["labels"]), _ptr(out["rois"]), _ptr(out["scores"]),
         _ptr(out["targets"]), _ptr(out["inside"]), _ptr(out["outside"]), _ptr(out["assign"]), _ptr(out["counts"]),
-        _stream()), "frcnn_proposal_target_layer")
+        _ptr(skip_mask), _stream()), "frcnn_proposal_target_layer")
     return out
 
 

@@ -332,13 +332,15 @@ int frcnn_anchor_target_layer(const float* anchors, int n, const float* gt_boxes
  * rois (num_rois,5), roi_scores (num_rois) or NULL, roi_count device int or NULL, gt_boxes (num_gt,5).
  * Outputs with rois_per_frame rows (foreground rows first): labels, out_rois (.,5), out_scores, targets / inside /
  * outside (., 4*num_classes; targets normalised with means/stds, HOST 4 floats each), gt_assignment (.) ints,
- * counts[4] = {fg rows, bg rows, fg candidates, bg candidates}.  num_rois <= 4096. */
+ * counts[4] = {fg rows, bg rows, fg candidates, bg candidates}.  num_rois <= 4096.
+ * skip_mask (num_rois bytes, may be NULL): rows with a non-zero byte are no candidates (TRAIN.IGNORE_DC: proposals whose
+ * overlap with a don't-care box reaches DC_THRESH, proposal_target_layer.py:180-191). */
 int frcnn_proposal_target_layer(const float* rois, const float* roi_scores, const int* roi_count, int num_rois,
                                 const float* gt_boxes, int num_gt, int num_classes, int rois_per_frame,
                                 float fg_fraction, float fg_thresh, float bg_thresh_hi, float bg_thresh_lo,
                                 const float* means_host, const float* stds_host, uint32_t seed, float* labels,
                                 float* out_rois, float* out_scores, float* targets, float* inside, float* outside,
-                                int* gt_assignment, int* counts, void* stream);
+                                int* gt_assignment, int* counts, const unsigned char* skip_mask, void* stream);
 
 /* LiDAR form (proposal_target_layer.py:142-154, NET_TYPE 'lidar'): overlaps and labels on the BEV rectangles gt_boxes
  * (num_gt,5); targets = lidar_3d_bbox_transform(roi, the RoI's 3-D anchor, true_gt_boxes (num_gt,8)
@@ -350,7 +352,8 @@ int frcnn_proposal_target_layer_lidar(const float* rois, const float* roi_scores
                                       float bg_thresh_hi, float bg_thresh_lo, const float* means_host,
                                       const float* stds_host, uint32_t seed, float* labels, float* out_rois,
                                       float* out_scores, float* out_anchors3d, float* targets, float* inside,
-                                      float* outside, int* gt_assignment, int* counts, void* stream);
+                                      float* outside, int* gt_assignment, int* counts, const unsigned char* skip_mask,
+                                      void* stream);
 
 /* frcnn_det_loss for the 7-element LiDAR boxes (lib/utils/loss_utils.py:61-77): the yaw difference goes through
  * sin() before the Huber term when ry_sin (cfg.LIDAR.EN_RY_SIN), every element is scaled by reg_loss_weight_host[7]

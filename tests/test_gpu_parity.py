@@ -1248,6 +1248,35 @@ def test_proposal_target_layer_use_gt(hip):
     C.reset_cfg()
 
 
+def test_proposal_target_layer_ignore_dc(hip):
+    """cfg.TRAIN.IGNORE_DC (proposal_target_layer.py:180-191): proposals whose overlap with a don't-care box reaches
+    DC_THRESH never enter the sample; the others are sampled as usual."""
+    from faster_rcnn_pytorch_multimodal_amd.layer_utils.proposal_target_layer import proposal_target_layer_device
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    C.reset_cfg()
+    C.cfg.NET_TYPE = "image"
+    C.cfg.TRAIN.IGNORE_DC = True
+    gt = torch.tensor([[100., 100, 299, 259, 1]]).to(DEV)
+    dc = torch.tensor([[600., 300, 899, 599, 0]]).to(DEV)                # don't-care region, lower right
+    g = torch.Generator().manual_seed(6)
+    fg = gt[:1, :4].cpu() + (torch.rand(30, 4, generator=g) - 0.5) * 8
+    in_dc = dc[:1, :4].cpu() + (torch.rand(200, 4, generator=g) - 0.5) * 60          # IoU with the region well above 0.5
+    in_dc[:, 2] = in_dc[:, 2].clamp(max=999)
+    in_dc[:, 3] = in_dc[:, 3].clamp(max=599)
+    free = _rand_boxes(200, g, extent=(560, 90), max_wh=40)
+    rois = torch.cat((torch.zeros(430, 1), torch.cat((fg, in_dc, free), 0)), 1).to(DEV).contiguous()
+    ov_dc = O.bbox_overlaps(rois[:, 1:5].cpu(), dc[:, :4].cpu()).max(1)[0]
+    assert int((ov_dc >= 0.5).sum()) > 20
+    out = proposal_target_layer_device(rois, None, gt, 2, seed=3, gt_boxes_dc=dc)
+    picked = out["rois"][:, 1:5].cpu()
+    ov_pick = O.bbox_overlaps(picked, dc[:, :4].cpu()).max(1)[0]
+    assert float(ov_pick.max()) < 0.5 and int((out["labels"] > 0).sum()) == 30
+    C.cfg.TRAIN.IGNORE_DC = False
+    out2 = proposal_target_layer_device(rois, None, gt, 2, seed=3, gt_boxes_dc=dc)
+    assert float(O.bbox_overlaps(out2["rois"][:, 1:5].cpu(), dc[:, :4].cpu()).max()) >= 0.5     # without the switch they are sampled
+    C.reset_cfg()
+
+
 def test_proposal_target_layer_sampling_properties(hip):
     ops = _ops()
     g = torch.Generator().manual_seed(8)
