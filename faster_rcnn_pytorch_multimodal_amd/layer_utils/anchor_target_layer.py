@@ -20,8 +20,10 @@ def _draw_seed():
 def anchor_target_layer_device(gt_boxes, info, all_anchors, seed=None):
     """Flat form used by the training forward: labels (N,), targets/inside/outside (N,4) in anchor order
     ((H,W,A), A fastest) and counts (2,) int32 = fg / bg candidates before sub-sampling."""
-    if cfg.TRAIN.IGNORE_DC or cfg.TRAIN.RPN_CLOBBER_POSITIVES or cfg.TRAIN.RPN_POSITIVE_WEIGHT >= 0:
-        raise NotImplementedError("IGNORE_DC / RPN_CLOBBER_POSITIVES / RPN_POSITIVE_WEIGHT >= 0 are not on the HIP path")
+    # cfg.TRAIN.IGNORE_DC needs nothing here: the reference's branch (anchor_target_layer.py:58-64) writes -1 into labels
+    # that are still all -1 and every later rule overwrites them, i.e. it has no effect on the output
+    if cfg.TRAIN.RPN_CLOBBER_POSITIVES or cfg.TRAIN.RPN_POSITIVE_WEIGHT >= 0:
+        raise NotImplementedError("RPN_CLOBBER_POSITIVES / RPN_POSITIVE_WEIGHT >= 0 are not on the HIP path")
     if tuple(cfg.TRAIN.RPN_BBOX_INSIDE_WEIGHTS) != (1.0, 1.0, 1.0, 1.0):
         raise NotImplementedError("RPN_BBOX_INSIDE_WEIGHTS other than (1,1,1,1)")
     return ops.anchor_target_layer(all_anchors.contiguous(), gt_boxes[:, :5].contiguous(), info, cfg.TRAIN.RPN_BATCHSIZE,

@@ -1271,6 +1271,16 @@ def test_proposal_target_layer_ignore_dc(hip):
     picked = out["rois"][:, 1:5].cpu()
     ov_pick = O.bbox_overlaps(picked, dc[:, :4].cpu()).max(1)[0]
     assert float(ov_pick.max()) < 0.5 and int((out["labels"] > 0).sum()) == 30
+    # the RPN targets are unaffected by the switch (the reference's branch there has no effect)
+    from faster_rcnn_pytorch_multimodal_amd.layer_utils.anchor_target_layer import anchor_target_layer_device
+    anchors = torch.from_numpy(O.generate_anchors_pre(10, 16, 16, O.ANCHOR_SCALES, O.ANCHOR_RATIOS, 1.0)[0]).to(DEV)
+    info = np.array([0, 256, 0, 160, 0, 0, 1.0], np.float32)
+    gt_small = torch.tensor([[40., 30, 139, 109, 1]]).to(DEV)
+    with_dc = anchor_target_layer_device(gt_small, info, anchors, seed=1)
+    C.cfg.TRAIN.IGNORE_DC = False
+    without_dc = anchor_target_layer_device(gt_small, info, anchors, seed=1)
+    assert all(torch.equal(a, b) for a, b in zip(with_dc[:4], without_dc[:4]))
+    C.cfg.TRAIN.IGNORE_DC = True
     C.cfg.TRAIN.IGNORE_DC = False
     out2 = proposal_target_layer_device(rois, None, gt, 2, seed=3, gt_boxes_dc=dc)
     assert float(O.bbox_overlaps(out2["rois"][:, 1:5].cpu(), dc[:, :4].cpu()).max()) >= 0.5     # without the switch they are sampled
