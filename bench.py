@@ -240,8 +240,8 @@ def pmc_mfma_util():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--plans", default=None, help="JSON file of tuned conv plans: loaded when it exists (profiler runs "
                     "then use exactly the kernels of the timed run), written after warm-up otherwise")
