@@ -166,6 +166,15 @@ def structured_rpn(seed, h=38, w=63, a=25):
     return cls, box
 
 
+def fuse_rpn(cls, box, ld=152):
+    """(1,2A,H,W) logits + (1,H,W,4A) deltas -> the fused RPN head layout (1,H,W,ld) [bg | fg | deltas | pad]."""
+    a = cls.shape[1] // 2
+    fused = torch.zeros((1, cls.shape[2], cls.shape[3], ld))
+    fused[..., :2 * a] = cls.permute(0, 2, 3, 1)
+    fused[..., 2 * a:6 * a] = box
+    return fused
+
+
 def map_delta(net, sd, frames_host, info):
     """"mAP delta vs CPU ref" of the metric, on the structured-RPN variant of the frames (same injected RPN logits /
     deltas on both paths; backbone, RoIAlign, layer4, heads and the per-class filter are each path's own).
@@ -184,11 +193,7 @@ def map_delta(net, sd, frames_host, info):
     for i, f in enumerate(frames_host):
         cls, box = structured_rpn(i)
         ref = O.frame_detect(cpu, f, info, NUM_CLASSES, THRESH, MAX_DETS, structured=(cls, box))
-        a = cls.shape[1] // 2
-        fused = torch.zeros((1, cls.shape[2], cls.shape[3], 152))
-        fused[..., :2 * a] = cls.permute(0, 2, 3, 1)
-        fused[..., 2 * a:6 * a] = box
-        net._rpn_override = fused.to(net._device)
+        net._rpn_override = fuse_rpn(cls, box).to(net._device)
         try:
             dets, counts = detect_frame_device(net, f, info, THRESH, MAX_DETS, MAX_DETS)
             n = int(net._predictions["rois_count"].item())
@@ -237,7 +242,7 @@ def pmc_mfma_util():
         return None
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -251,112 +256,207 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--layers", action="store_true", help="print the per-layer conv table to stderr")
-    args = ap.parse_args()
+    ap.add_argument("--rehearse-collate", action="store_true",
+                    help="control-flow rehearsal WITHOUT a GPU (CPU test of the N > 1 launcher): ranks exchange synthetic "
+                         "records over gloo through the same step / gather / verify / report code; measures nothing")
+    return ap.parse_args(argv)
+
+
+def self_launch(args, argv):
+    """``python bench.py --gpus N`` with N > 1 and no launcher around it: start the N ranks through
+    ``torch.distributed.run`` as a CHILD process (one rank per GPU, RCCL rendezvous on 127.0.0.1) and hand its exit
+    code back.  This parent never touches the GPU (no HIP call happens before this point) and is never replaced by
+    exec; rank 0 of the child prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env["FRCNN_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rehearsal_record(frame_id, numel):
+    """Deterministic stand-in for a detection record (rehearsal mode only)."""
+    return torch.arange(numel, dtype=torch.float32) * 0.5 + float(frame_id)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args, argv))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
+    rehearsal = args.rehearse_collate
+    if not rehearsal and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; this package has no CPU execution path")
     # FRCNN_BENCH_BACKEND=gloo is a REHEARSAL of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share
     # devices, the collated record goes through the host); the judged multi-GPU run uses the default: RCCL.
-    backend = os.environ.get("FRCNN_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    device = "cuda:%d" % dev_index
+    backend = "gloo" if rehearsal else os.environ.get("FRCNN_BENCH_BACKEND", "nccl")
+    # FRCNN_BENCH_FORCE_DIST=1: go through the process group / all-gather path even with one rank (RCCL smoke test)
+    use_dist = world > 1 or rehearsal or os.environ.get("FRCNN_BENCH_FORCE_DIST") == "1"
+    device = "cpu"
+    if not rehearsal:
+        dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        device = "cuda:%d" % dev_index
     dist = None
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:               # FORCE_DIST without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29531"),
+                              RANK="0", WORLD_SIZE="1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(device))
         else:
             dist.init_process_group(backend)
     gather_dev = device if backend == "nccl" else "cpu"
 
-    from faster_rcnn_pytorch_multimodal_amd.model.frame_graph import FrameRunner
-    net, sd = build_net(device)
-    info = np.array([0, W, 0, H, 0, 0, 1.0], np.float32)
-    # frames resident in HBM: rank r gets frames r, r+world, ... (BASELINE configs[4]: seeds 0..7 on 8 GPUs)
-    n_resident = 4
-    frames_host = [synthetic_frame(rank + world * i) for i in range(n_resident)]
-    frames = [torch.from_numpy(f).to(device) for f in frames_host]
-    n_streams = max(1, args.streams)
-    from faster_rcnn_pytorch_multimodal_amd import ops as _ops
-    plans_loaded = False
-    if args.plans and os.path.exists(args.plans):
-        with open(args.plans) as f:
-            _ops.import_conv_plans(json.load(f))
-        plans_loaded = True
-    runners = [FrameRunner(net, H, W, C, info, THRESH, MAX_DETS, use_graph=not args.no_graph) for _ in range(n_streams)]
-    streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
-    rec = [torch.zeros((NUM_CLASSES, MAX_DETS, 5), device=device) for _ in range(n_streams)]
-    cnt = [torch.zeros((NUM_CLASSES,), dtype=torch.int32, device=device) for _ in range(n_streams)]
     from faster_rcnn_pytorch_multimodal_amd.model import collate
-    gathered = [torch.zeros((world, collate.record_numel(NUM_CLASSES, MAX_DETS)), device=gather_dev)
-                for _ in range(n_streams)] if world > 1 else None
-    records = [torch.zeros(collate.record_numel(NUM_CLASSES, MAX_DETS), device=device) for _ in range(n_streams)]
-    for st in streams:
-        st.wait_stream(torch.cuda.current_stream())
+    numel = collate.record_numel(NUM_CLASSES, MAX_DETS)
+    info = np.array([0, W, 0, H, 0, 0, 1.0], np.float32)
+    n_resident = 4
+    n_streams = max(1, args.streams)
+    net = sd = None
+    if not rehearsal:
+        from faster_rcnn_pytorch_multimodal_amd.model.frame_graph import FrameRunner
+        from faster_rcnn_pytorch_multimodal_amd import ops as _ops
+        net, sd = build_net(device)
+        # frames resident in HBM: rank r gets frames r, r+world, ... (BASELINE configs[4]: seeds 0..7 on 8 GPUs)
+        frames_host = [synthetic_frame(rank + world * i) for i in range(n_resident)]
+        frames = [torch.from_numpy(f).to(device) for f in frames_host]
+        plans_loaded = False
+        if args.plans and os.path.exists(args.plans):
+            with open(args.plans) as f:
+                _ops.import_conv_plans(json.load(f))
+            plans_loaded = True
+        runners = [FrameRunner(net, H, W, C, info, THRESH, MAX_DETS, use_graph=not args.no_graph) for _ in range(n_streams)]
+        streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+    records = [torch.zeros(numel, device=device) for _ in range(n_streams)]
+    gathered = [torch.zeros((world, numel), device=gather_dev) for _ in range(n_streams)] if use_dist else None
+    # every step's collated record lands in pinned host memory (asynchronous device->host copy on the frame's stream):
+    # the reference hands each frame's detections to the host (lib/model/test.py:206-228), and the records are what
+    # the verification below reads
+    ring = max(args.steps, 1)
+    host_rec = torch.empty((ring, world if use_dist else 1, numel), dtype=torch.float32,
+                           pin_memory=not rehearsal)
 
     def step(i):
         k = i % n_streams
+        if rehearsal:
+            collate.gather_records(rehearsal_record(rank + world * (i % n_resident), numel), gathered[k])
+            host_rec[i % ring].copy_(gathered[k])
+            return
         with torch.cuda.stream(streams[k]):
             dets, counts = runners[k].run(frames[i % n_resident])
-            if world > 1:
+            record = collate.pack_record(dets, counts, records[k])
+            if use_dist:
                 # eval collate: one fixed-size record per rank (detections + counts), all-gathered over xGMI
-                record = collate.pack_record(dets, counts, records[k])
                 collate.gather_records(record if backend == "nccl" else record.cpu(), gathered[k])
+                host_rec[i % ring].copy_(gathered[k], non_blocking=True)
             else:
-                rec[k].copy_(dets, non_blocking=True)
-                cnt[k].copy_(counts, non_blocking=True)
+                host_rec[i % ring, 0].copy_(record, non_blocking=True)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not rehearsal:
+            torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i)
     fence()
-    if args.plans and not plans_loaded and rank == 0:
+    if not rehearsal and args.plans and not plans_loaded and rank == 0:
         with open(args.plans, "w") as f:
             json.dump(_ops.export_conv_plans(), f)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    for st in streams:
-        torch.cuda.current_stream().wait_stream(st)
-    if world > 1:
-        host = [g.cpu() for g in gathered]   # rank-local copy of the collated records (device->host, timed)
-    else:
-        host = ([r.cpu() for r in rec], [c.cpu() for c in cnt])
+    if not rehearsal:
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
+        torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    per_rank = [own_elapsed]
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    del host
+        own = torch.tensor([own_elapsed], dtype=torch.float64, device=gather_dev)
+        allr = torch.zeros(world, dtype=torch.float64, device=gather_dev)
+        dist.all_gather_into_tensor(allr, own)
+        per_rank = [float(v) for v in allr.cpu()]
+
+    # ---- verification of the timed records (untimed): every timed step's record must equal, bit for bit, what the
+    # eager single-stream path returns for the same frame; with N > 1 the expected records of all ranks are exchanged
+    # once more so that every rank checks every row the timed all-gathers delivered
+    if rehearsal:
+        expected = torch.stack([torch.stack([rehearsal_record(r + world * j, numel) for j in range(n_resident)])
+                                for r in range(world)])
+    else:
+        from faster_rcnn_pytorch_multimodal_amd.model.test import detect_frame_device
+        own_expected = torch.zeros((n_resident, numel), device=device)
+        for j in range(n_resident):
+            dets, counts = detect_frame_device(net, frames[j], info, THRESH, MAX_DETS, MAX_DETS)
+            collate.pack_record(dets, counts, own_expected[j])
+        torch.cuda.synchronize()
+        if use_dist:
+            expected = collate.gather_records((own_expected if backend == "nccl" else own_expected.cpu()).view(-1))
+            expected = expected.view(world, n_resident, numel).cpu()
+        else:
+            expected = own_expected.cpu().unsqueeze(0)
+    bad = [i for i in range(args.steps) if not torch.equal(host_rec[i % ring], expected[:, i % n_resident, :])]
+    if use_dist:
+        flag = torch.tensor([len(bad)], dtype=torch.int64, device=gather_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+        n_bad = int(flag.item())
+    else:
+        n_bad = len(bad)
+    if n_bad:
+        print("bench.py: rank %d: %d timed records differ from the eager path (first at steps %s)"
+              % (rank, len(bad), bad[:8]), file=sys.stderr)
+        if use_dist:
+            dist.destroy_process_group()
+        raise SystemExit(3)
+    import hashlib
+    checksum = hashlib.sha1(host_rec[:min(args.steps, ring)].numpy().tobytes()).hexdigest()[:16]
+    dets_last = host_rec[(args.steps - 1) % ring, 0 if not use_dist else rank]
+    verification = {"timed_steps_checked": args.steps, "equal_to_eager_path": True, "records_sha1_16": checksum,
+                    "detections_per_class_last_step": [int(v) for v in dets_last[NUM_CLASSES * MAX_DETS * 5:]],
+                    "what": "every timed step's record (device->host copied inside the timed region) equals the eager "
+                            "single-stream record of the same frame, bit for bit; tests/test_timed_path.py compares the "
+                            "same arrangement with the CPU oracle"}
+
+    # ---- the collective on its own (N > 1): HIP-event timing of the all-gather of one record on one stream
+    allgather_us = None
+    if use_dist and not rehearsal and backend == "nccl":
+        reps = 50
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            collate.gather_records(records[0], gathered[0])
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            collate.gather_records(records[0], gathered[0])
+        e1.record()
+        torch.cuda.synchronize()
+        allgather_us = 1e3 * e0.elapsed_time(e1) / reps
 
     out = None
     if rank == 0:
-        conv = conv_roofline(net, frames[0], info, steps=min(args.steps, 5))
-        achieved = conv["flops_per_frame"] / (conv["ms_per_frame"] * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "conv_igemm_f32 (all instantiations, %d launches/frame)"
-                    % round(conv["launches_per_frame"]), "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic("conv_igemm"),
-                    "mfma_util_pmc_percent": pmc_mfma_util(),
-                    "flops_per_frame": conv["flops_per_frame"], "kernel_ms_per_frame": conv["ms_per_frame"],
-                    "event_pair_overhead_us": conv["event_pair_overhead_us"],
-                    "avg_launch_us": 1e3 * conv["ms_per_frame"] / conv["launches_per_frame"]}
-        if args.layers:
-            for k, v in sorted(conv["per_layer"].items(), key=lambda kv: -kv[1]["us_per_call"] * kv[1]["calls_per_frame"]):
-                print("%-40s x%-4.0f %9.1f us/call %7.1f TFLOP/s" % (k, v["calls_per_frame"], v["us_per_call"], v["tflops"]),
-                      file=sys.stderr)
         out = {
             "metric": "frames/sec res101 Faster-RCNN 1000x600", "value": world * args.steps / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -366,14 +466,46 @@ def main():
                                    "thresh %.1f max_dets %d; weights seeded random init (BN tame)" % (THRESH, MAX_DETS),
                        "frames_per_step": world, "parallelism": "frame-sharded x%d, all-gather of detections" % world,
                        "launch": "eager" if args.no_graph else "hipGraph replay", "frames_in_flight": n_streams},
-            "roofline": roofline,
-            "roofline_roi_align": roi_align_timing(net, 20),
-            "roofline_nms": nms_timing(net, 20),
+            "verification": verification,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], _ = cpu_baseline(sd, frames_host[:args.cpu_frames], info)
-            out["map_delta_vs_cpu"] = map_delta(net, sd, frames_host[:2], info)
-    if world > 1:
+        if use_dist:
+            out["collective"] = {"backend": dist.get_backend(), "is_rccl": dist.get_backend() == "nccl",
+                                 "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
+                                 "ranks": dist.get_world_size(),
+                                 "per_rank_frames_per_s": [args.steps / v for v in per_rank],
+                                 "allgather_us_per_step": allgather_us, "record_bytes_per_rank": 4 * numel,
+                                 "self_launched": os.environ.get("FRCNN_BENCH_SELF_LAUNCHED") == "1"}
+        if rehearsal:
+            out["data"] = "rehearsal: synthetic records over gloo, no device work - NOT a measurement"
+            out["value"] = None
+        else:
+            conv = conv_roofline(net, frames[0], info, steps=min(args.steps, 5))
+            achieved = conv["flops_per_frame"] / (conv["ms_per_frame"] * 1e-3) / 1e12
+            timed_tflops = conv["flops_per_frame"] / (1e-3 * 1e3 * elapsed / args.steps) / 1e12
+            out["roofline"] = {
+                "bound": "mfma", "kernel": "conv_igemm_f32 (all instantiations, %d launches/frame)"
+                % round(conv["launches_per_frame"]), "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic("conv_igemm"),
+                "mode": "isolated kernels: eager launches on one stream, per-launch HIP events (the quantity rocprofv3's "
+                        "per-dispatch durations reproduce); the timed run overlaps %d frames, see frac_timed" % n_streams,
+                "achieved_timed": timed_tflops, "frac_timed": timed_tflops / MFMA_F32_PEAK_TFLOPS,
+                "frac_timed_what": "all conv FLOPs of a frame / ms_per_step of the TIMED run (hipGraph x %d streams) / "
+                                   "peak: a lower bound on the conv kernels' rate in the timed mode, since the step also "
+                                   "holds every non-conv kernel" % n_streams,
+                "mfma_util_pmc_percent": pmc_mfma_util(),
+                "flops_per_frame": conv["flops_per_frame"], "kernel_ms_per_frame": conv["ms_per_frame"],
+                "event_pair_overhead_us": conv["event_pair_overhead_us"],
+                "avg_launch_us": 1e3 * conv["ms_per_frame"] / conv["launches_per_frame"]}
+            if args.layers:
+                for k, v in sorted(conv["per_layer"].items(), key=lambda kv: -kv[1]["us_per_call"] * kv[1]["calls_per_frame"]):
+                    print("%-40s x%-4.0f %9.1f us/call %7.1f TFLOP/s" % (k, v["calls_per_frame"], v["us_per_call"], v["tflops"]),
+                          file=sys.stderr)
+            out["roofline_roi_align"] = roi_align_timing(net, 20)
+            out["roofline_nms"] = nms_timing(net, 20)
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"], _ = cpu_baseline(sd, frames_host[:args.cpu_frames], info)
+                out["map_delta_vs_cpu"] = map_delta(net, sd, frames_host[:2], info)
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

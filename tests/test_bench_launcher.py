@@ -1,0 +1,48 @@
+"""bench.py's N > 1 control flow without a GPU: `python bench.py --gpus 2` must start its own ranks (no external
+torch.distributed.run), exchange one record per rank per step, verify what the gathers delivered and print ONE JSON
+line from rank 0.  `--rehearse-collate` swaps the device work for synthetic records and RCCL for gloo; everything else
+(launcher, sharding, step loop, all-gather, barrier + max-over-ranks timing, verification, report) is the code the
+8-GPU run executes."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _run(args, env_extra=None, timeout=300):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, timeout=timeout,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+def test_gpus_2_self_launches_and_collates_over_gloo():
+    res = _run(["--gpus", "2", "--steps", "6", "--warmup", "2", "--rehearse-collate"])
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout                      # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert out["value"] is None and "rehearsal" in out["data"]          # never mistaken for a measurement
+    col = out["collective"]
+    assert col["ranks"] == 2 and col["backend"] == "gloo" and col["is_rccl"] is False and col["self_launched"] is True
+    assert len(col["per_rank_frames_per_s"]) == 2
+    ver = out["verification"]
+    assert ver["equal_to_eager_path"] is True and ver["timed_steps_checked"] == 6
+
+
+def test_world_size_mismatch_is_rejected():
+    res = _run(["--gpus", "2", "--rehearse-collate"], env_extra={"WORLD_SIZE": "1", "RANK": "0"})
+    assert res.returncode != 0 and "WORLD_SIZE" in (res.stderr + res.stdout)
+
+
+def test_bench_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        return
+    res = _run(["--steps", "1", "--warmup", "0"])
+    assert res.returncode != 0 and "MI355X" in (res.stderr + res.stdout)
