@@ -9,6 +9,8 @@
 // accumulation order follow the CPU kernel of the library the reference calls.
 #include "common.h"
 
+#include <algorithm>
+
 namespace {
 
 // XCD_SPLIT: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one), so workgroup b works on
@@ -88,208 +90,432 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const float* __restric
 
 
 // ------------------------------------------------------------------------------------------------
-// Separable form (C % 32 == 0).  Bilinear sampling factorises per axis — sample weight = wy(y) * wx(x), a sample is
-// dropped when EITHER coordinate is outside [-1, size] — so a bin's average is
+// Planned separable form — the fast path (P == 7).
+//
+// Bilinear sampling factorises per axis — sample weight = wy(y) * wx(x), a sample is dropped when EITHER coordinate is
+// outside [-1, size] — so a bin's average is
 //     out[ph][pw] = 1/count * sum_y Wy[ph][y] * ( sum_x Wx[pw][x] * F[y][x] )
-// with Wy / Wx the per-axis weights of a bin's samples accumulated per feature row / column.  One workgroup =
-// (RoI, CC-channel slice): it builds Wx, Wy in LDS, then walks the RoI window in chunks of RCH feature rows: the seven
-// per-column-bin row sums T[y][pw] of the chunk go to LDS, and every thread adds the chunk's rows into the bins it
-// owns (accumulators stay in registers across chunks).  Each window pixel is read about once instead of up to
-// 4*gh*gw times per bin (the generic kernel is bound by the 64 B/clk/CU vector-L1 path), and the LDS footprint is
-// RCH*P*CC*4 bytes whatever the window height: the op is a chain of short dependent phases, so what matters is how
-// many workgroups a CU can keep in flight (8 at ~17 KB each), not the work of one.
-// The summation order differs from the library kernel the oracle follows (agreement ~1e-6 relative, well inside the
-// 1e-4 bar).  Workgroup b handles slice b % nslices, so an XCD (b % 8) only touches 1/8 of the channels (L2 locality).
+// with Wy / Wx the per-axis weights of a bin's samples accumulated per feature row / column.
+//
+// Kernel 1, roi_plan_kernel: one workgroup per RoI, one wave per (axis, bin).  Lane i evaluates sample i of the bin
+// ONCE (coordinate arithmetic of the library kernel, built with -ffp-contract=off), then every pixel lane walks the
+// samples in order through v_readlane: deterministic, no read-modify-write.  It writes the axis weight tables
+// (Wx[P][.] relative to the bin's first column, Wy[P][.] by absolute row, zero outside a bin's range) and appends the
+// RoI's work items to a COMPACT list (its position = the item count of the RoIs before it, which every workgroup
+// recomputes from the boxes: no atomics, deterministic order).  Items = (RoI, row-bin piece, 256-channel slice):
+// a LIGHT RoI is one piece (all P row bins in one pass over the window, each feature row read once); a HEAVY RoI (an
+// untrained RPN proposes frame-wide boxes: 38 rows x 9 columns per bin = 340 loads per lane, a chain of 40 dependent
+// load groups) gets one piece per row bin (rows at a bin border are read by both neighbours: <= (rows + P) / rows
+// extra traffic, small exactly when the RoI is tall).
+//
+// Kernel 2, roi_align_fwd_planned: no LDS, no barrier.  One WAVE-ITEM = (item, column bin pw); lane l owns channels
+// 4*(64*slice + l) .. +3, so every feature-map access of the wave is one contiguous 1 KB line and every per-pixel
+// weight is wave-uniform: wx (lane j = column xlo + j) and wy[ph] (lane j = row yc + j) come from the plan and are
+// broadcast with v_readlane.  The window is walked pixel by pixel (row-major) in groups of G independent 16-byte
+// loads per lane (4 VALU per pixel: address, readlane, two v_pk_fma_f32); a finished row's column-weighted sum is
+// folded into the row-bin accumulators.  The grid is PERSISTENT — as many waves as the chip holds at once, each
+// looping over wave-items with a fixed stride — and software-pipelined across items: while item i is pooled, the
+// tables of item i+1 and the descriptor of item i+2 are already in flight, so a wave's dependent chain per item is
+// its pixel-load groups only.
+// Workgroup b only takes items of slice b % nslices, so with nslices | 8 an XCD (b % 8) touches one channel slice of
+// the map (1/nslices of it stays in its 4 MB L2).
+// What bounded the earlier forms (profiles/r02_roi_align.md): LDS row-chunk kernel, 4800 workgroups each a chain of
+// short dependent phases: 46 us; register form with per-lane redundant sample arithmetic and IEEE divisions: 2000
+// VALU per wave, VALUBusy 50 %, 54 us; lane-parallel samples, one workgroup per (RoI, piece, slice): 35 us of which
+// 13.6 us for the launch / scalar-load / exit skeleton of the 7200 unused pieces; persistent over a static item space
+// without pipelining: 31 us (a wave lived 12 us on average, 31 us at worst: per-item latency chain x imbalance).
 // ------------------------------------------------------------------------------------------------
-template <int CC, int RCH>
-__global__ __launch_bounds__(256) void roi_align_fwd_sep(const float* __restrict__ feat, int H, int W, int C,
-                                                        const float* __restrict__ rois,
-                                                        const int* __restrict__ roi_count, int num_rois, int P,
-                                                        float spatial_scale, int sampling_ratio,
-                                                        const int* __restrict__ level_of_roi, int level,
-                                                        float* __restrict__ out) {
-  constexpr int CL = CC / 4;          // float4 per pixel of the slice
-  constexpr int MAXJ = 4;             // bins*CL / 256 rounded up, for P = 7: 392/256 -> 2 (CC 32), 784/256 -> 4 (CC 64)
-  extern __shared__ __attribute__((aligned(16))) float sep_smem[];
-  const int nslices = C / CC;
-  const int r = blockIdx.x / nslices, slice = blockIdx.x - r * nslices;
-  if (level_of_roi && level_of_roi[r] != level) return;
-  const int t = threadIdx.x;
-  const int live = roi_count ? min(*roi_count, num_rois) : num_rois;
-  const int C4 = C >> 2;
-  const int items = P * P * CL;
-  float4* ob = reinterpret_cast<float4*>(out) + (size_t)r * P * P * C4 + slice * CL;
-  if (r >= live) {
-    for (int i = t; i < items; i += 256) ob[(size_t)(i / CL) * C4 + (i % CL)] = make_float4(0.f, 0.f, 0.f, 0.f);
-    return;
-  }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ bool axis_sample_pt(float start, float bin_size, int pbin, int i, int grid, int size, int& lo,
+                                               int& hi, float& wlo, float& whi) {
+  float v = start + pbin * bin_size + ((float)i + .5f) * bin_size / (float)grid;
+  if (v < -1.0f || v > (float)size) return false;
+  if (v <= 0.f) v = 0.f;
+  lo = (int)v;
+  if (lo >= size - 1) { hi = lo = size - 1; v = (float)lo; } else hi = lo + 1;
+  whi = v - (float)lo;
+  wlo = 1.f - whi;
+  return true;
+}
+
+__device__ __forceinline__ float lane_bcast(float v, int lane) {   // lane is wave-uniform
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ int lane_bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+constexpr int PLAN_P = 7;
+constexpr int NO_PIXEL = -(1 << 30);
+enum { ROI_SKIP = 0, ROI_LIGHT = 1, ROI_HEAVY = 2, ROI_DEAD = 3 };
+
+struct RoiItem {                  // 32 words, everything wave-uniform a wave-item needs
+  int r, sp, slice, flag;         // flag: ROI_LIGHT (all row bins), ROI_HEAVY (row bin sp only), ROI_DEAD (zero fill)
+  int y0, y1;                     // feature rows touched by the item's row bins (y0 > y1: none)
+  float inv_count;
+  int bimg;
+  int xlo[8], xhi[8];             // columns touched by column bin pw (lo > hi: none)
+  int pad[8];
+};
+static_assert(sizeof(RoiItem) == 128, "item descriptor is 32 words");
+
+struct RoiPlanHead {              // first 64 bytes of the workspace
+  int total_items;
+  int pad[15];
+};
+
+__host__ __device__ inline int plan_pad(int n) { return (n + 63) & ~63; }
+
+// flag of RoI r from the box alone (every workgroup of the plan kernel evaluates it for the RoIs before its own)
+__device__ __forceinline__ int roi_flag(const float* __restrict__ rois, int r, int live, const int* __restrict__ level_of_roi,
+                                        int level, float spatial_scale, int H, int W, int heavy_loads) {
+  if (level_of_roi && level_of_roi[r] != level) return ROI_SKIP;
+  if (r >= live) return ROI_DEAD;
   const float* roi = rois + (size_t)r * 5;
-  const int b = (int)roi[0];
-  const float roi_start_w = roi[1] * spatial_scale, roi_start_h = roi[2] * spatial_scale;
-  const float roi_end_w = roi[3] * spatial_scale, roi_end_h = roi[4] * spatial_scale;
-  const float roi_width = fmaxf(roi_end_w - roi_start_w, 1.0f), roi_height = fmaxf(roi_end_h - roi_start_h, 1.0f);
-  const float bin_size_h = roi_height / (float)P, bin_size_w = roi_width / (float)P;
-  const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)P);
-  const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)P);
-  const float count = (float)(grid_h * grid_w);
-  const float4* fb = reinterpret_cast<const float4*>(feat) + (size_t)b * H * W * C4 + slice * CL;
+  const float roi_width = fmaxf(roi[3] * spatial_scale - roi[1] * spatial_scale, 1.0f);
+  const float roi_height = fmaxf(roi[4] * spatial_scale - roi[2] * spatial_scale, 1.0f);
+  const int rows_est = min((int)roi_height + 2, H), cols_est = min((int)(roi_width / (float)PLAN_P) + 2, W);
+  return rows_est * cols_est > heavy_loads ? ROI_HEAVY : ROI_LIGHT;
+}
 
-  // LDS: Wx[P][W], Wy[P][H], per-bin ranges, then T[RCH][P][CL] float4
-  float* Wx = sep_smem;
-  float* Wy = Wx + P * W;
-  int* rng = reinterpret_cast<int*>(Wy + P * H);   // xlo[P], xhi[P], ylo[P], yhi[P]
-  float4* T = reinterpret_cast<float4*>(sep_smem + ((P * W + P * H + 4 * P + 3) & ~3));
-
-  // one axis sample -> (low index, high index, weight of low, weight of high, valid)
-  auto axis_sample = [](float start, float bin_size, int pbin, int i, int grid, int size, int& lo, int& hi, float& wlo,
-                        float& whi) -> bool {
-    float v = start + pbin * bin_size + ((float)i + .5f) * bin_size / (float)grid;
-    if (v < -1.0f || v > (float)size) return false;
-    if (v <= 0.f) v = 0.f;
-    lo = (int)v;
-    if (lo >= size - 1) { hi = lo = size - 1; v = (float)lo; } else hi = lo + 1;
-    whi = v - (float)lo;
-    wlo = 1.f - whi;
-    return true;
-  };
-  for (int i = t; i < P * W + P * H; i += 256) sep_smem[i] = 0.f;
-  __syncthreads();
-  // per-axis weights: thread (axis, bin) walks its samples in order -> deterministic sums
-  if (t < 2 * P) {
-    const bool is_x = t < P;
-    const int pb = is_x ? t : t - P;
-    const int grid = is_x ? grid_w : grid_h, size = is_x ? W : H;
-    float* wrow = is_x ? Wx + pb * W : Wy + pb * H;
-    int lo_all = size, hi_all = -1;
-    for (int i = 0; i < grid; ++i) {
+// one workgroup per RoI, 2P waves: wave w < P builds column bin w, wave P + w row bin w
+__global__ __launch_bounds__(64 * 2 * PLAN_P) void roi_plan_kernel(int H, int W, const float* __restrict__ rois,
+                                                                   const int* __restrict__ roi_count, int num_rois,
+                                                                   float spatial_scale, int sampling_ratio,
+                                                                   const int* __restrict__ level_of_roi, int level,
+                                                                   int nslices, int heavy_loads,
+                                                                   RoiPlanHead* __restrict__ head,
+                                                                   RoiItem* __restrict__ items, float* __restrict__ wxt,
+                                                                   float* __restrict__ wyt) {
+  constexpr int P = PLAN_P;
+  __shared__ int s_count[2 * P];
+  __shared__ int s_lo[2 * P], s_hi[2 * P];
+  const int r = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int live = roi_count ? min(*roi_count, num_rois) : num_rois;
+  // position of this RoI's items in the compact list: pieces of the RoIs before it
+  int before = 0;
+  for (int q = threadIdx.x; q < r; q += blockDim.x) {
+    const int f = roi_flag(rois, q, live, level_of_roi, level, spatial_scale, H, W, heavy_loads);
+    before += f == ROI_SKIP ? 0 : (f == ROI_HEAVY ? P : 1);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+  if (lane == 0) s_count[wave] = before;
+  const int flag = roi_flag(rois, r, live, level_of_roi, level, spatial_scale, H, W, heavy_loads);
+  int plo = 0, phi = -1;
+  float inv_count = 0.f;
+  int bimg = 0;
+  if (flag == ROI_LIGHT || flag == ROI_HEAVY) {
+    const float* roi = rois + (size_t)r * 5;
+    bimg = (int)roi[0];
+    const float roi_start_w = roi[1] * spatial_scale, roi_start_h = roi[2] * spatial_scale;
+    const float roi_end_w = roi[3] * spatial_scale, roi_end_h = roi[4] * spatial_scale;
+    const float roi_width = fmaxf(roi_end_w - roi_start_w, 1.0f), roi_height = fmaxf(roi_end_h - roi_start_h, 1.0f);
+    const float bin_size_h = roi_height / (float)P, bin_size_w = roi_width / (float)P;
+    const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)P);
+    const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)P);
+    inv_count = 1.0f / (float)(grid_h * grid_w);
+    const bool is_x = wave < P;
+    const int bin = is_x ? wave : wave - P;
+    const float start = is_x ? roi_start_w : roi_start_h, bin_size = is_x ? bin_size_w : bin_size_h;
+    const int grid = __builtin_amdgcn_readfirstlane(is_x ? grid_w : grid_h), size = is_x ? W : H;
+    float* table = is_x ? wxt + ((size_t)r * P + bin) * plan_pad(W) : wyt + ((size_t)r * P + bin) * plan_pad(H);
+    // lane-parallel sample evaluation; invalid -> NO_PIXEL
+    auto sample = [&](int i, int& lo, int& hi, float& wl, float& wh) {
+      lo = hi = NO_PIXEL;
+      wl = wh = 0.f;
+      if (i < grid) {
+        int l, hh;
+        if (axis_sample_pt(start, bin_size, bin, i, grid, size, l, hh, wl, wh)) { lo = l; hi = hh; }
+      }
+    };
+    // sample coordinates are non-decreasing, so the first valid sample has the smallest first pixel and the last valid
+    // sample the largest second pixel
+    plo = size;
+    for (int i0 = 0; i0 < grid; i0 += 64) {
       int lo, hi;
-      float wlo, whi;
-      if (!axis_sample(is_x ? roi_start_w : roi_start_h, is_x ? bin_size_w : bin_size_h, pb, i, grid, size, lo, hi, wlo, whi))
-        continue;
-      wrow[lo] += wlo;
-      wrow[hi] += whi;
-      lo_all = min(lo_all, lo);
-      hi_all = max(hi_all, hi);
+      float wl, wh;
+      sample(i0 + lane, lo, hi, wl, wh);
+      const unsigned long long m = __ballot(lo != NO_PIXEL);
+      if (m) {
+        plo = min(plo, lane_bcast(lo, (int)__builtin_ctzll(m)));
+        phi = max(phi, lane_bcast(hi, 63 - (int)__builtin_clzll(m)));
+      }
     }
-    rng[(is_x ? 0 : 2 * P) + pb] = lo_all;
-    rng[(is_x ? P : 3 * P) + pb] = hi_all;
+    // dense weight row: pixel lane accumulates the samples that touch it, in sample order.  Column tables are
+    // relative to the bin's first column, row tables are indexed by absolute row.
+    const int origin = is_x ? (phi >= plo ? plo : 0) : 0;
+    for (int p0 = 0; p0 < plan_pad(size); p0 += 64) {
+      const int px = origin + p0 + lane;
+      float wgt = 0.f;
+      if (origin + p0 <= phi && origin + p0 + 63 >= plo) {
+        for (int i0 = 0; i0 < grid; i0 += 64) {
+          int slo, shi;
+          float swl, swh;
+          sample(i0 + lane, slo, shi, swl, swh);
+          const int n = min(64, grid - i0);
+          for (int i = 0; i < n; ++i) {
+            wgt += (lane_bcast(slo, i) == px) ? lane_bcast(swl, i) : 0.f;
+            wgt += (lane_bcast(shi, i) == px) ? lane_bcast(swh, i) : 0.f;
+          }
+        }
+      }
+      table[p0 + lane] = wgt;
+    }
   }
+  if (lane == 0) { s_lo[wave] = plo; s_hi[wave] = phi; }
   __syncthreads();
-  int y0 = H, y1 = -1;
-  for (int ph = 0; ph < P; ++ph) { y0 = min(y0, rng[2 * P + ph]); y1 = max(y1, rng[3 * P + ph]); }
-  // the bins this thread owns: item = t + 256*j -> (bin, c4)
-  float4 acc[MAXJ];
-  int a_pw[MAXJ], a_c4[MAXJ], a_yl[MAXJ], a_yh[MAXJ];
-  const float* a_wr[MAXJ];
+  int base = 0;
 #pragma unroll
-  for (int j = 0; j < MAXJ; ++j) {
-    acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int i = min(t + 256 * j, items - 1);
-    const int bin = i / CL, ph = bin / P;
-    a_c4[j] = i % CL;
-    a_pw[j] = bin - ph * P;
-    a_yl[j] = rng[2 * P + ph];
-    a_yh[j] = rng[3 * P + ph];
-    a_wr[j] = Wy + ph * H;
-  }
-  for (int ys = y0; ys <= y1; ys += RCH) {      // y1 < y0: no valid sample at all -> zeros
-    const int rows = min(RCH, y1 - ys + 1);
-    // phase 1: T[y - ys][pw][c4] = sum_x Wx[pw][x] * F[y][x]; item = (row, pw, c4)
-    for (int i = t; i < rows * P * CL; i += 256) {
-      const int c4 = i % CL, pw = (i / CL) % P, yr = i / (CL * P);
-      const float4* frow = fb + (size_t)(ys + yr) * W * C4 + c4;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int xl = rng[pw], xh = rng[P + pw];
-      const float* wr = Wx + pw * W;
-      for (int x = xl; x <= xh; ++x) {
-        const float wgt = wr[x];
-        const float4 v = frow[(size_t)x * C4];
-        a.x += wgt * v.x; a.y += wgt * v.y; a.z += wgt * v.z; a.w += wgt * v.w;
-      }
-      T[(yr * P + pw) * CL + c4] = a;
+  for (int w = 0; w < 2 * P; ++w) base += s_count[w];
+  const int pieces = flag == ROI_SKIP ? 0 : (flag == ROI_HEAVY ? P : 1);
+  if (r == num_rois - 1 && threadIdx.x == 0) head->total_items = (base + pieces) * nslices;
+  // item descriptors: thread t writes (piece, slice) = (t / nslices, t % nslices)
+  for (int t = threadIdx.x; t < pieces * nslices; t += blockDim.x) {
+    const int sp = t / nslices, slice = t - sp * nslices;
+    RoiItem it;
+    it.r = r; it.sp = sp; it.slice = slice; it.flag = flag;
+    it.inv_count = inv_count;
+    it.bimg = bimg;
+    int y0 = H, y1 = -1;
+#pragma unroll
+    for (int ph = 0; ph < P; ++ph)
+      if (flag != ROI_HEAVY || ph == sp) { y0 = min(y0, s_lo[P + ph]); y1 = max(y1, s_hi[P + ph]); }
+    it.y0 = flag == ROI_DEAD ? 0 : y0;
+    it.y1 = flag == ROI_DEAD ? -1 : y1;
+#pragma unroll
+    for (int pw = 0; pw < 8; ++pw) {
+      it.xlo[pw] = pw < P ? s_lo[pw] : 0;
+      it.xhi[pw] = pw < P ? s_hi[pw] : -1;
+      it.pad[pw] = 0;
     }
-    __syncthreads();
-    // phase 2: acc[ph][pw] += sum_{y in chunk} Wy[ph][y] * T[y][pw]
-#pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-      if (t + 256 * j >= items) continue;
-      const int lo = max(a_yl[j], ys), hi = min(a_yh[j], ys + rows - 1);
-      for (int y = lo; y <= hi; ++y) {
-        const float wgt = a_wr[j][y];
-        const float4 v = T[((y - ys) * P + a_pw[j]) * CL + a_c4[j]];
-        acc[j].x += wgt * v.x; acc[j].y += wgt * v.y; acc[j].z += wgt * v.z; acc[j].w += wgt * v.w;
-      }
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int j = 0; j < MAXJ; ++j) {
-    const int i = t + 256 * j;
-    if (i >= items) continue;
-    ob[(size_t)(i / CL) * C4 + a_c4[j]] =
-        make_float4(acc[j].x / count, acc[j].y / count, acc[j].z / count, acc[j].w / count);
+    items[(size_t)(base + sp) * nslices + slice] = it;
   }
 }
 
-template <int CC, int RCH>
-int launch_sep(const float* feat, int h, int w, int c, const float* rois, const int* roi_count, int num_rois, int pooled,
-               float spatial_scale, int sampling_ratio, const int* level_of_roi, int level, float* out,
-               hipStream_t stream) {
-  const size_t tables = ((size_t)pooled * (w + h) + 4 * pooled + 3) & ~(size_t)3;
-  const size_t lds = tables * 4 + (size_t)RCH * pooled * CC * 4;
-  static size_t configured = 0;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_fwd_sep<CC, RCH>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return frcnn::fail(FRCNN_ERR_LAUNCH, "roi_align_fwd: set LDS size: %s", hipGetErrorString(e));
-    configured = lds;
+template <int G>
+__global__ __launch_bounds__(256) void roi_align_fwd_planned(const float* __restrict__ feat, int H, int W, int C4,
+                                                             int nslices, const RoiPlanHead* __restrict__ head,
+                                                             const RoiItem* __restrict__ items,
+                                                             const float* __restrict__ wxt, const float* __restrict__ wyt,
+                                                             float* __restrict__ out) {
+  constexpr int P = PLAN_P;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wpad = plan_pad(W), hpad = plan_pad(H);
+  const int slice = blockIdx.x % nslices;              // this workgroup's channel slice
+  const int n_slice = head->total_items / nslices;     // items of one slice
+  const int nt = n_slice * P;                          // wave-items of the slice: t -> (item t / P, column bin t % P)
+  const int stride = (gridDim.x / nslices) * 4;        // waves working on the slice
+  const int c4 = slice * 64 + lane;
+  const bool active = c4 < C4;
+  const int cl = min(c4, C4 - 1);                      // inactive lanes read the last channel group and never store
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  struct Desc { int r, sp, flag, y0, y1, bimg, xlo, xhi, pw; float inv_count; };
+  struct Tab { float wx; float wy[P]; };
+  auto load_desc = [&](int t, Desc& d) {               // scalar loads: addresses depend on t only
+    d.flag = ROI_SKIP;
+    if (t < nt) {
+      const int e = t / P;
+      d.pw = t - e * P;
+      const RoiItem* it = items + (size_t)e * nslices + slice;
+      d.r = it->r; d.sp = it->sp; d.flag = it->flag; d.y0 = it->y0; d.y1 = it->y1; d.bimg = it->bimg;
+      d.inv_count = it->inv_count;
+      d.xlo = it->xlo[d.pw]; d.xhi = it->xhi[d.pw];
+    }
+  };
+  auto load_tab = [&](const Desc& d, Tab& tb) {        // vector loads: first column chunk, first row chunk
+    if (d.flag == ROI_LIGHT || d.flag == ROI_HEAVY) {
+      tb.wx = wxt[((size_t)d.r * P + d.pw) * wpad + lane];
+      const int yc = d.y0 & ~63;
+#pragma unroll
+      for (int ph = 0; ph < P; ++ph) {
+        const int bin = d.flag == ROI_HEAVY ? d.sp : ph;
+        tb.wy[ph] = (d.flag == ROI_LIGHT || ph == 0) ? wyt[((size_t)d.r * P + bin) * hpad + min(yc + lane, hpad - 1)] : 0.f;
+      }
+    }
+  };
+
+  int t = (blockIdx.x / nslices) * 4 + wave;
+  Desc d_cur, d_nxt;
+  Tab t_cur, t_nxt;
+  load_desc(t, d_cur);
+  load_desc(t + stride, d_nxt);
+  load_tab(d_cur, t_cur);
+  for (; t < nt; t += stride) {
+    load_tab(d_nxt, t_nxt);                            // tables of the next wave-item
+    Desc d_nn;
+    load_desc(t + 2 * stride, d_nn);                   // descriptor of the one after
+    // ---- pool wave-item (d_cur, t_cur) ---------------------------------------------------------------
+    {
+      const Desc& d = d_cur;
+      const int pw = d.pw;
+      const bool heavy = d.flag == ROI_HEAVY;
+      const int ph_begin = heavy ? d.sp : 0, nph = heavy ? 1 : P;
+      float4* ob = reinterpret_cast<float4*>(out) + ((size_t)d.r * P * P + pw) * C4 + c4;   // + ph * P * C4
+      if (d.flag == ROI_DEAD) {
+        if (active)
+#pragma unroll
+          for (int ph = 0; ph < P; ++ph) ob[(size_t)ph * P * C4] = zero4;
+      } else {
+        f32x2 acc[P][2];
+#pragma unroll
+        for (int ph = 0; ph < P; ++ph) acc[ph][0] = acc[ph][1] = f32x2{0.f, 0.f};
+        const int ncols_all = d.xhi - d.xlo + 1;
+        if (ncols_all > 0 && d.y1 >= d.y0) {
+          const float4* fbu = reinterpret_cast<const float4*>(feat) + (size_t)d.bimg * H * W * C4;   // wave-uniform
+          for (int xc = 0; xc < ncols_all; xc += 64) {           // column chunks of 64 (one weight per lane)
+            const int ncols = min(64, ncols_all - xc), xlo = d.xlo + xc;
+            const float wx = xc == 0 ? t_cur.wx : wxt[((size_t)d.r * P + pw) * wpad + xc + lane];
+            const int row_skip = (W - ncols) * C4;  // float4 units from the end of a window row to the next row's start
+            for (int yc = d.y0 & ~63; yc <= d.y1; yc += 64) {   // aligned row chunks of 64 (one weight per lane)
+              const int ys = max(yc, d.y0), ye = min(yc + 63, d.y1);
+              float wy[P];
+#pragma unroll
+              for (int ph = 0; ph < P; ++ph) {
+                wy[ph] = t_cur.wy[ph];
+                if (yc != (d.y0 & ~63) && ph < nph)
+                  wy[ph] = wyt[((size_t)d.r * P + ph_begin + ph) * hpad + min(yc + lane, hpad - 1)];
+              }
+              const int total = (ye - ys + 1) * ncols;
+              f32x2 T0 = {0.f, 0.f}, T1 = {0.f, 0.f};
+              int cy = ys - yc, cx = 0;                 // consume cursor: row relative to yc, column relative to xlo
+              int lx = 0, loff = (ys * W + xlo) * C4;   // load cursor: column and float4 offset (wave-uniform)
+              auto consume = [&](const float4& v) {
+                const float wgt = lane_bcast(wx, cx);
+                const f32x2 w2 = {wgt, wgt};
+                T0 = __builtin_elementwise_fma(w2, f32x2{v.x, v.y}, T0);
+                T1 = __builtin_elementwise_fma(w2, f32x2{v.z, v.w}, T1);
+                if (++cx == ncols) {
+#pragma unroll
+                  for (int ph = 0; ph < P; ++ph) {
+                    if (ph >= nph) continue;
+                    const float wr = lane_bcast(wy[ph], cy);
+                    const f32x2 r2 = {wr, wr};
+                    acc[ph][0] = __builtin_elementwise_fma(r2, T0, acc[ph][0]);
+                    acc[ph][1] = __builtin_elementwise_fma(r2, T1, acc[ph][1]);
+                  }
+                  T0 = T1 = f32x2{0.f, 0.f};
+                  cx = 0;
+                  ++cy;
+                }
+              };
+              int base = 0;
+              for (; base + G <= total; base += G) {    // full groups: G independent loads in flight per lane
+                float4 v[G];
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                  v[k] = (fbu + loff)[cl];
+                  loff += C4;
+                  if (++lx == ncols) { lx = 0; loff += row_skip; }
+                }
+#pragma unroll
+                for (int k = 0; k < G; ++k) consume(v[k]);
+              }
+              if (base < total) {                       // tail group
+                const int n = total - base;
+                float4 v[G];
+#pragma unroll
+                for (int k = 0; k < G - 1; ++k) {
+                  v[k] = zero4;
+                  if (k < n) {
+                    v[k] = (fbu + loff)[cl];
+                    loff += C4;
+                    if (++lx == ncols) { lx = 0; loff += row_skip; }
+                  }
+                }
+#pragma unroll
+                for (int k = 0; k < G - 1; ++k)
+                  if (k < n) consume(v[k]);
+              }
+            }
+          }
+        }
+        if (active)
+#pragma unroll
+          for (int ph = 0; ph < P; ++ph)
+            if (ph < nph)
+              ob[(size_t)(ph_begin + ph) * P * C4] =
+                  make_float4(acc[ph][0][0] * d.inv_count, acc[ph][0][1] * d.inv_count, acc[ph][1][0] * d.inv_count,
+                              acc[ph][1][1] * d.inv_count);
+      }
+    }
+    d_cur = d_nxt;
+    t_cur = t_nxt;
+    d_nxt = d_nn;
   }
-  hipLaunchKernelGGL((roi_align_fwd_sep<CC, RCH>), dim3((unsigned)(num_rois * (c / CC))), dim3(256), lds, stream, feat, h,
-                     w, c, rois, roi_count, num_rois, pooled, spatial_scale, sampling_ratio, level_of_roi, level, out);
-  return frcnn::check_launch("roi_align_fwd_sep");
 }
+
+size_t plan_bytes(int h, int w, int c, int num_rois) {
+  const int nslices = (c / 4 + 63) / 64;
+  return sizeof(RoiPlanHead) + (size_t)num_rois * PLAN_P * nslices * sizeof(RoiItem) +
+         (size_t)num_rois * PLAN_P * (plan_pad(w) + plan_pad(h)) * sizeof(float);
+}
+
+bool planned_ok(int pooled) { return pooled == PLAN_P; }
 
 }  // namespace
 
-// tuning hook: 0 = automatic, 1 = generic, 2 = generic with XCD channel slices, 3..6 = separable <32,12> <64,8> <64,16> <32,24>
+// tuning hook: 0 = automatic, 1 = generic, 2 = generic with XCD channel slices, 3 / 4 = planned kernel with 8 / 4 loads
+// in flight per lane (needs a workspace)
 static int g_roi_variant = 0;
+// estimated loads per lane above which a RoI is split into its P row bins (variant >= 100 sets it: tuning only)
+static int g_roi_heavy_loads = 64;
 extern "C" int frcnn_roi_align_set_variant(int v) {
+  if (v >= 100) { g_roi_heavy_loads = v; return FRCNN_OK; }
   g_roi_variant = v;
   return FRCNN_OK;
 }
 
+extern "C" size_t frcnn_roi_align_fwd_ws_bytes(int h, int w, int c, int num_rois, int pooled) {
+  if (h <= 0 || w <= 0 || c <= 0 || num_rois <= 0 || !planned_ok(pooled)) return 0;
+  return plan_bytes(h, w, c, num_rois);
+}
+
 extern "C" int frcnn_roi_align_fwd(const float* feat, int h, int w, int c, const float* rois, const int* roi_count,
                                    int num_rois, int pooled, float spatial_scale, int sampling_ratio,
-                                   const int* level_of_roi, int level, float* out, void* stream_) {
+                                   const int* level_of_roi, int level, float* out, void* ws, size_t ws_bytes,
+                                   void* stream_) {
   FRCNN_REQUIRE(feat && rois && out && h > 0 && w > 0 && c > 0 && c % 4 == 0 && num_rois > 0 && pooled > 0,
                 "roi_align_fwd: bad arguments (c%%4==0)");
-  // separable kernel: needs the 7x7-style item count to fit the per-thread bin ownership (pooled*pooled*CC/4 <= 1024)
-  // and the weight tables to fit in LDS next to the row chunk
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const bool sep_ok = pooled <= 8 && (size_t)pooled * (w + h) * 4 < 48 * 1024;
-  if (sep_ok && c % 64 == 0 && g_roi_variant == 4)
-    return launch_sep<64, 8>(feat, h, w, c, rois, roi_count, num_rois, pooled, spatial_scale, sampling_ratio, level_of_roi,
-                             level, out, stream);
-  if (sep_ok && c % 64 == 0 && (g_roi_variant == 0 || g_roi_variant == 5))   // measured best (round 1)
-    return launch_sep<64, 16>(feat, h, w, c, rois, roi_count, num_rois, pooled, spatial_scale, sampling_ratio,
-                              level_of_roi, level, out, stream);
-  if (sep_ok && c % 32 == 0 && (g_roi_variant == 0 || g_roi_variant == 3))
-    return launch_sep<32, 12>(feat, h, w, c, rois, roi_count, num_rois, pooled, spatial_scale, sampling_ratio,
-                              level_of_roi, level, out, stream);
-  if (sep_ok && c % 32 == 0 && g_roi_variant == 6)
-    return launch_sep<32, 24>(feat, h, w, c, rois, roi_count, num_rois, pooled, spatial_scale, sampling_ratio,
-                              level_of_roi, level, out, stream);
+  const bool want_planned = g_roi_variant == 0 || g_roi_variant >= 3;
+  if (want_planned && planned_ok(pooled) && ws && ws_bytes >= plan_bytes(h, w, c, num_rois)) {
+    const int c4 = c / 4, nslices = (c4 + 63) / 64;
+    RoiPlanHead* head = static_cast<RoiPlanHead*>(ws);
+    RoiItem* items = reinterpret_cast<RoiItem*>(head + 1);
+    float* wxt = reinterpret_cast<float*>(items + (size_t)num_rois * PLAN_P * nslices);
+    float* wyt = wxt + (size_t)num_rois * PLAN_P * plan_pad(w);
+    hipLaunchKernelGGL(roi_plan_kernel, dim3((unsigned)num_rois), dim3(64 * 2 * PLAN_P), 0, stream, h, w, rois, roi_count,
+                       num_rois, spatial_scale, sampling_ratio, level_of_roi, level, nslices, g_roi_heavy_loads, head, items, wxt,
+                       wyt);
+    int rc = frcnn::check_launch("roi_plan_kernel");
+    if (rc != FRCNN_OK) return rc;
+    // persistent grid of 4-wave workgroups: 5 per CU (<= 96 VGPRs), a multiple of nslices so that a workgroup keeps
+    // its slice; never more waves than wave-items in the worst case
+    const long max_wave_items = (long)num_rois * nslices * PLAN_P * PLAN_P;
+    long nwg = 256 * 5;
+    nwg = std::min(nwg, (max_wave_items + 3) / 4);
+    nwg = std::max<long>(nslices, nwg / nslices * nslices);
+    if (g_roi_variant == 4)
+      hipLaunchKernelGGL(roi_align_fwd_planned<4>, dim3((unsigned)nwg), dim3(256), 0, stream, feat, h, w, c4, nslices, head,
+                         items, wxt, wyt, out);
+    else
+      hipLaunchKernelGGL(roi_align_fwd_planned<8>, dim3((unsigned)nwg), dim3(256), 0, stream, feat, h, w, c4, nslices, head,
+                         items, wxt, wyt, out);
+    return frcnn::check_launch("roi_align_fwd_planned");
+  }
   const size_t total = (size_t)num_rois * pooled * pooled * (c / 4);
   if (g_roi_variant != 1 && c % 32 == 0) {   // 8 channel slices of c/8 channels, one per XCD; grid = multiple of 8
     const size_t per_slice_blocks = std::min<size_t>((total / 8 + 255) / 256, (size_t)1 << 17);
-    hipLaunchKernelGGL(roi_align_fwd_nhwc<true>, dim3((unsigned)(per_slice_blocks * 8)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream_), feat, h, w, c / 4, rois, roi_count, num_rois, pooled,
-                       spatial_scale, sampling_ratio, level_of_roi, level, out);
+    hipLaunchKernelGGL(roi_align_fwd_nhwc<true>, dim3((unsigned)(per_slice_blocks * 8)), dim3(256), 0, stream, feat, h, w,
+                       c / 4, rois, roi_count, num_rois, pooled, spatial_scale, sampling_ratio, level_of_roi, level, out);
     return frcnn::check_launch("roi_align_fwd_nhwc<xcd>");
   }
   const size_t blocks = std::min<size_t>((total + 255) / 256, (size_t)1 << 20);
-  hipLaunchKernelGGL(roi_align_fwd_nhwc<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream_),
-                     feat, h, w, c / 4, rois, roi_count, num_rois, pooled, spatial_scale, sampling_ratio, level_of_roi,
-                     level, out);
+  hipLaunchKernelGGL(roi_align_fwd_nhwc<false>, dim3((unsigned)blocks), dim3(256), 0, stream, feat, h, w, c / 4, rois,
+                     roi_count, num_rois, pooled, spatial_scale, sampling_ratio, level_of_roi, level, out);
   return frcnn::check_launch("roi_align_fwd_nhwc");
 }

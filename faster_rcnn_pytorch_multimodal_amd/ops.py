@@ -335,9 +335,11 @@ def roi_align_nhwc(feat, rois, pooled, spatial_scale, sampling_ratio=0, roi_coun
     r = rois.shape[0]
     if out is None:
         out = torch.empty((r, pooled, pooled, c), dtype=torch.float32, device=feat.device)
+    ws_bytes = lib.frcnn_roi_align_fwd_ws_bytes(h, w, c, r, pooled)
+    ws = _workspace(ws_bytes, feat.device) if ws_bytes else None
     _hip.check(lib.frcnn_roi_align_fwd(_ptr(feat), h, w, c, _ptr(rois), _ptr(roi_count), r, pooled, float(spatial_scale),
-                                       int(sampling_ratio), _ptr(level_of_roi), level, _ptr(out), _stream()),
-               "frcnn_roi_align_fwd")
+                                       int(sampling_ratio), _ptr(level_of_roi), level, _ptr(out), _ptr(ws), ws_bytes,
+                                       _stream()), "frcnn_roi_align_fwd")
     return out
 
 

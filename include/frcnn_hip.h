@@ -186,11 +186,16 @@ int frcnn_make_rois(const float* sorted_boxes, const float* sorted_scores, const
  * >= count to zero.  level_of_roi/level (may be NULL/-1): only rois with level_of_roi[r]==level
  * are written (MultiScaleRoIAlign, torchpoolers.py:187-199).
  * ------------------------------------------------------------------------------------------- */
-/* Tuning / test hook: 0 automatic, 1 generic kernel, 2 generic with per-XCD channel slices, 3 separable kernel. */
+/* Tuning / test hook: 0 automatic, 1 generic kernel, 2 generic with per-XCD channel slices, 3 / 4 planned kernel with
+ * 8 / 4 loads in flight per lane. */
 int frcnn_roi_align_set_variant(int variant);
+/* Scratch for the planned (fast) kernel pair: the compact work-item list + the per-bin axis weight tables.  Returns 0
+ * when the shape has no fast path (pooled != 7: the generic kernel needs no scratch).  Passing ws == NULL to
+ * frcnn_roi_align_fwd is always valid and selects the generic kernel. */
+size_t frcnn_roi_align_fwd_ws_bytes(int h, int w, int c, int num_rois, int pooled);
 int frcnn_roi_align_fwd(const float* feat, int h, int w, int c, const float* rois, const int* roi_count,
                         int num_rois, int pooled, float spatial_scale, int sampling_ratio,
-                        const int* level_of_roi, int level, float* out, void* stream);
+                        const int* level_of_roi, int level, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* LevelMapper (lib/utils/torchpoolers.py:20-51) of MultiScaleRoIAlign: levels[i] = clamp(floor(canonical_level +
  * log2(sqrt(area_i) / canonical_scale) + eps), k_min, k_max) - k_min for rois (n,5); area without +1. */

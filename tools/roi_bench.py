@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """RoIAlign tuning aid: the RoIs of one bench frame (res101, 1000x600), their sampling-grid statistics and the time of
-each kernel variant (frcnn_roi_align_set_variant).  python tools/roi_bench.py [--reps 50]"""
+each kernel variant (frcnn_roi_align_set_variant: 1 / 2 generic, 3 / 4 planned with 8 / 4 loads in flight).  python tools/roi_bench.py [--reps 50]"""
 import argparse
 import os
 import sys
@@ -15,14 +15,17 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=50)
-    ap.add_argument("--variants", default="1,2,3")
+    ap.add_argument("--variants", default="2,3,4")
     ap.add_argument("--typical", action="store_true", help="also time seeded boxes of 32..320 px (what a trained RPN "
                     "proposes) and a plain 60 MB fill (the write floor of the op)")
+    ap.add_argument("--heavy", type=int, default=0, help="heavy-RoI threshold (loads per lane, >= 100)")
     args = ap.parse_args()
     import bench
     from faster_rcnn_pytorch_multimodal_amd import _hip, ops
     from faster_rcnn_pytorch_multimodal_amd.model.test import detect_frame_device
     lib = _hip.load()
+    if args.heavy:
+        lib.frcnn_roi_align_set_variant(args.heavy)
     net, _ = bench.build_net("cuda:0")
     info = np.array([0, bench.W, 0, bench.H, 0, 0, 1.0], np.float32)
     detect_frame_device(net, torch.from_numpy(bench.synthetic_frame(0)).cuda(), info, bench.THRESH, bench.MAX_DETS, bench.MAX_DETS)
