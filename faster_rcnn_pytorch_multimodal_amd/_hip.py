@@ -58,6 +58,7 @@ PROTOTYPES = {
     "frcnn_head_fc_softmax_decode_lidar": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P,
                                                    POINTER(c_float), POINTER(c_float), c_float, _P, _P, _P, _P, _P, _P]),
     "frcnn_generate_anchors_3d": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "frcnn_filter_set_variant": (c_int, [c_int]),
     "frcnn_filter_per_class_lidar": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, c_int, c_int, _P, _P, _P,
                                              c_size_t, _P]),
     "frcnn_act_bwd": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, _P]),

@@ -2,6 +2,8 @@
 // Built with -ffp-contract=off (see box_math.h).  These are HBM/latency-bound integer/bit kernels:
 // wave64 ballots/readlanes and LDS sorting, no matrix cores.
 #include "common.h"
+
+#include <atomic>
 #include "box_math.h"
 
 using namespace frcnn;
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_topk_desc_kernel(const floa
 //   topk_count_eq_kernel  per-workgroup count of keys == kth over a contiguous index range
 //   topk_scan_eq_kernel   exclusive scan of those counts (ties are taken lowest index first)
 //   topk_compact_kernel   keys < kth (any slot) and the first need_eq ties (ordered slots) -> u64 candidates
-//   topk_final_sort_kernel  bitonic sort of the <= 16384 candidates in LDS, outputs in the canonical order
+//   topk_rank_sort_kernel   every CU ranks 16 candidates against all <= 16384 of them; outputs in the canonical order
 // ------------------------------------------------------------------------------------------------
 constexpr int TOPK_BINS = 2048;
 constexpr int TOPK_BLOCK_ITEMS = 4096;  // scores per workgroup (256 threads x 16)
@@ -358,22 +360,41 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(const float* __restri
   }
 }
 
-__global__ __launch_bounds__(SORT_THREADS) void topk_final_sort_kernel(const float* __restrict__ scores,
-                                                                       const uint64_t* __restrict__ cand, int take,
-                                                                       int npad, int64_t* __restrict__ order_out,
-                                                                       float* __restrict__ scores_out,
-                                                                       int* __restrict__ count_out) {
+// Final ordering of the <= 16384 selected candidates by RANK: keys are unique (the index is in the low word), so the
+// position of a key in the sorted order is the number of candidates smaller than it.  One workgroup ranks 16 keys:
+// thread (key k, partition p) counts the keys of partition p below key k against an LDS copy of all candidates
+// (16 lanes read the same LDS word: broadcast), the 16 partial counts of a key are summed in a fixed order, and the
+// key is scattered to its rank.  n^2 / 2^12 compares per thread on every CU of the chip (6000 candidates: 375
+// workgroups, ~4 us) instead of a 91-stage bitonic network inside ONE workgroup (78 us, profiles/r01h_kernel_stats.md).
+constexpr int RANK_KEYS = 16, RANK_PARTS = 16;
+__global__ __launch_bounds__(RANK_KEYS * RANK_PARTS) void topk_rank_sort_kernel(const float* __restrict__ scores,
+                                                                              const uint64_t* __restrict__ cand, int take,
+                                                                              int64_t* __restrict__ order_out,
+                                                                              float* __restrict__ scores_out,
+                                                                              int* __restrict__ count_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sort_smem[];
-  uint64_t* keys = reinterpret_cast<uint64_t*>(sort_smem);
-  for (int i = threadIdx.x; i < npad; i += SORT_THREADS) keys[i] = i < take ? cand[i] : ~0ull;
+  uint64_t* keys = reinterpret_cast<uint64_t*>(sort_smem);          // [take]
+  __shared__ uint32_t part[RANK_PARTS][RANK_KEYS];
+  for (int i = threadIdx.x; i < take; i += blockDim.x) keys[i] = cand[i];
   __syncthreads();
-  block_bitonic_sort(keys, npad);
-  for (int i = threadIdx.x; i < take; i += SORT_THREADS) {
-    const uint32_t idx = (uint32_t)(keys[i] & 0xFFFFFFFFu);
-    order_out[i] = (int64_t)idx;
-    scores_out[i] = scores[idx];
+  const int k = threadIdx.x & (RANK_KEYS - 1), p = threadIdx.x / RANK_KEYS;
+  const int ki = blockIdx.x * RANK_KEYS + k;
+  const uint64_t mine = ki < take ? keys[ki] : 0ull;
+  const int per = (take + RANK_PARTS - 1) / RANK_PARTS;
+  const int lo = min(p * per, take), hi = min(lo + per, take);
+  uint32_t below = 0;
+  for (int j = lo; j < hi; ++j) below += keys[j] < mine ? 1u : 0u;
+  part[p][k] = below;
+  __syncthreads();
+  if (p == 0 && ki < take) {
+    uint32_t rank = 0;
+#pragma unroll
+    for (int q = 0; q < RANK_PARTS; ++q) rank += part[q][k];
+    const uint32_t idx = (uint32_t)(mine & 0xFFFFFFFFu);
+    order_out[rank] = (int64_t)idx;
+    scores_out[rank] = scores[idx];
   }
-  if (threadIdx.x == 0) count_out[0] = take;
+  if (blockIdx.x == 0 && threadIdx.x == 0) count_out[0] = take;
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ rows,
@@ -553,6 +574,103 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_class_kernel(
   if (t == 0) det_count[cls] = kept;
 }
 
+// Same per-class filter for num_rois <= 1024 (every detector of the reference: 300 test-time RoIs), entirely in LDS
+// with 16 waves.  The general kernel above spent 161 us per frame on ONE workgroup of 4 waves: a 45-stage bitonic
+// sort of 512 keys, a suppression matrix with one thread looping over the 64 IoUs of a word, and a greedy scan whose
+// row fetches each paid a global-memory round trip.  Here: keys are ranked (unique keys: position = number of smaller
+// keys, n broadcast LDS reads per thread, no stage barriers), one WAVE builds a matrix word with one IoU per lane and a
+// ballot, and the matrix (n x ceil(n/64) words) stays in LDS for the scan.  Same order, same IoU test, same outputs.
+constexpr int FILTER_SMALL_THREADS = 1024, FILTER_SMALL_MAX = 1024;
+
+template <int E>
+__global__ __launch_bounds__(FILTER_SMALL_THREADS) void filter_class_small_kernel(
+    const float* __restrict__ pred_boxes, const float* __restrict__ cls_prob, const int* __restrict__ roi_count,
+    int num_rois, int num_classes, float thresh, float nms_thresh, int max_dets, int max_out, float* __restrict__ dets,
+    int* __restrict__ det_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char filt_smem[];
+  // LDS: raw keys [num_rois] | sorted keys [num_rois] | boxes [num_rois] float4 | keep_idx [num_rois] i64 | mask [n][nbl] u64
+  uint64_t* raw = reinterpret_cast<uint64_t*>(filt_smem);
+  uint64_t* keys = raw + num_rois;
+  float4* sboxes = reinterpret_cast<float4*>(keys + num_rois);
+  int64_t* keep_idx = reinterpret_cast<int64_t*>(sboxes + num_rois);
+  uint64_t* mask = reinterpret_cast<uint64_t*>(keep_idx + num_rois);
+  __shared__ int s_n, s_keep;
+  const int cls = blockIdx.x + 1;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int R = roi_count ? min(*roi_count, num_rois) : num_rois;
+  if (t == 0) s_n = 0;
+  __syncthreads();
+  // inds = scores[:, c] > thresh  (filter_predictions.py:46)
+  for (int r = t; r < R; r += FILTER_SMALL_THREADS) {
+    const float sc = cls_prob[(size_t)r * num_classes + cls];
+    if (sc > thresh) raw[atomicAdd(&s_n, 1)] = ((uint64_t)desc_key(sc) << 32) | (uint32_t)r;
+  }
+  __syncthreads();
+  const int n = s_n;
+  // (score desc, roi index asc): rank = number of smaller keys
+  for (int i = t; i < n; i += FILTER_SMALL_THREADS) {
+    const uint64_t mine = raw[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += raw[j] < mine ? 1 : 0;
+    keys[rank] = mine;
+    const uint32_t r = (uint32_t)(mine & 0xFFFFFFFFu);
+    const float* pb = pred_boxes + ((size_t)r * num_classes + cls) * E;
+    sboxes[rank] = E == 4 ? make_float4(pb[0], pb[1], pb[2], pb[3])
+                          : make_float4(pb[0] - pb[3] / 2.0f, pb[1] - pb[4] / 2.0f, pb[0] + pb[3] / 2.0f,
+                                        pb[1] + pb[4] / 2.0f);
+  }
+  __syncthreads();
+  // suppression bit-matrix (words on/right of the diagonal): one wave per word, one IoU per lane
+  const int nbl = (n + 63) / 64;
+  for (int wi = wave; wi < n * nbl; wi += FILTER_SMALL_THREADS / 64) {
+    const int i = wi / nbl, w = wi - i * nbl;
+    if (w < (i >> 6)) continue;
+    const int j = w * 64 + lane;
+    const float4 bi = sboxes[i];
+    bool hit = false;
+    if (j < n && j > i) {
+      const float4 bj = sboxes[j];
+      const float a[4] = {bi.x, bi.y, bi.z, bi.w}, b[4] = {bj.x, bj.y, bj.z, bj.w};
+      hit = iou_gt(a, b, nms_thresh);
+    }
+    const uint64_t bits = __ballot(hit);
+    if (lane == 0) mask[(size_t)i * nbl + w] = bits;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int cnt = wave_nms_scan(mask, nbl, n, n, keep_idx, nullptr);
+    if (lane == 0) s_keep = cnt;
+  }
+  __syncthreads();
+  int kept = s_keep;
+  // test.py:213-221: if more than max_dets survive keep score >= the max_dets-th best (ties stay)
+  if (max_dets > 0 && kept > max_dets) {
+    const uint32_t cut = (uint32_t)(keys[keep_idx[max_dets - 1]] >> 32);     // ascending key = descending score
+    int m = max_dets;
+    while (m < kept && (uint32_t)(keys[keep_idx[m]] >> 32) <= cut) ++m;
+    kept = m;
+  }
+  kept = min(kept, max_out);
+  float* out = dets + (size_t)cls * max_out * (E + 1);
+  for (int i = t; i < max_out; i += FILTER_SMALL_THREADS) {
+    float v[E + 1];
+    for (int q = 0; q <= E; ++q) v[q] = 0.f;
+    if (i < kept) {
+      const uint32_t r = (uint32_t)(keys[keep_idx[i]] & 0xFFFFFFFFu);
+      const float* pb = pred_boxes + ((size_t)r * num_classes + cls) * E;
+      for (int q = 0; q < E; ++q) v[q] = pb[q];
+      v[E] = cls_prob[(size_t)r * num_classes + cls];
+    }
+    for (int q = 0; q <= E; ++q) out[i * (E + 1) + q] = v[q];
+  }
+  if (t == 0) det_count[cls] = kept;
+}
+
+static size_t filter_small_lds(int num_rois) {
+  const size_t nb = (size_t)(num_rois + 63) / 64;
+  return (size_t)num_rois * (8 + 8 + 16 + 8) + (size_t)num_rois * nb * 8;
+}
+
 // bbox_transform_inv for (N boxes) x (Kc classes) — lib/model/bbox_transform.py:75-105 — and clip_boxes
 // (:235-257) as stand-alone entry points (the proposal / head kernels fuse the same arithmetic).
 __global__ __launch_bounds__(256) void bbox_transform_inv_kernel(const float* __restrict__ boxes, int box_ld,
@@ -696,17 +814,17 @@ extern "C" int frcnn_sort_topk_desc(const float* scores, int n, int top_n, int64
     hipLaunchKernelGGL(topk_compact_kernel, dim3(nblocks), dim3(256), 0, stream, scores, n, take, st, block_eq, cand);
     int rc = check_launch("topk multi-workgroup select");
     if (rc != FRCNN_OK) return rc;
-    const size_t lds = (size_t)npad * 8;
-    static size_t configured_f = 0;
-    if (lds > configured_f) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_final_sort_kernel),
+    const size_t lds = (size_t)take * 8;
+    static std::atomic<size_t> configured_f{0};
+    if (lds > configured_f.load()) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_rank_sort_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "sort_topk_desc: set LDS size: %s", hipGetErrorString(e));
-      configured_f = lds;
+      configured_f.store(lds);
     }
-    hipLaunchKernelGGL(topk_final_sort_kernel, dim3(1), dim3(SORT_THREADS), lds, stream, scores, cand, take, npad,
-                       order_out, scores_out, count_out);
-    return check_launch("topk_final_sort_kernel");
+    hipLaunchKernelGGL(topk_rank_sort_kernel, dim3((take + RANK_KEYS - 1) / RANK_KEYS), dim3(RANK_KEYS * RANK_PARTS), lds,
+                       stream, scores, cand, take, order_out, scores_out, count_out);
+    return check_launch("topk_rank_sort_kernel");
   }
   const size_t lds = (size_t)npad * 8 + 256 * 4 + SORT_THREADS * 4;
   static size_t configured = 0;
@@ -767,6 +885,13 @@ extern "C" int frcnn_make_rois(const float* sorted_boxes, const float* sorted_sc
   return check_launch("make_rois_kernel");
 }
 
+// test hook: 0 = automatic (LDS kernel for num_rois <= 1024), 1 = always the general kernel
+static int g_filter_variant = 0;
+extern "C" int frcnn_filter_set_variant(int v) {
+  g_filter_variant = v;
+  return FRCNN_OK;
+}
+
 static size_t filter_ws_per_class(int num_rois) {
   const size_t nb = (size_t)(num_rois + 63) / 64;
   return align_up(align_up((size_t)num_rois * 16, 16) + (size_t)num_rois * nb * 8 + (size_t)num_rois * 8, 16);
@@ -796,18 +921,32 @@ static int launch_filter(float* pred_boxes, const float* cls_prob, const int* ro
     int rc = check_launch("clamp_pred_boxes_kernel");
     if (rc != FRCNN_OK) return rc;
   }  // LiDAR boxes are not clamped (filter_predictions.py:92-93)
+  hipError_t e = hipMemsetAsync(det_count, 0, sizeof(int) * num_classes, stream);
+  if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "filter_per_class: memset: %s", hipGetErrorString(e));
+  if (num_rois <= FILTER_SMALL_MAX && filter_small_lds(num_rois) <= (size_t)150 * 1024 && g_filter_variant != 1) {
+    const size_t lds = filter_small_lds(num_rois);
+    static std::atomic<size_t> configured_s{0};
+    if (lds > configured_s.load()) {
+      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_class_small_kernel<E>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e2 != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "filter_per_class: set LDS size: %s", hipGetErrorString(e2));
+      configured_s.store(lds);
+    }
+    hipLaunchKernelGGL(filter_class_small_kernel<E>, dim3(num_classes - 1), dim3(FILTER_SMALL_THREADS), lds, stream,
+                       pred_boxes, cls_prob, roi_count, num_rois, num_classes, thresh, nms_thresh, max_dets, max_out, dets,
+                       det_count);
+    return check_launch("filter_class_small_kernel");
+  }
   const int npad = next_pow2(std::max(num_rois, 2));
   const int nb = (num_rois + 63) / 64;
   const size_t lds = (size_t)npad * 8;
-  static size_t configured = 0;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_class_kernel<E>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "filter_per_class: set LDS size: %s", hipGetErrorString(e));
-    configured = lds;
+  static std::atomic<size_t> configured{0};
+  if (lds > configured.load()) {
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_class_kernel<E>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e2 != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "filter_per_class: set LDS size: %s", hipGetErrorString(e2));
+    configured.store(lds);
   }
-  hipError_t e = hipMemsetAsync(det_count, 0, sizeof(int) * num_classes, stream);
-  if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "filter_per_class: memset: %s", hipGetErrorString(e));
   hipLaunchKernelGGL(filter_class_kernel<E>, dim3(num_classes - 1), dim3(FILTER_THREADS), lds, stream, pred_boxes,
                      cls_prob, roi_count, num_rois, num_classes, thresh, nms_thresh, max_dets, max_out, npad, nb, dets,
                      det_count, static_cast<unsigned char*>(ws), filter_ws_per_class(num_rois));

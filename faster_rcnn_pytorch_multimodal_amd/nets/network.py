@@ -308,10 +308,15 @@ class Network(nn.Module):
             return linear_train(h, self.t_fc3, relu=True)
         if torch.is_grad_enabled() and self._mode == 'TRAIN':
             return spatial_mean_train(self._layer4(to_nhwc(pool5)))      # Bottleneck nodes + mean, all differentiable
+        # layer4 output (R,7,7,2048) -> fc7 in a chip-wide streaming pass (HBM-bound, 120 MB at 300 RoIs), then the
+        # heads on fc7 alone: one workgroup per RoI doing both needed 72 us (profiles/r01h_kernel_stats.md)
         y = self._layer4(to_nhwc(pool5))
-        out = self._tail_kernel(y, self._predictions['rois'])
+        fc7 = ops.spatial_mean(y)
+        r, c = fc7.shape
+        out = self._tail_kernel(fc7.view(r, 1, 1, c), self._predictions['rois'])
+        out['fc7'] = fc7
         self._predictions['_tail'] = out
-        return out['fc7']
+        return fc7
 
     def _region_classification(self, fc7):
         """cls_score_net + softmax, bbox_pred_net.  Returns (cls_prob, bbox_pred) like the ancestor."""

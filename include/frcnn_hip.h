@@ -231,6 +231,8 @@ int frcnn_head_fc_softmax_decode_lidar(const float* x, int num_rois, int pooled,
  * clamp to [0, frame/scale-1] in place, per class j>=1 keep score > thresh, NMS(nms_thresh) in
  * descending score order, keep dets with score >= the max_dets-th best.
  * dets (K, max_out, 5) [x1,y1,x2,y2,score], det_count (K) ints. roi_count device int or NULL. */
+/* Test hook: 0 = automatic (num_rois <= 1024: LDS-resident kernel), 1 = always the general workspace kernel. */
+int frcnn_filter_set_variant(int variant);
 size_t frcnn_filter_per_class_ws_bytes(int num_rois, int num_classes);
 int frcnn_filter_per_class(float* pred_boxes, const float* cls_prob, const int* roi_count, int num_rois,
                            int num_classes, float frame_w, float frame_h, float scale, float thresh,

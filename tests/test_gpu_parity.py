@@ -385,11 +385,15 @@ def test_head_fc_softmax_decode(hip):
     np.testing.assert_allclose(out["pred_boxes"].cpu().numpy(), pred.numpy(), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("r,variant", [(300, 0), (300, 1), (1024, 0), (1500, 0), (37, 0)])
 @pytest.mark.parametrize("thresh,max_dets", [(0.1, 100), (0.5, 100), (0.05, 20), (0.999, 100)])
-def test_filter_per_class_matches_oracle(hip, thresh, max_dets):
+def test_filter_per_class_matches_oracle(hip, thresh, max_dets, r, variant):
+    """variant 0: LDS-resident kernel for r <= 1024 (rank sort, wave-per-word ballot matrix), the general workspace kernel
+    above that; variant 1 forces the general kernel.  Both must reproduce the oracle's rows exactly."""
     from faster_rcnn_pytorch_multimodal_amd.utils.filter_predictions import filter_device
     g = torch.Generator().manual_seed(int(thresh * 1000) + max_dets)
-    r, k = 300, 3
+    k = 3
+    hip.frcnn_filter_set_variant(variant)
     info = np.array([0, 1000, 0, 600, 0, 0, 1.0], np.float32)
     prob = F.softmax(torch.randn(r, k, generator=g) * 2, 1)
     prob[5:9, 1] = prob[5, 1]                                  # score ties
@@ -413,6 +417,7 @@ def test_filter_per_class_matches_oracle(hip, thresh, max_dets):
             want = want[np.lexsort((np.arange(len(want)), -want[:, 4]))]
             np.testing.assert_array_equal(got, want)
     assert counts[0] == 0
+    hip.frcnn_filter_set_variant(0)
 
 
 def test_empty_and_degenerate_inputs(hip):
