@@ -59,7 +59,7 @@ PROTOTYPES = {
                                                    POINTER(c_float), POINTER(c_float), c_float, _P, _P, _P, _P, _P, _P]),
     "frcnn_generate_anchors_3d": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "frcnn_filter_set_variant": (c_int, [c_int]),
-    "frcnn_filter_per_class_lidar": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, c_int, c_int, _P, _P, _P,
+    "frcnn_filter_per_class_lidar": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, c_int, c_int, _P, _P, _P, _P,
                                              c_size_t, _P]),
     "frcnn_act_bwd": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, _P]),
     "frcnn_bev_voxelize_grid": (c_int, [POINTER(c_float), POINTER(c_float), POINTER(c_int)]),
@@ -83,7 +83,14 @@ PROTOTYPES = {
     "frcnn_det_loss_aleatoric": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, POINTER(c_float), c_int, c_float,
                                          c_float, _P, _P, _P, _P, _P]),
     "frcnn_mc_bbox_var": (c_int, [_P, c_int, c_int64, _P, _P]),
-    "frcnn_mc_cls_stats": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "frcnn_mc_cls_stats": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "frcnn_mc_mean": (c_int, [_P, c_int, c_int64, _P, _P]),
+    "frcnn_dropout_fwd": (c_int, [_P, c_int64, c_int, c_float, c_uint32, c_uint32, _P, _P]),
+    "frcnn_dropout_bwd": (c_int, [_P, c_int64, c_int, c_float, c_uint32, c_uint32, _P, _P]),
+    "frcnn_logit_distort": (c_int, [_P, _P, c_int64, c_int, c_uint32, c_uint32, c_int, _P, _P, _P]),
+    "frcnn_bayesian_cross_entropy": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_uint32, c_uint32, c_int, c_float, _P, _P, _P,
+                                             _P, _P]),
+    "frcnn_exp": (c_int, [_P, c_int64, _P, _P]),
     "frcnn_bbox_overlaps": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, _P]),
     "frcnn_anchor_target_layer_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "frcnn_anchor_target_layer": (c_int, [_P, c_int, _P, c_int, POINTER(c_float), c_int, c_float, c_float, c_float,
@@ -96,7 +103,7 @@ PROTOTYPES = {
                                                   _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "frcnn_filter_per_class_ws_bytes": (c_size_t, [c_int, c_int]),
     "frcnn_filter_per_class": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int,
-                                       c_int, _P, _P, _P, c_size_t, _P]),
+                                       c_int, _P, _P, _P, _P, c_size_t, _P]),
 }
 
 

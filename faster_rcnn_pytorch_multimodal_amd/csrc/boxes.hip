@@ -490,7 +490,8 @@ template <int E>
 __global__ __launch_bounds__(FILTER_THREADS) void filter_class_kernel(
     const float* __restrict__ pred_boxes, const float* __restrict__ cls_prob, const int* __restrict__ roi_count,
     int num_rois, int num_classes, float thresh, float nms_thresh, int max_dets, int max_out, int npad, int nb,
-    float* __restrict__ dets, int* __restrict__ det_count, unsigned char* __restrict__ ws, size_t ws_per_class) {
+    float* __restrict__ dets, int* __restrict__ det_count, int* __restrict__ det_roi, unsigned char* __restrict__ ws,
+    size_t ws_per_class) {
   extern __shared__ __attribute__((aligned(16))) unsigned char filt_smem[];
   uint64_t* keys = reinterpret_cast<uint64_t*>(filt_smem);  // [npad]
   __shared__ int s_n, s_keep;
@@ -562,14 +563,17 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_class_kernel(
   for (int i = t; i < max_out; i += FILTER_THREADS) {
     float v[E + 1];
     for (int q = 0; q <= E; ++q) v[q] = 0.f;
+    int roi = -1;
     if (i < kept) {
       const int64_t k = keep_idx[i];
       const uint32_t r = (uint32_t)(keys[k] & 0xFFFFFFFFu);
       const float* pb = pred_boxes + ((size_t)r * num_classes + cls) * E;
       for (int q = 0; q < E; ++q) v[q] = pb[q];
       v[E] = cls_prob[(size_t)r * num_classes + cls];
+      roi = (int)r;
     }
     for (int q = 0; q <= E; ++q) out[i * (E + 1) + q] = v[q];
+    if (det_roi) det_roi[(size_t)cls * max_out + i] = roi;
   }
   if (t == 0) det_count[cls] = kept;
 }
@@ -586,7 +590,7 @@ template <int E>
 __global__ __launch_bounds__(FILTER_SMALL_THREADS) void filter_class_small_kernel(
     const float* __restrict__ pred_boxes, const float* __restrict__ cls_prob, const int* __restrict__ roi_count,
     int num_rois, int num_classes, float thresh, float nms_thresh, int max_dets, int max_out, float* __restrict__ dets,
-    int* __restrict__ det_count) {
+    int* __restrict__ det_count, int* __restrict__ det_roi) {
   extern __shared__ __attribute__((aligned(16))) unsigned char filt_smem[];
   // LDS: raw keys [num_rois] | sorted keys [num_rois] | boxes [num_rois] float4 | keep_idx [num_rois] i64 | mask [n][nbl] u64
   uint64_t* raw = reinterpret_cast<uint64_t*>(filt_smem);
@@ -655,13 +659,16 @@ __global__ __launch_bounds__(FILTER_SMALL_THREADS) void filter_class_small_kerne
   for (int i = t; i < max_out; i += FILTER_SMALL_THREADS) {
     float v[E + 1];
     for (int q = 0; q <= E; ++q) v[q] = 0.f;
+    int roi = -1;
     if (i < kept) {
       const uint32_t r = (uint32_t)(keys[keep_idx[i]] & 0xFFFFFFFFu);
       const float* pb = pred_boxes + ((size_t)r * num_classes + cls) * E;
       for (int q = 0; q < E; ++q) v[q] = pb[q];
       v[E] = cls_prob[(size_t)r * num_classes + cls];
+      roi = (int)r;
     }
     for (int q = 0; q <= E; ++q) out[i * (E + 1) + q] = v[q];
+    if (det_roi) det_roi[(size_t)cls * max_out + i] = roi;
   }
   if (t == 0) det_count[cls] = kept;
 }
@@ -905,7 +912,7 @@ extern "C" size_t frcnn_filter_per_class_ws_bytes(int num_rois, int num_classes)
 template <int E>
 static int launch_filter(float* pred_boxes, const float* cls_prob, const int* roi_count, int num_rois, int num_classes,
                          float frame_w, float frame_h, float scale, float thresh, float nms_thresh, int max_dets,
-                         int max_out, float* dets, int* det_count, void* ws, size_t ws_bytes, void* stream_) {
+                         int max_out, float* dets, int* det_count, int* det_roi, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   FRCNN_REQUIRE(pred_boxes && cls_prob && dets && det_count && num_rois > 0 && num_classes > 1 && max_out > 0,
                 "filter_per_class: bad arguments");
@@ -934,7 +941,7 @@ static int launch_filter(float* pred_boxes, const float* cls_prob, const int* ro
     }
     hipLaunchKernelGGL(filter_class_small_kernel<E>, dim3(num_classes - 1), dim3(FILTER_SMALL_THREADS), lds, stream,
                        pred_boxes, cls_prob, roi_count, num_rois, num_classes, thresh, nms_thresh, max_dets, max_out, dets,
-                       det_count);
+                       det_count, det_roi);
     return check_launch("filter_class_small_kernel");
   }
   const int npad = next_pow2(std::max(num_rois, 2));
@@ -949,24 +956,24 @@ static int launch_filter(float* pred_boxes, const float* cls_prob, const int* ro
   }
   hipLaunchKernelGGL(filter_class_kernel<E>, dim3(num_classes - 1), dim3(FILTER_THREADS), lds, stream, pred_boxes,
                      cls_prob, roi_count, num_rois, num_classes, thresh, nms_thresh, max_dets, max_out, npad, nb, dets,
-                     det_count, static_cast<unsigned char*>(ws), filter_ws_per_class(num_rois));
+                     det_count, det_roi, static_cast<unsigned char*>(ws), filter_ws_per_class(num_rois));
   return check_launch("filter_class_kernel");
 }
 
 extern "C" int frcnn_filter_per_class(float* pred_boxes, const float* cls_prob, const int* roi_count, int num_rois,
                                       int num_classes, float frame_w, float frame_h, float scale, float thresh,
                                       float nms_thresh, int max_dets, int max_out, float* dets, int* det_count,
-                                      void* ws, size_t ws_bytes, void* stream_) {
+                                      int* det_roi, void* ws, size_t ws_bytes, void* stream_) {
   return launch_filter<4>(pred_boxes, cls_prob, roi_count, num_rois, num_classes, frame_w, frame_h, scale, thresh,
-                          nms_thresh, max_dets, max_out, dets, det_count, ws, ws_bytes, stream_);
+                          nms_thresh, max_dets, max_out, dets, det_count, det_roi, ws, ws_bytes, stream_);
 }
 
 extern "C" int frcnn_filter_per_class_lidar(const float* pred_boxes, const float* cls_prob, const int* roi_count,
                                             int num_rois, int num_classes, float thresh, float nms_thresh,
-                                            int max_dets, int max_out, float* dets, int* det_count, void* ws,
-                                            size_t ws_bytes, void* stream_) {
+                                            int max_dets, int max_out, float* dets, int* det_count, int* det_roi,
+                                            void* ws, size_t ws_bytes, void* stream_) {
   return launch_filter<7>(const_cast<float*>(pred_boxes), cls_prob, roi_count, num_rois, num_classes, 0.f, 0.f, 1.f,
-                          thresh, nms_thresh, max_dets, max_out, dets, det_count, ws, ws_bytes, stream_);
+                          thresh, nms_thresh, max_dets, max_out, dets, det_count, det_roi, ws, ws_bytes, stream_);
 }
 
 extern "C" int frcnn_generate_anchors_3d(const float* base, int num_types, int height, int width, int feat_stride,

@@ -7,6 +7,7 @@
 // not reproducible across devices either).  Built with -ffp-contract=off.
 #include "common.h"
 #include "box_math.h"
+#include "rng.h"
 
 using namespace frcnn;
 
@@ -35,13 +36,6 @@ __device__ __forceinline__ void encode_box(const float* ex, const float* gt, flo
   out[3] = (float)log((double)(gh / eh));
 }
 
-__device__ __forceinline__ uint32_t hash32(uint32_t x) {  // lowbias32
-  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-  return x;
-}
-__device__ __forceinline__ uint32_t rand_key(uint32_t seed, uint32_t stream, uint32_t i) {
-  return hash32(hash32(seed ^ (stream * 0x9e3779b9U)) + i * 0x85ebca6bU);
-}
 
 __global__ __launch_bounds__(256) void overlaps_kernel(const float* __restrict__ boxes, int box_ld, int n,
                                                       const float* __restrict__ query, int q_ld, int k,

@@ -5,6 +5,7 @@
 // Built with -ffp-contract=off: the reference evaluates these expressions as separate torch ops.
 #include "common.h"
 #include "box_math.h"
+#include "rng.h"
 
 using namespace frcnn;
 
@@ -560,10 +561,12 @@ __global__ __launch_bounds__(256) void mc_bbox_var_kernel(const float* __restric
 
 __global__ __launch_bounds__(256) void mc_cls_stats_kernel(const float* __restrict__ scores, int T, int N, int K,
                                                           float* __restrict__ mean_prob, float* __restrict__ entropy,
-                                                          float* __restrict__ mutual_info) {
+                                                          float* __restrict__ mutual_info, float* __restrict__ prob_var) {
   for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
     float plogp = 0.f;                       // sum over samples of sum_k p log2 p
     for (int k = 0; k < K; ++k) mean_prob[(size_t)n * K + k] = 0.f;
+    if (prob_var)
+      for (int k = 0; k < K; ++k) prob_var[(size_t)n * K + k] = 0.f;
     for (int t = 0; t < T; ++t) {
       const float* s = scores + ((size_t)t * N + n) * K;
       float m = s[0];
@@ -574,19 +577,138 @@ __global__ __launch_bounds__(256) void mc_cls_stats_kernel(const float* __restri
       for (int k = 0; k < K; ++k) {
         const float p = expf(s[k] - m) / den;
         mean_prob[(size_t)n * K + k] += p;
+        if (prob_var) prob_var[(size_t)n * K + k] += p * p;
         acc += p * log2f(p);
       }
       plogp += acc;
     }
     float h = 0.f;
     for (int k = 0; k < K; ++k) {
-      const float p = mean_prob[(size_t)n * K + k] / (float)T;
+      const float sum = mean_prob[(size_t)n * K + k];
+      if (prob_var) {       // compute_bbox_var (loss_utils.py:114-120) applied to the softmax samples
+        float r = prob_var[(size_t)n * K + k] + -(sum * sum) / (float)T;
+        r = T > 1 ? r / (float)(T - 1) : 0.f;
+        prob_var[(size_t)n * K + k] = r > 0.f ? r : 0.f;
+      }
+      const float p = sum / (float)T;
       mean_prob[(size_t)n * K + k] = p;
       h += p * log2f(p);
     }
     entropy[n] = -h;
     mutual_info[n] = plogp / (float)T + -h;
   }
+}
+
+// mean over the T leading samples of a (T, n) stack, summed in sample order
+__global__ __launch_bounds__(256) void mc_mean_kernel(const float* __restrict__ samples, int T, size_t n,
+                                                     float* __restrict__ mean) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += samples[(size_t)t * n + i];
+    mean[i] = s / (float)T;
+  }
+}
+
+// nn.Dropout in train() mode on `repeat` stochastic copies of x (n_in): y[t][i] = keep(t, i) ? x[i] / (1 - p) : 0 with
+// keep = uniform01(seed, stream, t * n_in + i) >= p.  repeat > 1 starts the Monte-Carlo passes of the epistemic heads
+// from ONE deterministic activation (lib/model/test.py:74-77: E_NUM_SAMPLE passes per frame).
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, size_t n_in, int repeat, float p,
+                                                         float scale, uint32_t seed, uint32_t stream,
+                                                         float* __restrict__ y) {
+  const size_t total = n_in * (size_t)repeat;
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[j % n_in];
+    y[j] = uniform01(seed, stream, (uint32_t)j) >= p ? v * scale : 0.f;
+  }
+}
+// dx[i] = sum_t keep(t, i) * dy[t][i] / (1 - p), summed in t order
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dy, size_t n_in, int repeat, float p,
+                                                         float scale, uint32_t seed, uint32_t stream,
+                                                         float* __restrict__ dx) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += (size_t)gridDim.x * blockDim.x) {
+    float g = 0.f;
+    for (int t = 0; t < repeat; ++t) {
+      const size_t j = (size_t)t * n_in + i;
+      if (uniform01(seed, stream, (uint32_t)j) >= p) g += dy[j] * scale;
+    }
+    dx[i] = g;
+  }
+}
+
+// logit_distort (loss_utils.py:143-147): samples[s][i] = score[i] + sqrt(var[i]) * N(0,1)(seed; s * n + i).
+// var_is_log: the head predicts s = log(var) (the convention of the box-variance head, lib/model/test.py:82); var_out
+// (n, may be NULL) then receives exp(s), the a_cls_var column of the detections.
+__global__ __launch_bounds__(256) void logit_distort_kernel(const float* __restrict__ score, const float* __restrict__ var,
+                                                           size_t n, int S, uint32_t seed, uint32_t stream, int var_is_log,
+                                                           float* __restrict__ out, float* __restrict__ var_out) {
+  const size_t total = n * (size_t)S;
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = j % n;
+    const float v = var_is_log ? expf(var[i]) : var[i];
+    out[j] = score[i] + sqrtf(v) * normal01(seed, stream, (uint32_t)j);
+    if (var_out && j < n) var_out[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void exp_kernel(const float* __restrict__ x, size_t n, float* __restrict__ y) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = expf(x[i]);
+}
+
+// bayesian_cross_entropy (loss_utils.py:149-169) with the reparameterised draws of logit_distort_kernel:
+//   loss = mean_n -log( mean_s softmax(score_n + sqrt(var_n) * eps_sn)[target_n] )
+// One thread per RoI; gradients w.r.t. score and var (through sqrt(var) * eps), scaled by grad / N.
+__global__ __launch_bounds__(256) void bayes_ce_kernel(const float* __restrict__ score, const float* __restrict__ var,
+                                                      const float* __restrict__ labels, int N, int K, int S,
+                                                      uint32_t seed, uint32_t stream, int var_is_log, float grad,
+                                                      float* __restrict__ per_roi, float* __restrict__ dscore,
+                                                      float* __restrict__ dvar) {
+  constexpr int KMAX = 16;
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    const int tgt = (int)labels[n];
+    float sc[KMAX], sd[KMAX], gs[KMAX], gv[KMAX];
+    for (int k = 0; k < K; ++k) {
+      sc[k] = score[(size_t)n * K + k];
+      const float v = var[(size_t)n * K + k];
+      sd[k] = sqrtf(var_is_log ? expf(v) : v);
+      gs[k] = gv[k] = 0.f;
+    }
+    float avg = 0.f;
+    for (int s = 0; s < S; ++s) {
+      float z[KMAX], e[KMAX];
+      float m = -INFINITY;
+      for (int k = 0; k < K; ++k) {
+        e[k] = normal01(seed, stream, (uint32_t)(((size_t)s * N + n) * K + k));
+        z[k] = sc[k] + sd[k] * e[k];
+        m = fmaxf(m, z[k]);
+      }
+      float den = 0.f;
+      for (int k = 0; k < K; ++k) { z[k] = expf(z[k] - m); den += z[k]; }
+      const float pt = z[tgt] / den;
+      avg += pt;
+      // d pt / d z_k = pt * ([k == tgt] - p_k)
+      for (int k = 0; k < K; ++k) {
+        const float d = pt * ((k == tgt ? 1.f : 0.f) - z[k] / den);
+        gs[k] += d;
+        gv[k] += d * e[k];
+      }
+    }
+    avg = avg / (float)S;
+    per_roi[n] = -logf(avg);
+    // d(-log avg)/dz summed over s = -(1 / (S avg)) * sum_s dpt/dz ; dz/dvar = eps / (2 sqrt(var))
+    const float c = -grad / ((float)N * (float)S * avg);
+    for (int k = 0; k < K; ++k) {
+      if (dscore) dscore[(size_t)n * K + k] = c * gs[k];
+      // z = score + sd * eps: d z / d var = eps / (2 sd); with var = exp(s): d z / d s = eps * sd / 2
+      if (dvar) dvar[(size_t)n * K + k] = var_is_log ? c * gv[k] * sd[k] * 0.5f : (sd[k] > 0.f ? c * gv[k] / (2.0f * sd[k]) : 0.f);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void mean_reduce_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += v[i];      // fixed partition, fixed order
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[0] = s / (float)n;
 }
 }  // namespace
 
@@ -598,12 +720,70 @@ extern "C" int frcnn_mc_bbox_var(const float* samples, int num_samples, int64_t 
 }
 
 extern "C" int frcnn_mc_cls_stats(const float* cls_score_samples, int num_samples, int num_rois, int num_classes,
-                                  float* mean_prob, float* entropy, float* mutual_info, void* stream_) {
+                                  float* mean_prob, float* entropy, float* mutual_info, float* prob_var, void* stream_) {
   FRCNN_REQUIRE(cls_score_samples && mean_prob && entropy && mutual_info && num_samples > 0 && num_rois > 0 &&
                     num_classes > 1,
                 "mc_cls_stats: bad arguments");
   hipLaunchKernelGGL(mc_cls_stats_kernel, dim3(grid_for((size_t)num_rois)), dim3(256), 0,
                      static_cast<hipStream_t>(stream_), cls_score_samples, num_samples, num_rois, num_classes, mean_prob,
-                     entropy, mutual_info);
+                     entropy, mutual_info, prob_var);
   return check_launch("mc_cls_stats_kernel");
+}
+
+extern "C" int frcnn_mc_mean(const float* samples, int num_samples, int64_t elems, float* mean, void* stream_) {
+  FRCNN_REQUIRE(samples && mean && num_samples > 0 && elems > 0, "mc_mean: bad arguments");
+  hipLaunchKernelGGL(mc_mean_kernel, dim3(grid_for((size_t)elems)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     samples, num_samples, (size_t)elems, mean);
+  return check_launch("mc_mean_kernel");
+}
+
+extern "C" int frcnn_dropout_fwd(const float* x, int64_t elems, int repeat, float p, uint32_t seed, uint32_t stream_id,
+                                 float* y, void* stream_) {
+  FRCNN_REQUIRE(x && y && elems > 0 && repeat > 0 && p >= 0.f && p < 1.f && elems * (int64_t)repeat < ((int64_t)1 << 32),
+                "dropout_fwd: bad arguments (0 <= p < 1, elems * repeat < 2^32)");
+  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for((size_t)elems * repeat)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), x, (size_t)elems, repeat, p, 1.0f / (1.0f - p), seed, stream_id, y);
+  return check_launch("dropout_fwd_kernel");
+}
+
+extern "C" int frcnn_dropout_bwd(const float* dy, int64_t elems, int repeat, float p, uint32_t seed, uint32_t stream_id,
+                                 float* dx, void* stream_) {
+  FRCNN_REQUIRE(dy && dx && elems > 0 && repeat > 0 && p >= 0.f && p < 1.f && elems * (int64_t)repeat < ((int64_t)1 << 32),
+                "dropout_bwd: bad arguments (0 <= p < 1, elems * repeat < 2^32)");
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for((size_t)elems)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     dy, (size_t)elems, repeat, p, 1.0f / (1.0f - p), seed, stream_id, dx);
+  return check_launch("dropout_bwd_kernel");
+}
+
+extern "C" int frcnn_logit_distort(const float* score, const float* var, int64_t elems, int num_samples, uint32_t seed,
+                                   uint32_t stream_id, int var_is_log, float* samples, float* var_out, void* stream_) {
+  FRCNN_REQUIRE(score && var && samples && elems > 0 && num_samples > 0 && elems * (int64_t)num_samples < ((int64_t)1 << 32),
+                "logit_distort: bad arguments (elems * num_samples < 2^32)");
+  hipLaunchKernelGGL(logit_distort_kernel, dim3(grid_for((size_t)elems * num_samples)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), score, var, (size_t)elems, num_samples, seed, stream_id, var_is_log,
+                     samples, var_out);
+  return check_launch("logit_distort_kernel");
+}
+
+extern "C" int frcnn_bayesian_cross_entropy(const float* cls_score, const float* cls_var, const float* labels,
+                                            int num_rois, int num_classes, int num_samples, uint32_t seed,
+                                            uint32_t stream_id, int var_is_log, float grad, float* loss, float* per_roi,
+                                            float* dscore, float* dvar, void* stream_) {
+  FRCNN_REQUIRE(cls_score && cls_var && labels && loss && per_roi && num_rois > 0 && num_classes > 1 && num_classes <= 16 &&
+                    num_samples > 0 && (int64_t)num_rois * num_classes * num_samples < ((int64_t)1 << 32),
+                "bayesian_cross_entropy: bad arguments (2 <= classes <= 16)");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(bayes_ce_kernel, dim3(grid_for((size_t)num_rois)), dim3(256), 0, stream, cls_score, cls_var, labels,
+                     num_rois, num_classes, num_samples, seed, stream_id, var_is_log, grad, per_roi, dscore, dvar);
+  int rc = check_launch("bayes_ce_kernel");
+  if (rc != FRCNN_OK) return rc;
+  hipLaunchKernelGGL(mean_reduce_kernel, dim3(1), dim3(256), 0, stream, per_roi, num_rois, loss);
+  return check_launch("mean_reduce_kernel");
+}
+
+extern "C" int frcnn_exp(const float* x, int64_t elems, float* y, void* stream_) {
+  FRCNN_REQUIRE(x && y && elems > 0, "exp: bad arguments");
+  hipLaunchKernelGGL(exp_kernel, dim3(grid_for((size_t)elems)), dim3(256), 0, static_cast<hipStream_t>(stream_), x,
+                     (size_t)elems, y);
+  return check_launch("exp_kernel");
 }

@@ -31,6 +31,10 @@ class FrameRunner:
 
     def __init__(self, net, height, width, channels, info, thresh=0.5, max_dets=100, use_graph=True, warmup=2,
                  autotune=True, rpn_override_shape=None):
+        from ..nets import uncertainty
+        if uncertainty.enabled():
+            raise NotImplementedError("FrameRunner with cfg.UC.*: the seed of the counter-based draws is a launch argument, "
+                                      "a replayed graph would repeat the masks of the captured frame; use detect_frame_device")
         self.net = net
         self.info = np.asarray(info, dtype=np.float32)
         self.thresh, self.max_dets = thresh, max_dets

@@ -15,9 +15,29 @@ from ..utils.filter_predictions import filter_and_draw_prep, filter_device
 
 
 def frame_detect(net, blobs, num_classes, thresh):
-    _, probs, bbox_pred, rois, uncertainties = net.test_frame(blobs['data'], blobs['info'])
+    """lib/model/test.py:68-93: the epistemic heads run cfg.UC.E_NUM_SAMPLE stochastic passes per frame."""
+    epistemic = cfg.UC.EN_BBOX_EPISTEMIC or cfg.UC.EN_CLS_EPISTEMIC
+    if epistemic:
+        net.set_e_num_sample(cfg.UC.E_NUM_SAMPLE)
+    try:
+        _, probs, bbox_pred, rois, uncertainties = net.test_frame(blobs['data'], blobs['info'])
+    finally:
+        if epistemic:
+            net.set_e_num_sample(1)
     return filter_and_draw_prep(rois, probs, bbox_pred, uncertainties, blobs['info'], num_classes, thresh,
                                 cfg.NET_TYPE)
+
+
+def stack_uncertainties(cls_bbox, cls_uncertainties, num_uc_pos):
+    """lib/model/test.py:260-270: detection rows followed by their uncertainty columns, in dict order."""
+    out = np.zeros((cls_bbox.shape[0], cls_bbox.shape[1] + num_uc_pos))
+    out[:, 0:cls_bbox.shape[1]] = cls_bbox
+    ptr = cls_bbox.shape[1]
+    for _, uncert in cls_uncertainties.items():
+        end = ptr + uncert.shape[1]
+        out[:, ptr:end] = uncert[:, :]
+        ptr = end
+    return out
 
 
 def apply_max_dets(cls_boxes, max_dets):
@@ -31,12 +51,19 @@ def apply_max_dets(cls_boxes, max_dets):
 def detect_frame_device(net, data, info, thresh=0.5, max_dets=100, max_out=None):
     """One frame, asynchronous: returns (dets (K, max_out, 5), det_count (K,)) device tensors holding,
     per class, the detections test_net would store in all_boxes[cls][frame]."""
-    with torch.no_grad():
-        net.forward(data, info, None, None, mode='TEST')
+    epistemic = cfg.UC.EN_BBOX_EPISTEMIC or cfg.UC.EN_CLS_EPISTEMIC
+    if epistemic:
+        net.set_e_num_sample(cfg.UC.E_NUM_SAMPLE)          # lib/model/test.py:74-77
+    try:
+        with torch.no_grad():
+            net.forward(data, info, None, None, mode='TEST')
+    finally:
+        if epistemic:
+            net.set_e_num_sample(1)
     p = net._predictions
     max_out = max_out if max_out is not None else p['cls_prob'].shape[0]
     return filter_device(p['rois_count'], p['cls_prob'], p['pred_boxes'], info, thresh, max_dets, max_out,
-                         db_type=cfg.NET_TYPE)
+                         db_type=cfg.NET_TYPE, uncertainties=p.get('uncertainties'))
 
 
 def lidar_extents():
@@ -81,7 +108,9 @@ def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=F
     np.random.seed(cfg.RNG_SEED)
     num_images, k = db.num_frames(mode), db.num_classes
     lidar = cfg.NET_TYPE == 'lidar'
-    elem = 8 if lidar else 5
+    from ..nets.uncertainty import num_uncertainty_pos
+    # rows carry the uncertainty columns of cfg.UC.* behind the box and the score (lib/model/test.py:151-159,222-226)
+    elem = (8 if lidar else 5) + num_uncertainty_pos(k, 7 if lidar else 4)
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     rank = dist.get_rank() if distributed else 0
     world = dist.get_world_size() if distributed else 1

@@ -11,8 +11,9 @@ import torch
 import torch.nn as nn
 
 from ..model.config import cfg
-from ..utils.init_utils import normal_init, set_bn_eval, set_bn_fix, set_bn_train, set_bn_var
+from ..utils.init_utils import const_init, normal_init, set_bn_eval, set_bn_fix, set_bn_train, set_bn_var
 from .fpn import fpn
+from . import uncertainty
 from .network import Network
 
 
@@ -50,13 +51,11 @@ class imagenet(Network):
         self._fc7_channels = 2048
         self.inplanes = 64
         self._num_resnet_layers = num_layers
-        if cfg.UC.EN_BBOX_EPISTEMIC or cfg.UC.EN_CLS_EPISTEMIC:
-            raise NotImplementedError("MC-dropout (epistemic) heads are outside the accelerated path")
-        self._det_net_channels = self._fc7_channels
-        self._dropout_en = False
-        self._cls_drop_rate = 0.0
-        self._bbox_drop_rate = 0.0
-        self._resnet_drop_rate = 0.0
+        # imagenet.py:52-63: with MC dropout the detection heads read fc7 / 4 features (nets/uncertainty.py builds them)
+        epistemic = bool(cfg.UC.EN_BBOX_EPISTEMIC or cfg.UC.EN_CLS_EPISTEMIC)
+        self._det_net_channels = self._fc7_channels // 4 if epistemic else self._fc7_channels
+        self._dropout_en = epistemic
+        self._cls_drop_rate, self._bbox_drop_rate, self._resnet_drop_rate = uncertainty.drop_rates(lidar=False)
 
     def init_weights(self):
         # imagenet.py:65-91
@@ -70,6 +69,8 @@ class imagenet(Network):
         normal_init(self.rpn_bbox_pred_net, 0, 0.01, cfg.TRAIN.TRUNCATED)
         normal_init(self.cls_score_net, 0, 0.01, cfg.TRAIN.TRUNCATED)
         normal_init(self.bbox_pred_net, 0, 0.001, cfg.TRAIN.TRUNCATED)
+        if uncertainty.enabled():
+            uncertainty.init_weights(self, normal_init, const_init, cfg.TRAIN.TRUNCATED, lidar=False)
 
     def _init_head_tail(self):
         self.resnet = self._build_resnet()
@@ -112,6 +113,8 @@ class imagenet(Network):
 
     def eval(self):
         nn.Module.eval(self)
+        if uncertainty.enabled():
+            uncertainty.apply_eval_protocol(self)      # dropout modules stay stochastic (imagenet.py:165-172)
         return self
 
     # ---- checkpoint helpers (imagenet.py:199-244): same key rules as the reference -------------------

@@ -13,9 +13,10 @@ import torch
 import torch.nn as nn
 
 from ..model.config import cfg
-from ..utils.init_utils import normal_init, set_bn_eval, set_bn_fix, set_bn_train, set_bn_var
+from ..utils.init_utils import const_init, normal_init, set_bn_eval, set_bn_fix, set_bn_train, set_bn_var
 from .fpn import fpn
 from .imagenet import _Head
+from . import uncertainty
 from .network import Network
 
 
@@ -32,8 +33,12 @@ class lidarnet(Network):
             self._net_conv_channels = 256
             self._roi_pooling_channels = cfg.POOLING_SIZE * cfg.POOLING_SIZE * self._net_conv_channels
         elif cfg.USE_LIDAR_FPN:
-            raise NotImplementedError("cfg.USE_LIDAR_FPN (stride-8, 1024-channel pyramid, lidarnet.py:41-46) is not on "
-                                      "the HIP path; cfg.USE_FPN is")
+            # lidarnet.py:41-46 only sets attributes (_feat_stride = 8, _fpn_en, 1024 channels); _init_head_tail
+            # (lidarnet.py:136-150) builds a pyramid for cfg.USE_FPN alone, so with this flag the reference's own
+            # subclass still produces the stride-16 layer3 map: whatever made a stride-8 pyramid of it lived in the
+            # missing network.py and is not recoverable from the snapshot
+            raise NotImplementedError("cfg.USE_LIDAR_FPN: the stride-8 variant is defined only in the reference's missing "
+                                      "lib/nets/network.py (lidarnet.py builds no pyramid for it); cfg.USE_FPN is supported")
         else:
             self._feat_stride = 16
             self._fpn_en = False
@@ -43,13 +48,11 @@ class lidarnet(Network):
         self._fc7_channels = 2048
         self.inplanes = 64
         self._num_resnet_layers = num_layers
-        if cfg.UC.EN_BBOX_EPISTEMIC or cfg.UC.EN_CLS_EPISTEMIC:
-            raise NotImplementedError("MC-dropout (epistemic) heads are outside the accelerated path")
-        self._det_net_channels = self._fc7_channels
-        self._dropout_en = False
-        self._resnet_drop_rate = 0.0
-        self._cls_drop_rate = 0.0
-        self._bbox_drop_rate = 0.0
+        # lidarnet.py:56-67: with MC dropout the detection heads read fc7 / 4 features (nets/uncertainty.py builds them)
+        epistemic = bool(cfg.UC.EN_BBOX_EPISTEMIC or cfg.UC.EN_CLS_EPISTEMIC)
+        self._det_net_channels = self._fc7_channels // 4 if epistemic else self._fc7_channels
+        self._dropout_en = epistemic
+        self._cls_drop_rate, self._bbox_drop_rate, self._resnet_drop_rate = uncertainty.drop_rates(lidar=True)
         self.num_lidar_channels = cfg.LIDAR.NUM_CHANNEL
 
     def init_weights(self):
@@ -64,6 +67,8 @@ class lidarnet(Network):
         normal_init(self.rpn_bbox_pred_net, 0, 0.01, cfg.TRAIN.TRUNCATED)
         normal_init(self.cls_score_net, 0, 0.01, cfg.TRAIN.TRUNCATED)
         normal_init(self.bbox_pred_net, 0, 0.001, cfg.TRAIN.TRUNCATED)
+        if uncertainty.enabled():
+            uncertainty.init_weights(self, normal_init, const_init, cfg.TRAIN.TRUNCATED, lidar=True)
 
     def _init_head_tail(self):
         self.resnet = self._build_resnet()
@@ -116,6 +121,8 @@ class lidarnet(Network):
 
     def eval(self):
         nn.Module.eval(self)
+        if uncertainty.enabled():
+            uncertainty.apply_eval_protocol(self)      # dropout modules stay stochastic (imagenet.py:165-172)
         return self
 
     # ---- checkpoint helpers (lidarnet.py:205-246): same key rules as the reference ---------------------

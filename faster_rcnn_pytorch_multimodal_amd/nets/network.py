@@ -34,6 +34,7 @@ from ..model.config import cfg
 from ..utils.bbox import bbaa_graphics_gems
 from . import resnet as custom_resnet
 from . import autograd_ops
+from . import uncertainty
 from .autograd_ops import (conv_bn_act_train, det_loss_train, fused_head_train, fused_head_weights, linear_train,
                            roi_align_train, rpn_loss_train, spatial_mean_train)
 from .hip_modules import conv_bn_act, pad4, to_nchw_view, to_nhwc
@@ -63,6 +64,8 @@ class Network(nn.Module):
         self._frame_scale = 1.0
         self.timers = {}
         self._rpn_fused = None
+        self._uc_seed = int(cfg.RNG_SEED)      # counter-based draws of the uncertainty heads: seed + forward count
+        self._uc_calls = 0
 
     # ------------------------------------------------------------------------------------------
     # construction
@@ -99,6 +102,9 @@ class Network(nn.Module):
         elif getattr(self, '_fpn_en', False):
             raise NotImplementedError("the FPN detector needs cfg.ENABLE_CUSTOM_TAIL (layer4 is part of its backbone); "
                                       "tools/trainval_net.py:326-330 sets both")
+        if uncertainty.enabled():
+            uncertainty.check_flags()
+            uncertainty.build_modules(self, lidar=cfg.NET_TYPE == 'lidar')
         self.init_weights()
 
     def _build_resnet(self):
@@ -115,7 +121,17 @@ class Network(nn.Module):
         raise NotImplementedError('resnet depth %s' % depth)
 
     def set_e_num_sample(self, n):
+        """Monte-Carlo passes of the epistemic heads per frame (lib/model/test.py:74-77)."""
         self._e_num_sample = int(n)
+
+    def set_uc_seed(self, seed):
+        """Restart the counter-based random draws of the uncertainty heads (dropout masks, logit distortion)."""
+        self._uc_seed, self._uc_calls = int(seed), 0
+
+    def next_uc_seed(self):
+        s = (self._uc_seed + self._uc_calls) & 0xFFFFFFFF
+        self._uc_calls += 1
+        return s
 
     # ------------------------------------------------------------------------------------------
     # forward pieces (reference names).  Public tensors are NCHW-shaped views of NHWC storage.
@@ -312,6 +328,8 @@ class Network(nn.Module):
         # heads on fc7 alone: one workgroup per RoI doing both needed 72 us (profiles/r01h_kernel_stats.md)
         y = self._layer4(to_nhwc(pool5))
         fc7 = ops.spatial_mean(y)
+        if uncertainty.enabled():
+            return fc7                                  # the heads run in _region_classification (nets/uncertainty.py)
         r, c = fc7.shape
         out = self._tail_kernel(fc7.view(r, 1, 1, c), self._predictions['rois'])
         out['fc7'] = fc7
@@ -320,6 +338,10 @@ class Network(nn.Module):
 
     def _region_classification(self, fc7):
         """cls_score_net + softmax, bbox_pred_net.  Returns (cls_prob, bbox_pred) like the ancestor."""
+        if uncertainty.enabled():
+            if torch.is_grad_enabled() and self._mode == 'TRAIN':
+                return uncertainty.classify_train(self, fc7)
+            return uncertainty.classify_test(self, fc7.contiguous(), self._predictions['rois'])
         if torch.is_grad_enabled() and self._mode == 'TRAIN':
             r, c = fc7.shape
             k, e = self._num_classes, self._bbox_elem()
@@ -387,8 +409,11 @@ class Network(nn.Module):
         rpn_l = rpn_loss_train(rpn_out.view(hw, ld), at['labels'], at['targets'], at['inside'], at['outside'],
                                self._num_anchors)
         lidar = (tuple(cfg.LIDAR.REG_LOSS_WEIGHT), bool(cfg.LIDAR.EN_RY_SIN)) if cfg.NET_TYPE == 'lidar' else None
-        det_l = det_loss_train(p['cls_score'], p['bbox_pred'], pt['labels'], pt['targets'], pt['inside'], pt['outside'],
-                               lidar=lidar)
+        if cfg.UC.EN_BBOX_ALEATORIC or cfg.UC.EN_CLS_ALEATORIC:
+            det_l = uncertainty.det_loss_uc(self, pt['labels'], pt['targets'], pt['inside'], pt['outside'], lidar)
+        else:
+            det_l = det_loss_train(p['cls_score'], p['bbox_pred'], pt['labels'], pt['targets'], pt['inside'], pt['outside'],
+                                   lidar=lidar)
         self._losses = {'rpn_cross_entropy': rpn_l[0], 'rpn_loss_box': rpn_l[1], 'cross_entropy': det_l[0],
                         'loss_box': det_l[1]}
         self._losses['total_loss'] = rpn_l[0] + rpn_l[1] + det_l[0] + det_l[1]
@@ -449,7 +474,8 @@ class Network(nn.Module):
         self.forward(data, info, None, None, mode='TEST')
         p = self._predictions
         n = int(p['rois_count'].item())
-        return p['cls_score'][:n], p['cls_prob'][:n], p['pred_boxes'][:n], p['rois'][:n], {}
+        uncertainties = {k: v[:n] for k, v in p.get('uncertainties', {}).items()}
+        return p['cls_score'][:n], p['cls_prob'][:n], p['pred_boxes'][:n], p['rois'][:n], uncertainties
 
     def _clip_gradients(self):
         """Per-element clamp to +-cfg.GRAD_MAX_CLIP (lib/model/config.py:338; the ancestor clips by value)."""

@@ -388,8 +388,10 @@ def generate_anchors_3d(base, height, width, feat_stride):
     return a3, a2
 
 
-def filter_per_class_lidar(pred_boxes, cls_prob, thresh, nms_thresh, max_dets, max_out=None, roi_count=None):
-    """7-DoF form: returns (dets (K, max_out, 8) [xc,yc,zc,l,w,h,ry,score], det_count int32 (K,))."""
+def filter_per_class_lidar(pred_boxes, cls_prob, thresh, nms_thresh, max_dets, max_out=None, roi_count=None,
+                           want_rois=False):
+    """7-DoF form: returns (dets (K, max_out, 8) [xc,yc,zc,l,w,h,ry,score], det_count int32 (K,)[, det_roi int32
+    (K, max_out)])."""
     lib = _hip.load()
     _dev_f32(pred_boxes, "pred_boxes"); _dev_f32(cls_prob, "cls_prob")
     r, k = cls_prob.shape
@@ -400,17 +402,18 @@ def filter_per_class_lidar(pred_boxes, cls_prob, thresh, nms_thresh, max_dets, m
     det_count = torch.zeros((k,), dtype=torch.int32, device=cls_prob.device)
     ws_bytes = lib.frcnn_filter_per_class_ws_bytes(r, k)
     ws = _workspace(ws_bytes, cls_prob.device)
+    det_roi = torch.full((k, max_out), -1, dtype=torch.int32, device=cls_prob.device) if want_rois else None   # class 0 stays -1
     _hip.check(lib.frcnn_filter_per_class_lidar(_ptr(pred_boxes), _ptr(cls_prob), _ptr(roi_count), r, k, float(thresh),
                                                 float(nms_thresh), int(max_dets), int(max_out), _ptr(dets),
-                                                _ptr(det_count), _ptr(ws), ws_bytes, _stream()),
+                                                _ptr(det_count), _ptr(det_roi), _ptr(ws), ws_bytes, _stream()),
                "frcnn_filter_per_class_lidar")
-    return dets, det_count
+    return (dets, det_count, det_roi) if want_rois else (dets, det_count)
 
 
 def filter_per_class(pred_boxes, cls_prob, frame_w, frame_h, scale, thresh, nms_thresh, max_dets, max_out=None,
-                     roi_count=None):
+                     roi_count=None, want_rois=False):
     """In-place clamp of pred_boxes + per-class threshold/NMS/max_dets.
-    Returns (dets (K, max_out, 5), det_count int32 (K,))."""
+    Returns (dets (K, max_out, 5), det_count int32 (K,)[, det_roi int32 (K, max_out): RoI row of each detection])."""
     lib = _hip.load()
     _dev_f32(pred_boxes, "pred_boxes"); _dev_f32(cls_prob, "cls_prob")
     r, k = cls_prob.shape
@@ -419,11 +422,12 @@ def filter_per_class(pred_boxes, cls_prob, frame_w, frame_h, scale, thresh, nms_
     det_count = torch.zeros((k,), dtype=torch.int32, device=cls_prob.device)
     ws_bytes = lib.frcnn_filter_per_class_ws_bytes(r, k)
     ws = _workspace(ws_bytes, cls_prob.device)
+    det_roi = torch.full((k, max_out), -1, dtype=torch.int32, device=cls_prob.device) if want_rois else None   # class 0 stays -1
     _hip.check(lib.frcnn_filter_per_class(_ptr(pred_boxes), _ptr(cls_prob), _ptr(roi_count), r, k, float(frame_w),
                                           float(frame_h), float(scale), float(thresh), float(nms_thresh), int(max_dets),
-                                          int(max_out), _ptr(dets), _ptr(det_count), _ptr(ws), ws_bytes, _stream()),
-               "frcnn_filter_per_class")
-    return dets, det_count
+                                          int(max_out), _ptr(dets), _ptr(det_count), _ptr(det_roi), _ptr(ws), ws_bytes,
+                                          _stream()), "frcnn_filter_per_class")
+    return (dets, det_count, det_roi) if want_rois else (dets, det_count)
 
 
 def bev_voxelize(points, pc_range, voxel_size, z_shift, max_points, max_voxels, num_slices, num_meta,
@@ -629,17 +633,91 @@ def mc_bbox_var(samples):
     return out
 
 
-def mc_cls_stats(cls_score_samples):
-    """(T, N, K) logits -> (mean softmax (N,K), entropy (N,), mutual information (N,)), log base 2."""
+def mc_cls_stats(cls_score_samples, want_var=False):
+    """(T, N, K) logits -> (mean softmax (N,K), entropy (N,), mutual information (N,)[, variance of the softmax over T
+    (N,K)]), log base 2."""
     lib = _hip.load()
     _dev_f32(cls_score_samples, "cls_score_samples")
     t, n, k = cls_score_samples.shape
     dev = cls_score_samples.device
     mean_prob = torch.empty((n, k), dtype=torch.float32, device=dev)
     entropy, mi = torch.empty((n,), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev)
+    var = torch.empty((n, k), dtype=torch.float32, device=dev) if want_var else None
     _hip.check(lib.frcnn_mc_cls_stats(_ptr(cls_score_samples), t, n, k, _ptr(mean_prob), _ptr(entropy), _ptr(mi),
-                                      _stream()), "frcnn_mc_cls_stats")
-    return mean_prob, entropy, mi
+                                      _ptr(var), _stream()), "frcnn_mc_cls_stats")
+    return (mean_prob, entropy, mi, var) if want_var else (mean_prob, entropy, mi)
+
+
+def mc_mean(samples):
+    """(T, ...) -> mean over T (summed in sample order)."""
+    lib = _hip.load()
+    _dev_f32(samples, "samples")
+    out = torch.empty(samples.shape[1:], dtype=torch.float32, device=samples.device)
+    _hip.check(lib.frcnn_mc_mean(_ptr(samples), samples.shape[0], out.numel(), _ptr(out), _stream()), "frcnn_mc_mean")
+    return out
+
+
+def dropout(x, p, seed, stream_id, repeat=1):
+    """nn.Dropout(p) in train() mode with counter-based masks; ``repeat`` stochastic copies: x (...) -> (repeat, ...)
+    (the leading dimension is dropped for repeat == 1)."""
+    lib = _hip.load()
+    _dev_f32(x, "x")
+    shape = tuple(x.shape) if repeat == 1 else (repeat,) + tuple(x.shape)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    _hip.check(lib.frcnn_dropout_fwd(_ptr(x), x.numel(), int(repeat), float(p), int(seed) & 0xFFFFFFFF,
+                                     int(stream_id) & 0xFFFFFFFF, _ptr(y), _stream()), "frcnn_dropout_fwd")
+    return y
+
+
+def dropout_bwd(dy, p, seed, stream_id, repeat=1):
+    lib = _hip.load()
+    _dev_f32(dy, "dy")
+    shape = tuple(dy.shape) if repeat == 1 else tuple(dy.shape[1:])
+    dx = torch.empty(shape, dtype=torch.float32, device=dy.device)
+    _hip.check(lib.frcnn_dropout_bwd(_ptr(dy), dx.numel(), int(repeat), float(p), int(seed) & 0xFFFFFFFF,
+                                     int(stream_id) & 0xFFFFFFFF, _ptr(dx), _stream()), "frcnn_dropout_bwd")
+    return dx
+
+
+def logit_distort(score, var, num_samples, seed, stream_id, var_is_log=False):
+    """logit_distort (loss_utils.py:143-147): (N,K) logits and (log-)variances -> ((S, N, K) distorted logits, (N,K)
+    variances)."""
+    lib = _hip.load()
+    _dev_f32(score, "score"); _dev_f32(var, "var")
+    if score.shape != var.shape:
+        raise _hip.HipError("logit_distort: score %s vs var %s" % (tuple(score.shape), tuple(var.shape)))
+    out = torch.empty((int(num_samples),) + tuple(score.shape), dtype=torch.float32, device=score.device)
+    var_out = torch.empty_like(var)
+    _hip.check(lib.frcnn_logit_distort(_ptr(score), _ptr(var), score.numel(), int(num_samples), int(seed) & 0xFFFFFFFF,
+                                       int(stream_id) & 0xFFFFFFFF, int(bool(var_is_log)), _ptr(out), _ptr(var_out),
+                                       _stream()), "frcnn_logit_distort")
+    return out, var_out
+
+
+def exp(x):
+    lib = _hip.load()
+    _dev_f32(x, "x")
+    y = torch.empty_like(x)
+    _hip.check(lib.frcnn_exp(_ptr(x), x.numel(), _ptr(y), _stream()), "frcnn_exp")
+    return y
+
+
+def bayesian_cross_entropy(cls_score, cls_var, labels, num_samples, seed, stream_id, grad=1.0, want_grad=True,
+                           var_is_log=False):
+    """bayesian_cross_entropy (loss_utils.py:149-169).  Returns (loss (1,), dscore, dvar) (gradients scaled by grad)."""
+    lib = _hip.load()
+    _dev_f32(cls_score, "cls_score"); _dev_f32(cls_var, "cls_var"); _dev_f32(labels, "labels")
+    n, k = cls_score.shape
+    dev = cls_score.device
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    per_roi = torch.empty((n,), dtype=torch.float32, device=dev)
+    dscore = torch.empty_like(cls_score) if want_grad else None
+    dvar = torch.empty_like(cls_var) if want_grad else None
+    _hip.check(lib.frcnn_bayesian_cross_entropy(_ptr(cls_score), _ptr(cls_var), _ptr(labels), n, k, int(num_samples),
+                                                int(seed) & 0xFFFFFFFF, int(stream_id) & 0xFFFFFFFF, int(bool(var_is_log)),
+                                                float(grad), _ptr(loss), _ptr(per_roi), _ptr(dscore), _ptr(dvar), _stream()),
+               "frcnn_bayesian_cross_entropy")
+    return loss, dscore, dvar
 
 
 def bbox_overlaps(boxes, query_boxes):

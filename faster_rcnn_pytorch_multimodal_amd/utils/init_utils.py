@@ -82,7 +82,7 @@ def seeded_state_dict(module, seed, bn_mode="identity", all_backbone=False):
             std = 0.001 if name == "bbox_pred_net" else 0.01
             out[pre + "weight"] = torch.randn(m.weight.shape, generator=g) * std
             out[pre + "bias"] = torch.zeros_like(m.bias)
-        elif isinstance(m, nn.BatchNorm2d):
+        elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):      # BatchNorm1d: the LiDAR uncertainty heads
             c = m.num_features
             if bn_mode == "identity":
                 out[pre + "weight"], out[pre + "bias"] = torch.ones(c), torch.zeros(c)

@@ -230,14 +230,16 @@ int frcnn_head_fc_softmax_decode_lidar(const float* x, int num_rois, int pooled,
  * 45-72; lib/model/test.py:210-221) for the image detector, all on the device:
  * clamp to [0, frame/scale-1] in place, per class j>=1 keep score > thresh, NMS(nms_thresh) in
  * descending score order, keep dets with score >= the max_dets-th best.
- * dets (K, max_out, 5) [x1,y1,x2,y2,score], det_count (K) ints. roi_count device int or NULL. */
+ * dets (K, max_out, 5) [x1,y1,x2,y2,score], det_count (K) ints. roi_count device int or NULL.
+ * det_roi (K, max_out) ints or NULL: RoI row of every detection (-1 past det_count) - what nms_hstack_var_torch
+ * (filter_predictions.py:23-43) needs to gather the per-RoI uncertainties of the kept detections. */
 /* Test hook: 0 = automatic (num_rois <= 1024: LDS-resident kernel), 1 = always the general workspace kernel. */
 int frcnn_filter_set_variant(int variant);
 size_t frcnn_filter_per_class_ws_bytes(int num_rois, int num_classes);
 int frcnn_filter_per_class(float* pred_boxes, const float* cls_prob, const int* roi_count, int num_rois,
                            int num_classes, float frame_w, float frame_h, float scale, float thresh,
                            float nms_thresh, int max_dets, int max_out, float* dets, int* det_count,
-                           void* ws, size_t ws_bytes, void* stream);
+                           int* det_roi, void* ws, size_t ws_bytes, void* stream);
 
 /* LiDAR input producer (lib/roi_data_layer/minibatch.py:232-235,434-512): points (num_points, point_stride >= 4)
  * rows [x,y,z,intensity,(elongation)...] in file order -> bev (gy, gx, num_slices + num_meta) fp32, the blob of one
@@ -370,8 +372,7 @@ int frcnn_det_loss_lidar(const float* cls_score, const float* labels, int num_ro
                          const float* reg_loss_weight_host, int ry_sin, float grad_ce, float grad_box, float* losses,
                          float* dcls, float* dbox, void* stream);
 
-/* Uncertainty pieces whose arithmetic IS in the reference snapshot (lib/utils/loss_utils.py; the heads that would feed
- * them live in the missing lib/nets/network.py and are not rebuilt - DESIGN.md section 2, row f-3):
+/* Uncertainty pieces whose arithmetic IS in the reference snapshot (lib/utils/loss_utils.py):
  *  - frcnn_det_loss with the aleatoric attenuation of loss_utils.py:82-85: bbox_var = predicted log-variance s,
  *    per-element loss (0.5*huber*exp(-s) + 0.5*s)*inside; dvar receives d(loss)/ds.  bbox_elem 4 or 7
  *    (7: sin(ry) + reg_loss_weight_host as in frcnn_det_loss_lidar).
@@ -386,14 +387,41 @@ int frcnn_det_loss_aleatoric(const float* cls_score, const float* labels, int nu
                              void* stream);
 int frcnn_mc_bbox_var(const float* samples, int num_samples, int64_t elems, float* var, void* stream);
 int frcnn_mc_cls_stats(const float* cls_score_samples, int num_samples, int num_rois, int num_classes,
-                       float* mean_prob, float* entropy, float* mutual_info, void* stream);
+                       float* mean_prob, float* entropy, float* mutual_info, float* prob_var /* (num_rois,K) or NULL:
+                       compute_bbox_var of the softmax samples */, void* stream);
+/* mean over the T leading samples of a (T, elems) stack (mean logits / mean deltas of the Monte-Carlo passes). */
+int frcnn_mc_mean(const float* samples, int num_samples, int64_t elems, float* mean, void* stream);
+
+/* Uncertainty heads (rebuilt from the module names and rates of lib/nets/imagenet.py:52-91 / lidarnet.py:56-102; wiring
+ * choices are named constants in nets/network.py).  Random draws are counter-based, value = f(seed, stream_id, index)
+ * (csrc/rng.h), so the CPU oracle replays them:
+ *  - frcnn_dropout_fwd: nn.Dropout(p) in train() mode on `repeat` stochastic copies of x (elems): y (repeat, elems);
+ *    repeat = cfg.UC.E_NUM_SAMPLE starts the Monte-Carlo passes (lib/model/test.py:74-77) from one activation.
+ *  - frcnn_dropout_bwd: dx (elems) = sum over the copies of mask * dy / (1 - p).
+ *  - frcnn_logit_distort: logit_distort of loss_utils.py:143-147, samples (S, elems) = score + sqrt(var) * N(0,1).
+ *  - frcnn_bayesian_cross_entropy: loss_utils.py:149-169 on the same draws: loss[0] = mean over RoIs of
+ *    -log(mean_s softmax(score + sqrt(var) eps_s)[label]); per_roi (num_rois) scratch/diagnostic; dscore / dvar
+ *    (num_rois, K, may be NULL) receive grad * d loss / d{score, var}. */
+int frcnn_dropout_fwd(const float* x, int64_t elems, int repeat, float p, uint32_t seed, uint32_t stream_id, float* y,
+                      void* stream);
+int frcnn_dropout_bwd(const float* dy, int64_t elems, int repeat, float p, uint32_t seed, uint32_t stream_id, float* dx,
+                      void* stream);
+int frcnn_logit_distort(const float* score, const float* var, int64_t elems, int num_samples, uint32_t seed,
+                        uint32_t stream_id, int var_is_log /* var holds log-variances */, float* samples,
+                        float* var_out /* (elems) exp(var) or var; may be NULL */, void* stream);
+int frcnn_bayesian_cross_entropy(const float* cls_score, const float* cls_var, const float* labels, int num_rois,
+                                 int num_classes, int num_samples, uint32_t seed, uint32_t stream_id, int var_is_log,
+                                 float grad, float* loss, float* per_roi, float* dscore, float* dvar, void* stream);
+/* y = exp(x) elementwise (log-variance heads -> variances at test time). */
+int frcnn_exp(const float* x, int64_t elems, float* y, void* stream);
 
 /* LiDAR form (filter_predictions.py:55-62,67, db_type 'lidar'): no clamp, NMS on the yaw-less BEV rectangle
  * xc -+ l/2, yc -+ w/2 of the 7-DoF boxes, dets (K, max_out, 8) [xc,yc,zc,l,w,h,ry,score].
  * Workspace: frcnn_filter_per_class_ws_bytes. */
 int frcnn_filter_per_class_lidar(const float* pred_boxes, const float* cls_prob, const int* roi_count,
                                  int num_rois, int num_classes, float thresh, float nms_thresh, int max_dets,
-                                 int max_out, float* dets, int* det_count, void* ws, size_t ws_bytes, void* stream);
+                                 int max_out, float* dets, int* det_count, int* det_roi, void* ws, size_t ws_bytes,
+                                 void* stream);
 
 #ifdef __cplusplus
 }

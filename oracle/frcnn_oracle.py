@@ -812,6 +812,132 @@ def categorical_mutual_information(cls_score):
 
 
 # ----------------------------------------------------------------------------------------------
+# Uncertainty heads (cfg.UC.*) — module names / sizes / rates lib/nets/imagenet.py:52-91, lidarnet.py:56-102; Monte-Carlo
+# protocol lib/model/test.py:74-77; arithmetic lib/utils/loss_utils.py:114-169.  The wiring restates the RECONSTRUCTED
+# contract of the missing network.py (constants mirrored from the product's nets/uncertainty.py).  The counter-based
+# random draws of the device (csrc/rng.h) are replayed here so that stochastic outputs can be compared value by value.
+# ----------------------------------------------------------------------------------------------
+UC_STREAM = {'bbox_drop1': 11, 'bbox_drop2': 12, 'cls_drop1': 13, 'cls_drop2': 14, 'logit_distort': 15, 'bayes_ce': 16}
+UNCERTAINTY_ORDER = ('a_entropy', 'a_mutual_info', 'a_cls_var', 'e_entropy', 'e_mutual_info', 'e_cls_var',
+                     'a_bbox_var', 'e_bbox_var')
+
+
+def _hash32(x):
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d); x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b); x ^= x >> np.uint32(16)
+    return x
+
+
+def rand_key(seed, stream, idx):
+    """csrc/rng.h rand_key: hash32(hash32(seed ^ stream * 0x9e3779b9) + i * 0x85ebca6b), all mod 2^32."""
+    with np.errstate(over="ignore"):
+        base = _hash32(np.array([(int(seed) ^ ((int(stream) * 0x9e3779b9) & 0xFFFFFFFF)) & 0xFFFFFFFF], dtype=np.uint32))[0]
+        i = np.asarray(idx, dtype=np.uint64)
+        return _hash32(((np.uint64(base) + i * np.uint64(0x85ebca6b)) & np.uint64(0xFFFFFFFF)).astype(np.uint32))
+
+
+def uniform01(seed, stream, idx):
+    return ((rand_key(seed, stream, idx) >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+
+
+def normal01(seed, stream, idx):
+    u1, u2 = uniform01(seed, 2 * stream, idx), uniform01(seed, 2 * stream + 1, idx)
+    return (np.sqrt(np.float32(-2.0) * np.log(u1)) * np.cos(np.float32(6.2831853071795864) * u2)).astype(np.float32)
+
+
+def dropout_replay(x, p, seed, stream, repeat=1):
+    """nn.Dropout(p) in train() mode with the device's masks: x (n...) -> (repeat, n...) (squeezed for repeat == 1)."""
+    n = x.numel()
+    keep = torch.from_numpy(uniform01(seed, stream, np.arange(n * repeat)) >= np.float32(p)).view((repeat,) + tuple(x.shape))
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    y = torch.where(keep, x.unsqueeze(0) * float(scale), torch.zeros((), dtype=x.dtype))
+    return y[0] if repeat == 1 else y
+
+
+def logit_distort_replay(score, var, num_sample, seed, stream=UC_STREAM['logit_distort']):
+    """logit_distort (loss_utils.py:143-147) with the device's normal draws: (N,K) -> (S,N,K)."""
+    n = score.numel()
+    eps = torch.from_numpy(normal01(seed, stream, np.arange(n * num_sample))).view((num_sample,) + tuple(score.shape))
+    return score.unsqueeze(0) + torch.sqrt(var).unsqueeze(0) * eps.to(score.dtype), eps
+
+
+def bayesian_cross_entropy(cls_score, cls_var, targets, num_sample, seed, stream=UC_STREAM['bayes_ce']):
+    """loss_utils.py:149-169 (differentiable; the draws replay the device's)."""
+    samples, _ = logit_distort_replay(cls_score, cls_var, num_sample, seed, stream)
+    avg = torch.mean(F.softmax(samples, dim=2), dim=0)
+    sel = -torch.log(avg).gather(1, targets.long().unsqueeze(1))
+    return torch.mean(sel), categorical_mutual_information(samples)
+
+
+class UcHeadsOracle(nn.Module):
+    """The detection heads with cfg.UC.* flags on (R, fc7) features.  flags: dict of the four EN_* booleans."""
+
+    def __init__(self, flags, num_classes=2, bbox_elem=4, fc7=2048, lidar=False):
+        super().__init__()
+        self.flags, self.k, self.e, self.lidar = dict(flags), num_classes, bbox_elem, lidar
+        epi = flags.get('EN_BBOX_EPISTEMIC') or flags.get('EN_CLS_EPISTEMIC')
+        d = fc7 // 4 if epi else fc7                                   # imagenet.py:52-53
+        h = fc7 // 2                                                    # reconstruction constant UC_FC1_DIVISOR
+        self.rates = {'cls': 0.2 if lidar else 0.3, 'bbox': 0.5 if lidar else 0.1}   # imagenet.py:55-56, lidarnet.py:60-61
+        for prefix, key in (('bbox', 'EN_BBOX_EPISTEMIC'), ('cls', 'EN_CLS_EPISTEMIC')):
+            if flags.get(key):
+                setattr(self, prefix + '_fc1', nn.Linear(fc7, h))
+                setattr(self, prefix + '_fc2', nn.Linear(h, d))
+                if lidar:
+                    setattr(self, prefix + '_bn1', nn.BatchNorm1d(h))
+                    setattr(self, prefix + '_bn2', nn.BatchNorm1d(d))
+        self.cls_score_net = nn.Linear(d, num_classes)
+        self.bbox_pred_net = nn.Linear(d, num_classes * bbox_elem)
+        if flags.get('EN_BBOX_ALEATORIC'):
+            self.bbox_al_var_net = nn.Linear(d, num_classes * bbox_elem)
+        if flags.get('EN_CLS_ALEATORIC'):
+            self.cls_al_var_net = nn.Linear(d, num_classes)
+        self.eval()
+
+    def _branch(self, prefix, fc7, on, t, seed):
+        if not on:
+            return fc7, 1
+        fc1, fc2 = getattr(self, prefix + '_fc1'), getattr(self, prefix + '_fc2')
+        bn1, bn2 = getattr(self, prefix + '_bn1', None), getattr(self, prefix + '_bn2', None)
+        p = self.rates[prefix]
+        h = fc1(fc7)
+        h = F.relu(bn1(h) if bn1 is not None else h)
+        h = dropout_replay(h, p, seed, UC_STREAM[prefix + '_drop1'], repeat=t).reshape(t * fc7.shape[0], -1)
+        h = fc2(h)
+        h = F.relu(bn2(h) if bn2 is not None else h)
+        return dropout_replay(h, p, seed, UC_STREAM[prefix + '_drop2']), t
+
+    @torch.no_grad()
+    def test(self, fc7, e_num_sample, a_num_ce_sample, seed, stds, means):
+        f, r, k, e = self.flags, fc7.shape[0], self.k, self.e
+        unc = {}
+        feat_c, tc = self._branch('cls', fc7, f.get('EN_CLS_EPISTEMIC'), e_num_sample, seed)
+        score_s = self.cls_score_net(feat_c).view(tc, r, k)
+        prob_s = F.softmax(score_s, dim=2)
+        cls_prob, cls_score = prob_s.mean(0), score_s.mean(0)
+        if f.get('EN_CLS_ALEATORIC'):
+            logvar = self.cls_al_var_net(feat_c).view(tc, r, k).mean(0)
+            var = torch.exp(logvar)
+            dist, _ = logit_distort_replay(cls_score, var, a_num_ce_sample, seed)
+            unc['a_entropy'] = categorical_entropy(F.softmax(dist, dim=2).mean(0))
+            unc['a_mutual_info'] = categorical_mutual_information(dist)
+            unc['a_cls_var'] = var
+        if f.get('EN_CLS_EPISTEMIC'):
+            unc['e_entropy'] = categorical_entropy(cls_prob)
+            unc['e_mutual_info'] = categorical_mutual_information(score_s)
+            unc['e_cls_var'] = compute_bbox_var(prob_s) if tc > 1 else torch.zeros_like(cls_prob)
+        feat_b, tb = self._branch('bbox', fc7, f.get('EN_BBOX_EPISTEMIC'), e_num_sample, seed)
+        box_s = self.bbox_pred_net(feat_b).view(tb, r, k * e)
+        bbox_pred = box_s.mean(0)
+        stds_t, means_t = torch.tensor(stds).repeat(k), torch.tensor(means).repeat(k)
+        if f.get('EN_BBOX_ALEATORIC'):
+            unc['a_bbox_var'] = torch.exp(self.bbox_al_var_net(feat_b).view(tb, r, k * e).mean(0))
+        if f.get('EN_BBOX_EPISTEMIC'):
+            unc['e_bbox_var'] = (compute_bbox_var(box_s) if tb > 1 else torch.zeros_like(bbox_pred)) * stds_t * stds_t
+        return cls_score, cls_prob, bbox_pred, bbox_pred * stds_t + means_t, {n: unc[n] for n in UNCERTAINTY_ORDER if n in unc}
+
+
+# ----------------------------------------------------------------------------------------------
 # LiDAR-BEV detector — lib/nets/lidarnet.py:28-151 on the RECONSTRUCTED Network contract: 15-plane stem,
 # layer4 without BatchNorm (non-FPN), 3-D anchors + their BEV rectangles for the RPN, 7-DoF decode.
 # ----------------------------------------------------------------------------------------------
