@@ -51,6 +51,14 @@ __device__ __forceinline__ void decode_box_lidar(float x1, float y1, float x2, f
 // torch.clamp(v, lo, hi) = min(max(v, lo), hi)
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
+// NAMED CHOICE: what happens when IoU == threshold exactly.  torchvision 0.4.0 (req.txt:283) is
+// not vendored; to the builders' knowledge its CUDA kernel suppresses on `iou > threshold` while its CPU kernel of that
+// release used `>=` (the two were unified on `>` later).  The reference runs its detectors on the GPU whenever one is
+// present (tools/test_net.py:286-288 falls back to 'cpu' only without CUDA), so the device path, the oracle
+// (oracle/frcnn_oracle.py NMS_SUPPRESS_AT_EQUAL) and every fixture follow the strict form.  Flip both constants together;
+// tests/test_gpu_parity.py::test_nms_threshold_edge documents the behaviour.
+constexpr bool NMS_SUPPRESS_AT_EQUAL = false;
+
 // IoU test of torchvision.ops.nms: areas (x2-x1)*(y2-y1) without +1, suppress when iou > thresh.
 __device__ __forceinline__ bool iou_gt(const float* a, const float* b, float thresh) {
   const float xx1 = fmaxf(a[0], b[0]), yy1 = fmaxf(a[1], b[1]);
@@ -59,7 +67,8 @@ __device__ __forceinline__ bool iou_gt(const float* a, const float* b, float thr
   const float inter = w * h;
   const float sa = (a[2] - a[0]) * (a[3] - a[1]);
   const float sb = (b[2] - b[0]) * (b[3] - b[1]);
-  return inter / (sa + sb - inter) > thresh;
+  const float iou = inter / (sa + sb - inter);
+  return NMS_SUPPRESS_AT_EQUAL ? iou >= thresh : iou > thresh;
 }
 
 // fp32 -> u32 key whose ASCENDING order is DESCENDING score (-0 is folded into +0 first).

@@ -118,14 +118,17 @@ def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=F
     mine = collate.shard_frames(num_images, rank, world)
     steps = (num_images + world - 1) // world
     dev = torch.device(net._device)
+    # rows per class in the exchanged record: the max_dets cut keeps every detection that TIES with the max_dets-th best
+    # score (lib/model/test.py:213-221), so a record of max_dets rows could truncate; one row per RoI cannot
+    max_out = max(max_dets, int(cfg.TEST.RPN_POST_NMS_TOP_N)) if max_dets > 0 else int(cfg.TEST.RPN_POST_NMS_TOP_N)
     for s in range(steps):
-        dets = torch.zeros((k, max_dets, elem), dtype=torch.float32, device=dev)
+        dets = torch.zeros((k, max_out, elem), dtype=torch.float32, device=dev)
         counts = torch.zeros((k,), dtype=torch.int32, device=dev)
         blobs = db.blobs_at(mine[s], mode) if s < len(mine) else None
         if blobs is not None and blobs.get('data') is not None:
-            dets, counts = detect_frame_device(net, blobs['data'], blobs['info'], thresh, max_dets, max_dets)
+            dets, counts = detect_frame_device(net, blobs['data'], blobs['info'], thresh, max_dets, max_out)
         if distributed:
-            rows = collate.unpack_records(collate.gather_records(collate.pack_record(dets, counts)), k, max_dets, elem)
+            rows = collate.unpack_records(collate.gather_records(collate.pack_record(dets, counts)), k, max_out, elem)
             frames_of_step = [(r, s * world + r) for r in range(world) if s * world + r < num_images]
         else:
             d, c = dets.cpu().numpy(), counts.cpu().numpy()

@@ -82,17 +82,28 @@ class DataParallelOptimizer:
         self.optimizer = optimizer
         self.bucket = bucket
         self.group = group
+        self._reduced = False
 
     @property
     def param_groups(self):
         return self.optimizer.param_groups
 
+    def reduce(self):
+        """Average the accumulated gradients over the ranks NOW.  ``Network.train_step`` calls this before it clips, so
+        the clip acts on the gradient of the whole N-GPU batch (the value that is stepped), as in the single-process
+        reference, instead of on each rank's share."""
+        if not self._reduced:
+            self.bucket.all_reduce_mean(self.group)
+            self._reduced = True
+
     def step(self):
-        self.bucket.all_reduce_mean(self.group)
+        self.reduce()
         self.optimizer.step()
+        self._reduced = False
 
     def zero_grad(self, set_to_none=False):
         self.bucket.zero()
+        self._reduced = False
 
     def state_dict(self):
         return self.optimizer.state_dict()
@@ -156,28 +167,66 @@ class SolverWrapper:
     def _snapshot_name(self, it, ext):
         return os.path.join(self.output_dir, '%s_%s_iter_%d%s' % (cfg.NET_TYPE, cfg.TRAIN.SNAPSHOT_PREFIX, it, ext))
 
-    def snapshot(self, it):
-        """train_val.py:100-129: weights as .pth, numpy RNG + sampler pointers + iteration as consecutive pickles.
-        Only rank 0 writes."""
-        sfile, nfile = self._snapshot_name(it, '.pth'), self._snapshot_name(it, '.pkl')
-        if self.rank != 0:
-            return sfile, nfile
-        os.makedirs(self.output_dir, exist_ok=True)
-        torch.save(self.net.state_dict(), sfile)
+    def _dist(self):
+        return self.data_parallel and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def _sampler_state(self):
         cur, perm = self.data_gen.get_pointer() if hasattr(self.data_gen, 'get_pointer') else (0, None)
         cur_val, perm_val = (self.data_gen_val.get_pointer() if hasattr(self.data_gen_val, 'get_pointer')
                              else (0, None))
-        with open(nfile, 'wb') as fid:
-            for obj in (np.random.get_state(), cur, perm, cur_val, perm_val, it):
-                pickle.dump(obj, fid, pickle.HIGHEST_PROTOCOL)
-        self.log('Wrote snapshot to: %s' % sfile)
+        return (np.random.get_state(), cur, perm, cur_val, perm_val)
+
+    def _sync_batchnorm_statistics(self):
+        """Replicas see different frames, so BatchNorm running statistics (LiDAR detector, FIXED_BLOCKS == -1) drift
+        apart; before a snapshot every rank takes the mean over the ranks, so the saved weights describe all of them and
+        the replicas continue from identical buffers."""
+        world = dist.get_world_size()
+        for name, buf in self.net.named_buffers():
+            if buf.dtype.is_floating_point and (name.endswith('running_mean') or name.endswith('running_var')):
+                dist.all_reduce(buf.data, op=dist.ReduceOp.SUM)
+                buf.data.div_(world)
+
+    def snapshot(self, it):
+        """train_val.py:100-129: weights as .pth, numpy RNG + sampler pointers + iteration as consecutive pickles
+        (rank 0's, in the reference's order).  Data parallel: every rank contributes ITS sampler / RNG state (appended
+        as a seventh object, a list over ranks), BatchNorm statistics are averaged first, rank 0 writes and everyone
+        waits for the files."""
+        sfile, nfile = self._snapshot_name(it, '.pth'), self._snapshot_name(it, '.pkl')
+        states = None
+        if self._dist():
+            self._sync_batchnorm_statistics()
+            states = [None] * dist.get_world_size()
+            dist.all_gather_object(states, self._sampler_state())
+        if self.rank == 0:
+            os.makedirs(self.output_dir, exist_ok=True)
+            torch.save(self.net.state_dict(), sfile)
+            st0, cur, perm, cur_val, perm_val = self._sampler_state()
+            with open(nfile, 'wb') as fid:
+                for obj in (st0, cur, perm, cur_val, perm_val, it):
+                    pickle.dump(obj, fid, pickle.HIGHEST_PROTOCOL)
+                if states is not None:
+                    pickle.dump(states, fid, pickle.HIGHEST_PROTOCOL)
+            self.log('Wrote snapshot to: %s' % sfile)
+        if self._dist():
+            dist.barrier()
         return sfile, nfile
 
     def from_snapshot(self, sfile, nfile):
-        """train_val.py:131-150."""
+        """train_val.py:131-150.  With a per-rank state list in the file every rank resumes ITS OWN sampler position and
+        numpy RNG (restoring rank 0's everywhere would make the N-GPU batch N copies of one frame)."""
         self.net.load_state_dict(torch.load(str(sfile), map_location=self.net._device))
         with open(nfile, 'rb') as fid:
             st0, cur, perm, cur_val, perm_val, last = [pickle.load(fid) for _ in range(6)]
+            try:
+                states = pickle.load(fid)
+            except EOFError:
+                states = None
+        if states is not None and self.rank < len(states):
+            st0, cur, perm, cur_val, perm_val = states[self.rank]
+        elif self._dist() and self.rank > 0:
+            # a single-process snapshot resumed on several GPUs: decorrelate the replicas deterministically
+            np.random.seed((cfg.RNG_SEED + 7919 * self.rank) % (2 ** 32))
+            st0 = np.random.get_state()
         np.random.set_state(st0)
         if hasattr(self.data_gen, 'set_pointer'):
             self.data_gen.set_pointer(cur, perm)

@@ -494,9 +494,18 @@ class Network(nn.Module):
         """One forward/backward on a frame (lib/model/train_val.py:458).  Gradients accumulate over calls and the
         optimizer steps only when ``update_weights`` (pseudo-batching, train_val.py:379-382).  Returns the loss."""
         self.forward(blobs['data'], blobs['info'], blobs['gt_boxes'], blobs.get('gt_boxes_dc'), mode='TRAIN')
+        counts = self._proposal_targets.get('counts') if isinstance(self._proposal_targets, dict) else None
+        if counts is not None:
+            n_fg, n_bg = [int(v) for v in counts[:2].cpu()]
+            if n_fg + n_bg == 0:
+                # the reference stops here (pdb.set_trace, proposal_target_layer.py:232-235): no RoI is a foreground or
+                # a background candidate (all masked by IGNORE_DC, or every IoU outside both bands)
+                raise RuntimeError("proposal_target_layer: neither foreground nor background candidate RoIs in this frame")
         loss = self._losses['total_loss']
         self.backward(loss)
         if update_weights:
+            if hasattr(optimizer, 'reduce'):
+                optimizer.reduce()        # data parallel: average over the ranks first, clip the batch gradient after
             self._clip_gradients()
             optimizer.step()
             optimizer.zero_grad()

@@ -153,6 +153,12 @@ def stable_desc_order(scores):
     return torch.sort(s, descending=True, stable=True)[1]
 
 
+# NAMED CHOICE shared with the device code (csrc/box_math.h NMS_SUPPRESS_AT_EQUAL): a box whose IoU with a kept box EQUALS
+# the threshold survives (`>`, the library's CUDA kernel and every release after the pinned one); the pinned release's CPU
+# kernel is believed to have used `>=`.  torchvision is not available here, so the choice is recorded, not verified.
+NMS_SUPPRESS_AT_EQUAL = False
+
+
 def nms(boxes, scores, thresh):
     boxes = torch.as_tensor(boxes, dtype=torch.float32)
     n = boxes.shape[0]
@@ -180,7 +186,7 @@ def nms(boxes, scores, thresh):
             h = np.maximum(np.float32(0), yy2 - yy1)
             inter = w * h
             ovr = inter / (areas[i] + areas[i + 1:] - inter)
-            dead[i + 1:] |= ovr > thr
+            dead[i + 1:] |= (ovr >= thr) if NMS_SUPPRESS_AT_EQUAL else (ovr > thr)
     return torch.as_tensor(np.asarray(keep, dtype=np.int64))
 
 

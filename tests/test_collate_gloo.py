@@ -84,7 +84,11 @@ class _FakeDb:
 
 def _fake_detect(net, data, info, thresh, max_dets, max_out):
     dets, counts = _fake_frame(int(data[0, 0, 0, 0]))
-    return torch.from_numpy(dets), torch.from_numpy(counts)
+    # test_net asks for one row per RoI (max_out >= max_dets) so that ties at the max_dets-th score survive the record
+    assert max_out >= max_dets
+    padded = np.zeros((dets.shape[0], max_out, dets.shape[2]), np.float32)
+    padded[:, :dets.shape[1]] = dets
+    return torch.from_numpy(padded), torch.from_numpy(counts)
 
 
 def _test_net_worker(rank, world, port, out_dir):

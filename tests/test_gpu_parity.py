@@ -261,7 +261,10 @@ def test_nms_keep_bit_exact(hip, kind, n):
 
 
 def test_nms_threshold_edge(hip):
+    """Documents the NAMED CHOICE NMS_SUPPRESS_AT_EQUAL = false (csrc/box_math.h, oracle): box 1 has IoU exactly 0.5 with
+    box 0 and SURVIVES at threshold 0.5 (suppression needs iou > threshold); at 0.49 it is suppressed."""
     ops = _ops()
+    assert O.NMS_SUPPRESS_AT_EQUAL is False
     boxes = torch.tensor([[0., 0, 10, 10], [0, 0, 10, 5], [0, 0, 10, 7], [20, 20, 30, 30], [0, 0, 10, 7.0001]])
     for thr, want in ((0.5, [0, 1, 3]), (0.49, [0, 3]), (0.7, [0, 1, 2, 3])):
         k, c, _ = ops.nms_sorted(boxes.to(DEV), thr)

@@ -153,3 +153,79 @@ def test_data_parallel_step_matches_single_process_average(tmp_path):
             sgd.zero_grad()
     for k, v in ref.state_dict().items():
         assert torch.allclose(v, w0[k], atol=1e-6), k
+
+
+class _BnStubNet(_StubNet):
+    """Adds a BatchNorm whose running statistics drift per rank, and the clip-after-reduce protocol of Network.train_step."""
+
+    def __init__(self):
+        super().__init__()
+        self.bn = torch.nn.BatchNorm1d(4)
+
+    def train_step(self, blobs, optimizer, update_weights=False):
+        loss = ((self.lin(self.bn(blobs["data"])) - blobs["y"]) ** 2).sum()
+        loss.backward()
+        if update_weights:
+            optimizer.reduce()
+            self.clipped_input = self.lin.weight.grad.clone()        # what the clip sees = the averaged gradient
+            self.lin.weight.grad.clamp_(-0.5, 0.5)
+            optimizer.step()
+            optimizer.zero_grad()
+        return float(loss.item())
+
+
+def _dp_resume_worker(rank, world, port, out_dir):
+    import pickle
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    C.reset_cfg()
+    C.cfg.NET_TYPE = "image"
+    C.cfg.TRAIN.SNAPSHOT_ITERS = 3
+    C.cfg.TRAIN.STEPSIZE = [1000]
+    snap = os.path.join(out_dir, "snap")
+    torch.manual_seed(3 + rank)
+    net = _BnStubNet()
+    net.train()
+    frames = _Frames(200 + rank)
+    frames.cur = 10 * rank                       # ranks sit at different sampler positions
+    np.random.seed(500 + rank)
+    solver = train_val.SolverWrapper(net, 2, frames, output_dir=snap, batch_size=2, sum_size=0, log=lambda *_: None)
+    solver.train_model(3)
+    np_state_at_snapshot = np.random.get_state()[1][:4].tolist()
+    # a fresh process group member resumes: its OWN pointer and numpy state come back, not rank 0's
+    net2 = _BnStubNet()
+    frames2 = _Frames(0)
+    np.random.seed(0)
+    solver2 = train_val.SolverWrapper(net2, 2, frames2, output_dir=snap, batch_size=2, sum_size=0, log=lambda *_: None)
+    solver2.construct_graph()
+    _, nfiles, sfiles = solver2.find_previous()
+    last = solver2.from_snapshot(sfiles[-1], nfiles[-1])
+    out = {"rank": rank, "last": last, "cur_before": 10 * rank + 3, "cur_after": frames2.cur,
+           "np_after": np.random.get_state()[1][:4].tolist(), "np_at_snapshot": np_state_at_snapshot,
+           "bn_mean": net.bn.running_mean.clone(), "bn_mean_loaded": net2.bn.running_mean.clone(),
+           "clipped_input": net.clipped_input, "weight": net.lin.weight.detach().clone()}
+    with open(os.path.join(out_dir, "resume%d.pkl" % rank), "wb") as f:
+        pickle.dump(out, f)
+    dist.destroy_process_group()
+
+
+def test_data_parallel_resume_restores_each_ranks_own_sampler_state(tmp_path):
+    """a resume used to put rank 0's sampler / RNG state on every rank (the N-GPU batch became N
+    copies of one frame), nothing waited for the snapshot, BatchNorm statistics diverged, and the gradient clip ran
+    before the all-reduce."""
+    import pickle
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_resume_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [pickle.load(open(tmp_path / ("resume%d.pkl" % i), "rb")) for i in range(2)]
+    for x in r:
+        assert x["last"] == 3 and x["cur_after"] == x["cur_before"]          # own pointer
+        assert x["np_after"] == x["np_at_snapshot"]                           # own numpy RNG stream
+    assert r[0]["cur_after"] != r[1]["cur_after"] and r[0]["np_after"] != r[1]["np_after"]
+    # BatchNorm statistics were averaged before saving: identical on both ranks and equal to what the file holds
+    assert torch.equal(r[0]["bn_mean"], r[1]["bn_mean"]) and torch.equal(r[0]["bn_mean"], r[0]["bn_mean_loaded"])
+    # the clip acted on the averaged gradient: both ranks saw the same tensor and stepped to the same weights
+    assert torch.equal(r[0]["clipped_input"], r[1]["clipped_input"]) and torch.equal(r[0]["weight"], r[1]["weight"])
