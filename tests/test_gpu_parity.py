@@ -713,25 +713,28 @@ def _bev_blob(h, w, seed):
     return (rng.random((1, h, w, 15)) * (rng.random((1, h, w, 15)) < 0.05)).astype(np.float32)
 
 
-def test_lidar_detector_stagewise_against_oracle(hip):
-    """LiDAR detector on a 208x176 BEV blob (scale 0.5).  As for the image detector, the index-producing stages
-    are re-run on the ORACLE's intermediate tensors so that conv rounding noise cannot blur index parity."""
+@pytest.mark.parametrize("bev_h,bev_w", [(208, 176), (400, 350)])       # (400, 350, 15) = BASELINE.json configs[2]
+def test_lidar_detector_stagewise_against_oracle(hip, bev_h, bev_w):
+    """LiDAR detector on a BEV blob at --scale 0.5, up to the full 400 x 350 x 15 grid of lib/roi_data_layer/
+    minibatch.py:434-438.  As for the image detector, the index-producing stages are re-run on the ORACLE's
+    intermediate tensors so that conv rounding noise cannot blur index parity."""
     from faster_rcnn_pytorch_multimodal_amd import ops
     from faster_rcnn_pytorch_multimodal_amd.layer_utils.proposal_layer import proposal_layer
     from faster_rcnn_pytorch_multimodal_amd.model import config as C
     from faster_rcnn_pytorch_multimodal_amd.utils.filter_predictions import filter_and_draw_prep
     net, oracle = _build_lidar_pair()
-    data = _bev_blob(208, 176, 3)
-    info = np.array([0, 176, 0, 208, 0, 12, 0.5], np.float32)
+    data = _bev_blob(bev_h, bev_w, 3)
+    info = np.array([0, bev_w, 0, bev_h, 0, 12, 0.5], np.float32)
     cs_r, cp_r, pb_r, rois_r, _ = oracle.test_frame(data, info)
     d = oracle._dbg
     cs, cp, pb, rois, _ = net.test_frame(data, info)
     p = net._predictions
     assert net.resnet.conv1.weight.shape[1] == 15 and pb.shape[1] == 14
+    assert net._act_summaries["conv"].shape[1:3] == ((bev_h + 15) // 16, (bev_w + 15) // 16)
     _close_feat(net._act_summaries["conv"].cpu().permute(0, 3, 1, 2).numpy(), d["net_conv"].numpy(), "net_conv", 5e-5)
     np.testing.assert_array_equal(net._anchors.cpu().numpy(), d["anchors"].numpy())
     np.testing.assert_array_equal(net._anchors_3d.cpu().numpy(), d["anchors_3d"].numpy())
-    # proposal_layer with the reference signature on the oracle's probabilities / deltas (13*11*2 = 286 anchors)
+    # proposal_layer with the reference signature on the oracle's probabilities / deltas (13*11*2 = 286 or 25*22*2 = 1100 anchors)
     blob, scores, a3 = proposal_layer(d["rpn_cls_prob"].to(DEV), d["rpn_bbox_pred"].to(DEV), info, "TEST",
                                       d["anchors"].to(DEV), d["anchors_3d"].to(DEV), 2)
     assert blob.shape[0] == rois_r.shape[0]
@@ -1347,27 +1350,33 @@ def _build_fpn_pair(seed=21):
     return net, oracle
 
 
-def _fpn_case():
+def _fpn_case(h=256, w=320):
+    """(256, 320): quick case; (600, 1000): BASELINE.json configs[3], the frame tools/trainval_net.py trains on."""
     rng = np.random.default_rng(5)
-    data = (rng.standard_normal((1, 256, 320, 3)) * 50).astype(np.float32)
-    info = np.array([0, 320, 0, 256, 0, 0, 1.0], np.float32)
+    data = (rng.standard_normal((1, h, w, 3)) * 50).astype(np.float32)
+    info = np.array([0, w, 0, h, 0, 0, 1.0], np.float32)
+    sx, sy = w / 320.0, h / 256.0
     gt = np.array([[20, 30, 69, 79, 1], [100, 20, 219, 139, 1], [60, 10, 299, 249, 1], [200, 150, 260, 230, 1]], np.float32)
+    gt[:, 0:4:2] *= sx
+    gt[:, 1:4:2] *= sy
     g = torch.Generator().manual_seed(2)
-    jit = torch.from_numpy(gt[:, :4])[torch.arange(120) % 4] + (torch.rand(120, 4, generator=g) - 0.5) * 12
-    rnd = _rand_boxes(380, g, extent=(320, 256), max_wh=200)
+    jit = torch.from_numpy(gt[:, :4])[torch.arange(120) % 4] + (torch.rand(120, 4, generator=g) - 0.5) * 12 * min(sx, sy)
+    rnd = _rand_boxes(380, g, extent=(w, h), max_wh=200 * min(sx, sy))
     boxes = torch.cat((jit, rnd), 0)
-    boxes[:, 0::2] = boxes[:, 0::2].clamp(0, 319)
-    boxes[:, 1::2] = boxes[:, 1::2].clamp(0, 255)
+    boxes[:, 0::2] = boxes[:, 0::2].clamp(0, w - 1)
+    boxes[:, 1::2] = boxes[:, 1::2].clamp(0, h - 1)
     rois = torch.cat((torch.zeros(len(boxes), 1), boxes), 1)
     return data, info, gt, rois, torch.rand(len(boxes), 1, generator=g)
 
 
-def test_fpn_train_step_matches_oracle_autograd(hip):
+@pytest.mark.parametrize("h,w", [(256, 320), (600, 1000)])
+def test_fpn_train_step_matches_oracle_autograd(hip, h, w):
     """Same weights, same frame, same sampled targets (injected from the oracle so the RNG streams do not matter):
-    pyramid, RoI features, the four losses and the parameter gradients must agree with torch-CPU autograd."""
+    pyramid, RoI features, the four losses and the parameter gradients must agree with torch-CPU autograd - also at the
+    full 1000 x 600 frame of BASELINE.json configs[3] (937 500 anchors on p2)."""
     from faster_rcnn_pytorch_multimodal_amd.model import config as C
     net, oracle = _build_fpn_pair()
-    data, info, gt, rois, scores = _fpn_case()
+    data, info, gt, rois, scores = _fpn_case(h, w)
     losses, d = oracle.train_forward(data, info, gt, generator=torch.Generator().manual_seed(3), proposals=(rois, scores))
     losses["total_loss"].backward()
     assert int((d["labels"] > 0).sum()) >= 20 and len(torch.unique(d["levels"])) >= 3     # fg rows, several levels
