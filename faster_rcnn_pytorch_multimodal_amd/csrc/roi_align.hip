@@ -165,16 +165,19 @@ struct RoiPlanHead {              // first 64 bytes of the workspace
 
 __host__ __device__ inline int plan_pad(int n) { return (n + 63) & ~63; }
 
-// flag of RoI r from the box alone (every workgroup of the plan kernel evaluates it for the RoIs before its own)
+// flag of RoI r from the box alone (every workgroup of the plan kernel evaluates it for the RoIs before its own).
+// Branch-free: the box is loaded unconditionally so that the loads of the whole prefix pass are in flight together.
 __device__ __forceinline__ int roi_flag(const float* __restrict__ rois, int r, int live, const int* __restrict__ level_of_roi,
                                         int level, float spatial_scale, int H, int W, int heavy_loads) {
-  if (level_of_roi && level_of_roi[r] != level) return ROI_SKIP;
-  if (r >= live) return ROI_DEAD;
   const float* roi = rois + (size_t)r * 5;
-  const float roi_width = fmaxf(roi[3] * spatial_scale - roi[1] * spatial_scale, 1.0f);
-  const float roi_height = fmaxf(roi[4] * spatial_scale - roi[2] * spatial_scale, 1.0f);
+  const float x1 = roi[1], y1 = roi[2], x2 = roi[3], y2 = roi[4];
+  const int lvl = level_of_roi ? level_of_roi[r] : level;
+  const float roi_width = fmaxf(x2 * spatial_scale - x1 * spatial_scale, 1.0f);
+  const float roi_height = fmaxf(y2 * spatial_scale - y1 * spatial_scale, 1.0f);
   const int rows_est = min((int)roi_height + 2, H), cols_est = min((int)(roi_width / (float)PLAN_P) + 2, W);
-  return rows_est * cols_est > heavy_loads ? ROI_HEAVY : ROI_LIGHT;
+  int flag = rows_est * cols_est > heavy_loads ? ROI_HEAVY : ROI_LIGHT;
+  flag = r >= live ? ROI_DEAD : flag;
+  return lvl != level ? ROI_SKIP : flag;
 }
 
 // one workgroup per RoI, 2P waves: wave w < P builds column bin w, wave P + w row bin w
@@ -458,8 +461,8 @@ bool planned_ok(int pooled) { return pooled == PLAN_P; }
 
 }  // namespace
 
-// tuning hook: 0 = automatic, 1 = generic, 2 = generic with XCD channel slices, 3 / 4 = planned kernel with 8 / 4 loads
-// in flight per lane (needs a workspace)
+// tuning hook: 0 = automatic (= 4), 1 = generic, 2 = generic with XCD channel slices, 3 / 4 = planned kernel with 8 / 4
+// loads in flight per lane (needs a workspace)
 static int g_roi_variant = 0;
 // estimated loads per lane above which a RoI is split into its P row bins (variant >= 100 sets it: tuning only)
 static int g_roi_heavy_loads = 64;
@@ -493,13 +496,15 @@ extern "C" int frcnn_roi_align_fwd(const float* feat, int h, int w, int c, const
                        wyt);
     int rc = frcnn::check_launch("roi_plan_kernel");
     if (rc != FRCNN_OK) return rc;
-    // persistent grid of 4-wave workgroups: 5 per CU (<= 96 VGPRs), a multiple of nslices so that a workgroup keeps
-    // its slice; never more waves than wave-items in the worst case
+    // persistent grid of 4-wave workgroups, as many as are resident at once: 88 VGPRs with 4 loads in flight per lane =
+    // 5 waves per SIMD = 5 workgroups per CU (measured best: 22.9 us; 8 loads in flight need 104 VGPRs = 4 per CU: 25.5 us).  A multiple of nslices so that a workgroup keeps its slice;
+    // never more waves than wave-items in the worst case
     const long max_wave_items = (long)num_rois * nslices * PLAN_P * PLAN_P;
-    long nwg = 256 * 5;
+    const bool g8 = g_roi_variant == 3;                  // variant 3: 8 loads in flight (104 VGPRs, 4 workgroups per CU)
+    long nwg = 256 * (g8 ? 4 : 5);
     nwg = std::min(nwg, (max_wave_items + 3) / 4);
     nwg = std::max<long>(nslices, nwg / nslices * nslices);
-    if (g_roi_variant == 4)
+    if (!g8)
       hipLaunchKernelGGL(roi_align_fwd_planned<4>, dim3((unsigned)nwg), dim3(256), 0, stream, feat, h, w, c4, nslices, head,
                          items, wxt, wyt, out);
     else

@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--fpn", action="store_true", help="use the trainable convolutions of the FPN train step instead")
     ap.add_argument("--batch", type=int, default=1, help="frames per launch (n is multiplied; us/frame is per frame)")
     ap.add_argument("--autotune", action="store_true", help="time every (tile, split-K) candidate first")
+    ap.add_argument("--streams", type=int, default=1, help="launch the same convolution on S HIP streams at once (own "
+                    "buffers each): aggregate rate of a saturated chip, what the 4-frames-in-flight timed mode sees")
     args = ap.parse_args()
     from faster_rcnn_pytorch_multimodal_amd import _hip, ops
     lib = _hip.load()
@@ -112,14 +114,29 @@ def main():
             run = lambda: ops.conv2d_bwd_weight(x, y, r, r, stride=stride, pad=pad)
         for _ in range(2):
             run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(args.reps):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        us = 1e3 * e0.elapsed_time(e1) / args.reps
+        if args.streams > 1 and args.mode == "fwd":
+            import time
+            sts = [torch.cuda.Stream() for _ in range(args.streams)]
+            xs = [x.clone() for _ in sts]
+            ys = [torch.empty_like(y) for _ in sts]
+            rss = [rs.clone() if rs is not None else None for _ in sts]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.reps):
+                for st, xi, yi, ri in zip(sts, xs, ys, rss):
+                    with torch.cuda.stream(st):
+                        ops.conv2d_nhwc(xi, wt, sc, sh, ri, stride=stride, pad=pad, relu=True, split_k=args.split, out=yi)
+            torch.cuda.synchronize()
+            us = 1e6 * (time.perf_counter() - t0) / (args.reps * args.streams)
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(args.reps):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / args.reps
         fl = 2.0 * n * ho * wo * k * r * r * c
         tot_us += us * calls / args.batch
         tot_fl += fl * calls / args.batch

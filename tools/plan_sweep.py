@@ -56,6 +56,8 @@ def variants(base):
     out["big_m_256x128"] = [with_plan(r, 0, 1) if m_of(r) >= 9000 and r[4] >= 128 and r[3] % 32 == 0 else list(r) for r in base]
     out["layer3_128x64_fill"] = [with_plan(r, 3, fill_splits(r, 3)) if m_of(r) == 2394 else list(r) for r in base]
     out["layer3_128x128_fill"] = [with_plan(r, 2, fill_splits(r, 2)) if m_of(r) == 2394 else list(r) for r in base]
+    out["layer3_nosplit"] = [with_plan(r, r[10], 1) if m_of(r) == 2394 else list(r) for r in base]
+    out["layer3_split2"] = [with_plan(r, r[10], min(r[11], 2)) if m_of(r) == 2394 else list(r) for r in base]
     return out
 
 
@@ -75,6 +77,7 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "plan_sweep.json"))
     ap.add_argument("--only", default="")
+    ap.add_argument("--streams", default="4,1", help="comma list of frames-in-flight settings to time")
     args = ap.parse_args()
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     base_path = args.out.replace(".json", "_base_plans.json")
@@ -88,10 +91,12 @@ def main():
             continue
         path = args.out.replace(".json", "_%s.json" % name)
         json.dump(rows, open(path, "w"))
-        r4 = run_bench(path, args.steps, 4)
-        r1 = run_bench(path, args.steps, 1)
-        results[name] = {"fps_4_streams": r4[0], "fps_1_stream": r1[0], "isolated_conv_tflops": r4[1]}
-        print("%-24s 4 streams %7.1f fps   1 stream %7.1f fps   isolated conv %6.1f TFLOP/s" % (name, r4[0], r1[0], r4[1]), flush=True)
+        res = {}
+        for st in [int(v) for v in args.streams.split(",")]:
+            res[st] = run_bench(path, args.steps, st)
+        results[name] = {"fps_by_streams": {st: v[0] for st, v in res.items()}, "isolated_conv_tflops": list(res.values())[0][1]}
+        print("%-24s %s   isolated conv %6.1f TFLOP/s" % (name, "  ".join("%d streams %6.1f fps" % (st, v[0]) for st, v in res.items()),
+                                                         list(res.values())[0][1]), flush=True)
     json.dump(results, open(args.out, "w"), indent=1)
 
 
