@@ -32,6 +32,7 @@ THRESH, MAX_DETS = 0.5, 100          # tools/test_net.py:290
 WEIGHT_SEED, BN_MODE = 3, "tame"     # cfg.RNG_SEED; see DESIGN.md "workload" for why BN is damped
 MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix peak
 HBM_PEAK_GBS = 8000.0
+PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")   # committed rocprofv3 PMC passes, newest first
 
 
 def synthetic_frame(seed):
@@ -57,42 +58,46 @@ def build_net(device):
 
 
 def conv_roofline(net, frame, info, steps):
-    """Per-launch HIP-event timing of every conv kernel over `steps` eager frames (events are recorded on
-    the launch stream).  Returns the aggregate over all conv launches of a frame."""
+    """Per-dispatch durations of every convolution kernel over `steps` eager frames: each launch carries its own
+    start / stop HIP events on the launch stream (frcnn_conv2d_profile_begin / _end -> hipExtLaunchKernelGGL), i.e. the
+    begin -> end time of that dispatch, the quantity rocprofv3 --kernel-trace reports.  Returns the aggregate over all
+    conv launches of a frame (main implicit-GEMM kernels + the split-K second passes)."""
     from faster_rcnn_pytorch_multimodal_amd import ops
     from faster_rcnn_pytorch_multimodal_amd.model.test import detect_frame_device
     detect_frame_device(net, frame, info, THRESH, MAX_DETS, MAX_DETS)
     torch.cuda.synchronize()
     ops.PROFILE = []
-    for _ in range(steps):
-        detect_frame_device(net, frame, info, THRESH, MAX_DETS, MAX_DETS)
-    torch.cuda.synchronize()
-    prof, ops.PROFILE = ops.PROFILE, None
-    # an (event, event) pair with nothing in between still measures the event packets themselves; calibrate that on
-    # the same stream and take it off every interval (rocprofv3's per-dispatch durations do not contain it)
-    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
-    for a, b in pairs:
-        a.record()
-        b.record()
-    torch.cuda.synchronize()
-    null_ms = float(np.median([a.elapsed_time(b) for a, b in pairs]))
+    ops.conv_profile_begin()
+    try:
+        for _ in range(steps):
+            detect_frame_device(net, frame, info, THRESH, MAX_DETS, MAX_DETS)
+        torch.cuda.synchronize()
+    finally:
+        recs = ops.conv_profile_end()
+        shapes, ops.PROFILE = ops.PROFILE, None
+    per_call = [[0.0, 0.0] for _ in shapes]               # [main kernel us, second pass us] per conv2d call
+    for us, call, kind in recs:
+        per_call[call][kind] += us
     per_layer = {}
-    total_ms, total_flops = 0.0, 0.0
-    for shp, e0, e1 in prof:
-        ms = max(e0.elapsed_time(e1) - null_ms, 1e-4)
+    total_us = total_flops = main_us = 0.0
+    for shp, (m_us, e_us) in zip(shapes, per_call):
         fl = shp["flops"] * (3.0 / 4.0 if (shp["r"] == 7 and shp["c"] == 4) else 1.0)  # stem: 3 real channels
-        total_ms += ms
+        total_us += m_us + e_us
+        main_us += m_us
         total_flops += fl
         key = "%dx%dx%d c%d k%d r%d s%d" % (shp["n"], shp["h"], shp["w"], shp["c"], shp["k"], shp["r"], shp["stride"])
         ent = per_layer.setdefault(key, [0, 0.0, 0.0])
         ent[0] += 1
-        ent[1] += ms
+        ent[1] += m_us + e_us
         ent[2] += fl
-    launches = len(prof) / steps
-    return {"ms_per_frame": total_ms / steps, "flops_per_frame": total_flops / steps, "launches_per_frame": launches,
-            "event_pair_overhead_us": 1e3 * null_ms,
-            "per_layer": {k: {"calls_per_frame": v[0] / steps, "us_per_call": 1e3 * v[1] / v[0],
-                              "tflops": v[2] / v[1] / 1e9} for k, v in per_layer.items()}}
+    n_main = sum(1 for r in recs if r[2] == 0)
+    n_second = len(recs) - n_main
+    return {"ms_per_frame": 1e-3 * total_us / steps, "flops_per_frame": total_flops / steps,
+            "launches_per_frame": len(shapes) / steps, "main_kernel_avg_us": main_us / max(n_main, 1),
+            "second_pass_launches_per_frame": n_second / steps,
+            "second_pass_avg_us": (total_us - main_us) / max(n_second, 1),
+            "per_layer": {k: {"calls_per_frame": v[0] / steps, "us_per_call": v[1] / v[0],
+                              "tflops": v[2] / v[1] / 1e6} for k, v in per_layer.items()}}
 
 
 def roi_align_timing(net, steps):
@@ -111,7 +116,7 @@ def roi_align_timing(net, steps):
     us = 1e3 * e0.elapsed_time(e1) / steps
     n, h, w, c = feat.shape
     bytes_ = h * w * c * 4 + rois.shape[0] * 7 * 7 * c * 4 + rois.numel() * 4
-    return {"bound": "hbm", "kernel": "roi_align_fwd_sep", "achieved": bytes_ / us / 1e3, "peak": HBM_PEAK_GBS,
+    return {"bound": "hbm", "kernel": "roi_plan_kernel + roi_align_fwd_planned (one frcnn_roi_align_fwd call)", "achieved": bytes_ / us / 1e3, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": bytes_ / us / 1e3 / HBM_PEAK_GBS, "traffic": pmc_traffic("roi_align_fwd"),
             "us_per_launch": us,
             "algorithmic_bytes": bytes_}
@@ -222,24 +227,27 @@ def map_delta(net, sd, frames_host, info):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/r01_pmc_traffic.json:
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/r02_pmc_traffic.json:
     FETCH_SIZE and WRITE_SIZE are collected in separate runs, so they cannot be measured inside the timed run)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["kernels"][kernel]["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in PMC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["kernels"][kernel]["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def pmc_mfma_util():
     """MfmaUtil (percent of SIMD cycles with the matrix pipe busy, duration-weighted over the conv launches of the
     roofline frames) from the committed PMC pass; None when the file has no such pass."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return json.load(f)["kernels"]["conv_igemm"]["mfma"]["mfma_util_percent"]
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in PMC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["kernels"]["conv_igemm"]["mfma"]["mfma_util_percent"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def parse_args(argv=None):
@@ -486,16 +494,20 @@ def main(argv=None):
                 "bound": "mfma", "kernel": "conv_igemm_f32 (all instantiations, %d launches/frame)"
                 % round(conv["launches_per_frame"]), "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic("conv_igemm"),
-                "mode": "isolated kernels: eager launches on one stream, per-launch HIP events (the quantity rocprofv3's "
-                        "per-dispatch durations reproduce); the timed run overlaps %d frames, see frac_timed" % n_streams,
+                "mode": "isolated kernels: eager launches on one stream, every dispatch bracketed by its own start / stop HIP "
+                        "events (hipExtLaunchKernelGGL) = rocprofv3's per-dispatch duration; avg_launch_us is per "
+                        "frcnn_conv2d_fwd call (main kernel + split-K second pass); the timed run overlaps %d frames, see "
+                        "frac_timed" % n_streams,
                 "achieved_timed": timed_tflops, "frac_timed": timed_tflops / MFMA_F32_PEAK_TFLOPS,
                 "frac_timed_what": "all conv FLOPs of a frame / ms_per_step of the TIMED run (hipGraph x %d streams) / "
                                    "peak: a lower bound on the conv kernels' rate in the timed mode, since the step also "
                                    "holds every non-conv kernel" % n_streams,
                 "mfma_util_pmc_percent": pmc_mfma_util(),
                 "flops_per_frame": conv["flops_per_frame"], "kernel_ms_per_frame": conv["ms_per_frame"],
-                "event_pair_overhead_us": conv["event_pair_overhead_us"],
-                "avg_launch_us": 1e3 * conv["ms_per_frame"] / conv["launches_per_frame"]}
+                "avg_launch_us": 1e3 * conv["ms_per_frame"] / conv["launches_per_frame"],
+                "main_kernel_avg_us": conv["main_kernel_avg_us"],
+                "second_pass_launches_per_frame": conv["second_pass_launches_per_frame"],
+                "second_pass_avg_us": conv["second_pass_avg_us"]}
             if args.layers:
                 for k, v in sorted(conv["per_layer"].items(), key=lambda kv: -kv[1]["us_per_call"] * kv[1]["calls_per_frame"]):
                     print("%-40s x%-4.0f %9.1f us/call %7.1f TFLOP/s" % (k, v["calls_per_frame"], v["us_per_call"], v["tflops"]),

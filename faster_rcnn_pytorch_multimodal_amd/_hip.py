@@ -23,6 +23,8 @@ PROTOTYPES = {
     "frcnn_conv2d_set_tile": (c_int, [c_int, c_int]),
     "frcnn_conv2d_set_staging": (c_int, [c_int]),
     "frcnn_conv2d_set_autotune": (c_int, [c_int]),
+    "frcnn_conv2d_profile_begin": (c_int, []),
+    "frcnn_conv2d_profile_end": (c_int, [POINTER(c_float), POINTER(c_int), POINTER(c_int), c_int]),
     "frcnn_conv2d_clear_plans": (c_int, []),
     "frcnn_conv2d_export_plans": (c_int, [POINTER(c_int), c_int]),
     "frcnn_conv2d_import_plans": (c_int, [POINTER(c_int), c_int]),

@@ -28,6 +28,8 @@
 // of the tile configuration for split_k == 1.
 #include "common.h"
 
+#include <hip/hip_ext.h>
+
 #include <array>
 #include <map>
 #include <mutex>
@@ -617,6 +619,27 @@ bool lookup_plan(const ShapeKey& key, Plan* pl) {
   return true;
 }
 
+// ---- per-dispatch timing (frcnn_conv2d_profile_begin / _end) -----------------------------------------------------------
+// While a profile is open every kernel of frcnn_conv2d_fwd is launched through hipExtLaunchKernelGGL with its own
+// start / stop events: the pair brackets THAT dispatch on the launch stream (begin -> end of the kernel, the quantity
+// rocprofv3 --kernel-trace reports), without the event-packet overhead two separately recorded events add around a
+// launch.  bench.py's `roofline` is computed from these durations.
+struct ProfRec {
+  hipEvent_t e0, e1;
+  int call, kind;      // frcnn_conv2d_fwd call number since profile_begin; kind 0 = main kernel, 1 = split-K second pass
+};
+std::vector<ProfRec> g_prof;
+bool g_prof_on = false;
+int g_prof_call = -1;
+
+bool prof_events(int kind, hipEvent_t* e0, hipEvent_t* e1) {
+  if (!g_prof_on) return false;
+  if (hipEventCreate(e0) != hipSuccess) return false;
+  if (hipEventCreate(e1) != hipSuccess) { (void)hipEventDestroy(*e0); return false; }
+  g_prof.push_back(ProfRec{*e0, *e1, g_prof_call, kind});
+  return true;
+}
+
 template <int WM, int WN, int TM, int TN, bool ALIGNED>
 int launch_conv(const ConvParams& p, int splits, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -629,7 +652,12 @@ int launch_conv(const ConvParams& p, int splits, hipStream_t stream) {
     configured = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
-  hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, ALIGNED>), grid, dim3(64 * WM * WN), lds, stream, p);
+  hipEvent_t e0, e1;
+  if (prof_events(0, &e0, &e1))
+    hipExtLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, ALIGNED>), grid, dim3(64 * WM * WN), (uint32_t)lds, stream, e0, e1,
+                          0, p);
+  else
+    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, ALIGNED>), grid, dim3(64 * WM * WN), lds, stream, p);
   return frcnn::check_launch("conv_igemm_f32");
 }
 
@@ -645,7 +673,11 @@ int launch_conv_dma(const ConvParams& p, int splits, hipStream_t stream) {
     configured = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
-  hipLaunchKernelGGL((conv_igemm_dma_f32<WM, WN>), grid, dim3(512), lds, stream, p);
+  hipEvent_t e0, e1;
+  if (prof_events(0, &e0, &e1))
+    hipExtLaunchKernelGGL((conv_igemm_dma_f32<WM, WN>), grid, dim3(512), (uint32_t)lds, stream, e0, e1, 0, p);
+  else
+    hipLaunchKernelGGL((conv_igemm_dma_f32<WM, WN>), grid, dim3(512), lds, stream, p);
   return frcnn::check_launch("conv_igemm_dma_f32");
 }
 
@@ -775,8 +807,13 @@ int launch_plan(ConvParams p, const Plan& pl, long M, int k, const float* scale,
   if (pl.splits > 1) {
     const size_t mk = (size_t)M * k;
     const int blocks = (int)std::min<size_t>((mk + 255) / 256, 2048);
-    hipLaunchKernelGGL(conv_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, p.partial, pl.splits, mk, k,
-                       scale, shift, residual, y, relu);
+    hipEvent_t e0, e1;
+    if (prof_events(1, &e0, &e1))
+      hipExtLaunchKernelGGL(conv_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, e0, e1, 0,
+                            (const float*)p.partial, pl.splits, mk, k, scale, shift, residual, y, relu);
+    else
+      hipLaunchKernelGGL(conv_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, p.partial, pl.splits, mk, k,
+                         scale, shift, residual, y, relu);
     return frcnn::check_launch("conv_splitk_epilogue");
   }
   return FRCNN_OK;
@@ -869,8 +906,35 @@ extern "C" int frcnn_conv2d_fwd(const float* x, const float* wgt, const float* s
   FRCNN_REQUIRE(conv_args_ok(n, h, w, c, k, r, s, stride, pad),
                 "conv2d_fwd: bad shape n=%d h=%d w=%d c=%d k=%d r=%d s=%d stride=%d pad=%d (need c%%4==0)", n, h, w, c,
                 k, r, s, stride, pad);
+  if (g_prof_on) ++g_prof_call;
   return run_conv(x, wgt, scale, shift, residual, y, n, h, w, c, k, r, s, stride, pad, relu, split_k, ws, ws_bytes,
                   static_cast<hipStream_t>(stream_), 1, 0, 0);
+}
+
+extern "C" int frcnn_conv2d_profile_begin(void) {
+  for (ProfRec& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  g_prof.clear();
+  g_prof_call = -1;
+  g_prof_on = true;
+  return FRCNN_OK;
+}
+
+extern "C" int frcnn_conv2d_profile_end(float* us, int* call, int* kind, int capacity) {
+  g_prof_on = false;
+  int n = 0;
+  for (ProfRec& r : g_prof) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess && n < capacity && us) {
+      us[n] = ms * 1e3f;
+      call[n] = r.call;
+      kind[n] = r.kind;
+    }
+    ++n;
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  g_prof.clear();
+  return n;      // dispatches recorded (call again with a larger buffer if it exceeds the capacity: the data is gone)
 }
 
 // ------------------------------------------------------------------------------------------------

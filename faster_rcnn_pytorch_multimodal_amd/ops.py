@@ -13,8 +13,8 @@ import torch
 
 from . import _hip
 
-# Optional per-launch timing of the conv kernel (bench.py / tuning): when PROFILE is a list, every
-# conv2d_nhwc call appends (shape dict, start_event, end_event) recorded on the launch stream.
+# Shape log for bench.py / tuning: when PROFILE is a list, every conv2d_nhwc call appends its shape dict, in call order -
+# the order of the call numbers conv_profile_end() reports with the per-dispatch durations.
 PROFILE = None
 
 
@@ -44,6 +44,23 @@ def set_conv_autotune(enable):
     """Turn the convolution plan autotuner on/off (frcnn_conv2d_set_autotune): tune during eager warm-up frames,
     the cached plans are then used inside captured graphs."""
     _hip.check(_hip.load().frcnn_conv2d_set_autotune(int(bool(enable))), "frcnn_conv2d_set_autotune")
+
+
+def conv_profile_begin():
+    """Start per-dispatch timing of the convolution kernels (frcnn_conv2d_profile_begin)."""
+    _hip.check(_hip.load().frcnn_conv2d_profile_begin(), "frcnn_conv2d_profile_begin")
+
+
+def conv_profile_end(capacity=1 << 16):
+    """Stop it; returns a list of (microseconds, conv2d_fwd call number, kind) per dispatch, kind 0 = main kernel,
+    1 = split-K second pass."""
+    us = (ctypes.c_float * capacity)()
+    call = (ctypes.c_int * capacity)()
+    kind = (ctypes.c_int * capacity)()
+    n = _hip.load().frcnn_conv2d_profile_end(us, call, kind, capacity)
+    if n > capacity:
+        raise _hip.HipError("conv_profile_end: %d dispatches > capacity %d" % (n, capacity))
+    return [(float(us[i]), int(call[i]), int(kind[i])) for i in range(n)]
 
 
 def export_conv_plans():
@@ -94,16 +111,12 @@ def conv2d_nhwc(x, w_krsc, scale=None, shift=None, residual=None, stride=1, pad=
             raise _hip.HipError("conv2d_nhwc: residual shape %s != output shape %s" % (tuple(residual.shape), (n, ho, wo, k)))
     ws_bytes = lib.frcnn_conv2d_fwd_ws_bytes(n, h, w, c, k, r, s, stride, pad, split_k)
     ws = _workspace(ws_bytes, x.device) if ws_bytes else None
-    if PROFILE is not None:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
     _hip.check(lib.frcnn_conv2d_fwd(_ptr(x), _ptr(w_krsc), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out), n, h, w,
                                     c, k, r, s, stride, pad, int(bool(relu)), split_k, _ptr(ws), ws_bytes, _stream()),
                "frcnn_conv2d_fwd")
     if PROFILE is not None:
-        ev1.record()
-        PROFILE.append(({"n": n, "h": h, "w": w, "c": c, "k": k, "r": r, "s": s, "stride": stride, "pad": pad,
-                         "flops": 2.0 * n * ho * wo * k * r * s * c}, ev0, ev1))
+        PROFILE.append({"n": n, "h": h, "w": w, "c": c, "k": k, "r": r, "s": s, "stride": stride, "pad": pad,
+                        "flops": 2.0 * n * ho * wo * k * r * s * c})
     return out
 
 

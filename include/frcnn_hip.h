@@ -79,6 +79,14 @@ int frcnn_conv2d_set_tile(int tm, int tn);
  * frcnn_conv2d_fwd_ws_bytes returns room for the largest candidate of a not-yet-tuned shape.  Default: off (the
  * analytic model picks).  frcnn_conv2d_bwd_weight follows the same switch with its own cache (tile 128x128 or 64x64 x
  * pixel splits).  frcnn_conv2d_clear_plans forgets both caches. */
+/* Per-dispatch timing of the kernels frcnn_conv2d_fwd launches (the main implicit-GEMM kernel and, for a split-K
+ * plan, the second pass): between _begin and _end every launch gets its own start / stop HIP events on the launch stream
+ * (hipExtLaunchKernelGGL), i.e. the begin -> end time of that dispatch.  _end synchronises and fills, per dispatch in
+ * launch order, the duration in microseconds, the number of the frcnn_conv2d_fwd call it belongs to (0-based since
+ * _begin) and its kind (0 main kernel, 1 second pass).  Returns the number of dispatches recorded.  Not for use during
+ * stream capture. */
+int frcnn_conv2d_profile_begin(void);
+int frcnn_conv2d_profile_end(float* us, int* call, int* kind, int capacity);
 int frcnn_conv2d_set_autotune(int enable);
 int frcnn_conv2d_clear_plans(void);
 /* The plan cache as a table of 13 ints per entry (shape key n,h,w,c,k,r,s,stride,pad,out_stride; tile index, splits,

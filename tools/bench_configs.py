@@ -113,7 +113,7 @@ def fpn_train(steps, autotune=True):
     ops.PROFILE = []
     net.train_step(blobs, opt, update_weights=False)
     torch.cuda.synchronize()
-    fwd_flops = sum(s["flops"] for s, _, _ in ops.PROFILE)
+    fwd_flops = sum(s["flops"] for s in ops.PROFILE)
     ops.PROFILE = None
     losses, dt = _timed_train_windows(net, blobs, opt, steps)
     C.reset_cfg()

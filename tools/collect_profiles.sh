@@ -2,9 +2,9 @@
 # End-of-round evidence on a GPU box (run through gpurun): headline bench, kernel-trace stats of the same command,
 # and the PMC passes (one counter per run, never combined with other trace domains).  The first run saves its tuned
 # conv plans; the profiler runs load them, so they measure exactly the kernels that were timed.
-#   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r1z'
+#   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r2z'
 set -e -o pipefail
-TAG=${1:-r1z}
+TAG=${1:-r2z}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
@@ -19,3 +19,8 @@ for C in FETCH_SIZE WRITE_SIZE MfmaUtil; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/${TAG}_pmc_$C -o pmc -- python3 $R/bench.py --plans $O/${TAG}_plans.json --steps 3 --warmup 1 --no-graph --streams 1 --no-cpu-baseline > $O/${TAG}_$C.log 2>&1
   echo "$C done"
 done
+# training step (BASELINE.json configs[3] names a "rocprof MFMA capture"): MfmaUtil per kernel over the last steps
+rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -d $O/${TAG}_train_pmc -o pmc -- python3 $R/tools/bench_configs.py --train --steps 12 > $O/${TAG}_train_pmc.log 2>&1
+echo "train MfmaUtil done"
+rocprofv3 --kernel-trace --stats -d $O/${TAG}_train_prof -o t -- python3 $R/tools/bench_configs.py --train --steps 12 > $O/${TAG}_train_prof.log 2>&1
+echo "train trace done"

@@ -20,6 +20,9 @@ import sys
 # family -> substring of the kernel name (all template instances of the conv kernel count as one family, like
 # bench.py's per-frcnn_conv2d_fwd-launch timing)
 FAMILIES = {"conv_igemm": "conv_igemm", "roi_align_fwd": "roi_align_fwd", "conv_wgrad_f32": "conv_wgrad_f32"}
+# kernels whose bytes are ADDED to a family without counting as launches of it: one RoIAlign operation = the plan kernel
+# + the pooling kernel, reported per operation
+COMPANIONS = {"roi_plan_kernel": "roi_align_fwd"}
 
 
 # bench.py tunes its conv plans during the first frames (extra candidate launches); its roofline is timed over the
@@ -31,11 +34,14 @@ def per_kernel(directory, counter):
     paths = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
     if not paths:
         raise SystemExit("no *counter_collection.csv under %s" % directory)
-    vals = {}
+    vals, extra = {}, {}
     with open(paths[0], newline="") as f:
         for row in csv.DictReader(f):
             if row["Counter_Name"] != counter:
                 continue
+            for sub, fam in COMPANIONS.items():
+                if sub in row["Kernel_Name"]:
+                    extra[fam] = extra.get(fam, 0.0) + float(row["Counter_Value"])
             for fam, sub in FAMILIES.items():
                 if sub in row["Kernel_Name"]:
                     vals.setdefault(fam, []).append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
@@ -45,7 +51,7 @@ def per_kernel(directory, counter):
         rows.sort()
         if fam in LAST:
             rows = rows[-LAST[fam]:]
-        acc[fam] = (len(rows), sum(v for _, v in rows))
+        acc[fam] = (len(rows), sum(v for _, v in rows) + extra.get(fam, 0.0))
     return acc
 
 
