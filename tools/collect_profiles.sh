@@ -24,3 +24,15 @@ rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -d $O/${TAG}_train_p
 echo "train MfmaUtil done"
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_train_prof -o t -- python3 $R/tools/bench_configs.py --train --steps 12 > $O/${TAG}_train_prof.log 2>&1
 echo "train trace done"
+# summaries (small, these are what gets committed under profiles/); the raw traces stay on the box
+S=$O/${TAG}_summary
+mkdir -p $S
+cd $R
+CMD="python3 bench.py --plans <plans of the timed run> --steps 30 --warmup 5 --no-cpu-baseline (4 frames in flight, hipGraph replay)"
+python3 tools/rocpd_summary.py $O/${TAG}_prof/${TAG}_results.db "$CMD" --conv-cross-check > $S/kernel_stats.md
+python3 tools/pmc_traffic.py $O/${TAG}_pmc_FETCH_SIZE $O/${TAG}_pmc_WRITE_SIZE --mfma=$O/${TAG}_pmc_MfmaUtil "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE|MfmaUtil> --output-format csv -- python3 bench.py --plans <plans of the timed run> --steps 3 --warmup 1 --no-graph --streams 1 --no-cpu-baseline" > $S/pmc_traffic.json
+python3 tools/pmc_mfma.py $O/${TAG}_train_pmc "rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -- python3 tools/bench_configs.py --train --steps 12" --last-frac=0.4 > $S/train_pmc.json
+python3 tools/rocpd_summary.py $O/${TAG}_train_prof/t_results.db "python3 tools/bench_configs.py --train --steps 12 (res101+FPN 1000x600 forward+backward; includes the plan autotuning launches of the warm-up)" > $S/train_kernel_stats.md
+cp $O/${TAG}_bench.json $O/${TAG}_plans.json $S/
+rm -rf $O/${TAG}_prof $O/${TAG}_pmc_FETCH_SIZE $O/${TAG}_pmc_WRITE_SIZE $O/${TAG}_pmc_MfmaUtil $O/${TAG}_train_pmc $O/${TAG}_train_prof
+echo "summaries in $S"; ls -la $S
