@@ -163,3 +163,25 @@ def test_timed_path_against_cpu_oracle_structured_rpn(hip):
     print("timed path vs CPU oracle over %d frames: max |roi diff| %.3e, |cls_prob diff| %.3e, |score diff| %.3e"
           % (n_frames, worst_roi, worst_prob, worst_score))
     assert worst_roi <= 1e-4 and worst_prob <= SCORE_TOL and worst_score <= SCORE_TOL
+
+
+def test_bench_runs_its_collective_path_over_rccl_with_one_rank(hip):
+    """bench.py's N > 1 branch (process group, all_gather_into_tensor of the detection record, max-over-ranks timing, record
+    verification, rank audit) on the RCCL backend itself, with the one rank a 1-GPU box allows.  The multi-rank control flow
+    is covered on CPU by tests/test_bench_launcher.py (gloo); this run is what loads librccl and drives it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, FRCNN_BENCH_FORCE_DIST="1", MASTER_PORT="29577")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR"):
+        env.pop(k, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "4", "--no-cpu-baseline"],
+                         env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    col = out["collective"]
+    assert col["backend"] == "nccl" and col["is_rccl"] and col["rccl_ranks"] == 1 and col["allgather_us_per_step"] > 0
+    assert out["verification"]["equal_to_eager_path"] is True and out["verification"]["timed_steps_checked"] == 12
+    assert out["n_gpus"] == 1 and out["value"] > 50
