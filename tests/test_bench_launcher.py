@@ -26,6 +26,12 @@ def test_gpus_2_self_launches_and_collates_over_gloo():
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout                      # rank 0 only
     out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "verification", "collective"):
+        assert key in out, key                                # the driver's contract (device-only objects aside)
+    assert out["metric"].startswith("frames/sec res101 Faster-RCNN") and out["unit"] == "frames/s"
+    assert out["higher_is_better"] is True and out["vs_baseline"] is None and out["dtype"] == "f32"
+    assert "workload" in out["config"] and "model" not in out["config"] and out["config"]["frames_per_step"] == 2
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2 and out["scaling"] == "weak"
     assert out["value"] is None and "rehearsal" in out["data"]          # never mistaken for a measurement
     col = out["collective"]

@@ -185,3 +185,10 @@ def test_bench_runs_its_collective_path_over_rccl_with_one_rank(hip):
     assert col["backend"] == "nccl" and col["is_rccl"] and col["rccl_ranks"] == 1 and col["allgather_us_per_step"] > 0
     assert out["verification"]["equal_to_eager_path"] is True and out["verification"]["timed_steps_checked"] == 12
     assert out["n_gpus"] == 1 and out["value"] > 50
+    # the measurement objects of the contract, produced by this run's code (not read from a committed file)
+    assert abs(out["value"] - 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]          # one frame per step on one GPU
+    r = out["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_timed")) <= set(r) and r["bound"] == "mfma"
+    assert r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.4 < r["frac"] < r["frac_timed"] < 1.0
+    ra = out["roofline_roi_align"]
+    assert ra["bound"] == "hbm" and ra["unit"] == "GB/s" and abs(ra["frac"] - ra["achieved"] / ra["peak"]) < 1e-9
