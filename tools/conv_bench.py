@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--fpn", action="store_true", help="use the trainable convolutions of the FPN train step instead")
     ap.add_argument("--batch", type=int, default=1, help="frames per launch (n is multiplied; us/frame is per frame)")
     ap.add_argument("--autotune", action="store_true", help="time every (tile, split-K) candidate first")
+    ap.add_argument("--nores", action="store_true", help="drop the residual operand (epilogue traffic experiment)")
+    ap.add_argument("--graph", action="store_true", help="replay the launches from a hipGraph also with one stream")
     ap.add_argument("--streams", type=int, default=1, help="launch the same convolution on S HIP streams at once (own "
                     "buffers each): aggregate rate of a saturated chip, what the 4-frames-in-flight timed mode sees")
     args = ap.parse_args()
@@ -99,7 +101,7 @@ def main():
         sc = torch.rand((k,), generator=g).to(dev) + 0.5
         sh = torch.randn((k,), generator=g).to(dev)
         ho, wo = ops.conv_out_hw(h, w, r, r, stride, pad)
-        rs = torch.randn((n, ho, wo, k), generator=g).to(dev) if res else None
+        rs = torch.randn((n, ho, wo, k), generator=g).to(dev) if (res and not args.nores) else None
         y = torch.empty((n, ho, wo, k), device=dev)
         if args.mode == "fwd":
             run = lambda: ops.conv2d_nhwc(x, wt, sc, sh, rs, stride=stride, pad=pad, relu=True, split_k=args.split, out=y)
@@ -114,18 +116,29 @@ def main():
             run = lambda: ops.conv2d_bwd_weight(x, y, r, r, stride=stride, pad=pad)
         for _ in range(2):
             run()
-        if args.streams > 1 and args.mode == "fwd":
+        if (args.streams > 1 or args.graph) and args.mode == "fwd":
             import time
             sts = [torch.cuda.Stream() for _ in range(args.streams)]
             xs = [x.clone() for _ in sts]
             ys = [torch.empty_like(y) for _ in sts]
             rss = [rs.clone() if rs is not None else None for _ in sts]
+            # each stream replays ONE hipGraph of `reps` launches: an eager loop is paced by the host (~20 us per call),
+            # which hides what the chip does with four small GEMMs in flight
+            graphs = []
+            for st, xi, yi, ri in zip(sts, xs, ys, rss):
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=st):
+                    for _ in range(args.reps):
+                        ops.conv2d_nhwc(xi, wt, sc, sh, ri, stride=stride, pad=pad, relu=True, split_k=args.split, out=yi)
+                graphs.append(gr)
+            for st, gr in zip(sts, graphs):
+                with torch.cuda.stream(st):
+                    gr.replay()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(args.reps):
-                for st, xi, yi, ri in zip(sts, xs, ys, rss):
-                    with torch.cuda.stream(st):
-                        ops.conv2d_nhwc(xi, wt, sc, sh, ri, stride=stride, pad=pad, relu=True, split_k=args.split, out=yi)
+            for st, gr in zip(sts, graphs):
+                with torch.cuda.stream(st):
+                    gr.replay()
             torch.cuda.synchronize()
             us = 1e6 * (time.perf_counter() - t0) / (args.reps * args.streams)
         else:
