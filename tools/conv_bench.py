@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--fpn", action="store_true", help="use the trainable convolutions of the FPN train step instead")
     ap.add_argument("--batch", type=int, default=1, help="frames per launch (n is multiplied; us/frame is per frame)")
     ap.add_argument("--autotune", action="store_true", help="time every (tile, split-K) candidate first")
+    ap.add_argument("--shape", action="append", default=[], help="extra shape n,h,w,c,k,r,stride,pad (replaces the table)")
     ap.add_argument("--nores", action="store_true", help="drop the residual operand (epilogue traffic experiment)")
     ap.add_argument("--graph", action="store_true", help="replay the launches from a hipGraph also with one stream")
     ap.add_argument("--streams", type=int, default=1, help="launch the same convolution on S HIP streams at once (own "
@@ -91,6 +92,11 @@ def main():
     tot_us = tot_fl = 0.0
     print("%-24s %6s %9s %9s %8s" % ("shape", "calls", "us/call", "TFLOP/s", "us/frame"))
     shapes = FPN_TRAIN_SHAPES if args.fpn else SHAPES
+    if args.shape:
+        shapes = []
+        for sp in args.shape:
+            v = [int(t) for t in sp.split(',')]
+            shapes.append(("custom " + sp, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], False, 1))
     ops.set_conv_autotune(args.autotune)
     for name, n, h, w, c, k, r, stride, pad, res, calls in shapes:
         if args.only and args.only not in name:
