@@ -75,27 +75,37 @@ def conv_roofline(net, frame, info, steps):
     finally:
         recs = ops.conv_profile_end()
         shapes, ops.PROFILE = ops.PROFILE, None
-    per_call = [[0.0, 0.0] for _ in shapes]               # [main kernel us, second pass us] per conv2d call
-    for us, call, kind in recs:
-        per_call[call][kind] += us
+    per_call = [[0.0, 0.0] for _ in shapes]               # [GEMM kernel us, other passes us] per conv2d call
+    wino_calls = set()
+    for us, call, kind in recs:                           # kind 1 = split-K second pass, 2 = Winograd transform
+        per_call[call][min(kind, 1)] += us
+        if kind == 2:
+            wino_calls.add(call)
     per_layer = {}
-    total_us = total_flops = main_us = 0.0
-    for shp, (m_us, e_us) in zip(shapes, per_call):
+    total_us = total_flops = main_us = executed_flops = 0.0
+    for ci, (shp, (m_us, e_us)) in enumerate(zip(shapes, per_call)):
         fl = shp["flops"] * (3.0 / 4.0 if (shp["r"] == 7 and shp["c"] == 4) else 1.0)  # stem: 3 real channels
         total_us += m_us + e_us
         main_us += m_us
         total_flops += fl
+        # Winograd F(2x2,3x3) calls multiply 16 values per 2x2 output tile instead of 36: what the MFMA pipe executed
+        executed_flops += (2.0 * 16 * shp["n"] * ((shp["h"] + 1) // 2) * ((shp["w"] + 1) // 2) * shp["c"] * shp["k"]
+                           if ci in wino_calls else fl)
         key = "%dx%dx%d c%d k%d r%d s%d" % (shp["n"], shp["h"], shp["w"], shp["c"], shp["k"], shp["r"], shp["stride"])
         ent = per_layer.setdefault(key, [0, 0.0, 0.0])
         ent[0] += 1
         ent[1] += m_us + e_us
         ent[2] += fl
     n_main = sum(1 for r in recs if r[2] == 0)
-    n_second = len(recs) - n_main
+    n_second = sum(1 for r in recs if r[2] == 1)
+    n_wino = sum(1 for r in recs if r[2] == 2)
+    wino_us = sum(r[0] for r in recs if r[2] == 2)
     return {"ms_per_frame": 1e-3 * total_us / steps, "flops_per_frame": total_flops / steps,
+            "executed_flops_per_frame": executed_flops / steps, "winograd_calls_per_frame": len(wino_calls) / steps,
             "launches_per_frame": len(shapes) / steps, "main_kernel_avg_us": main_us / max(n_main, 1),
             "second_pass_launches_per_frame": n_second / steps,
-            "second_pass_avg_us": (total_us - main_us) / max(n_second, 1),
+            "second_pass_avg_us": (total_us - main_us - wino_us) / max(n_second, 1),
+            "winograd_transform_launches_per_frame": n_wino / steps, "winograd_transform_us_per_frame": wino_us / steps,
             "per_layer": {k: {"calls_per_frame": v[0] / steps, "us_per_call": v[1] / v[0],
                               "tflops": v[2] / v[1] / 1e6} for k, v in per_layer.items()}}
 
@@ -256,6 +266,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--conv-algo", type=int, default=0, help="frcnn_conv2d_set_algo: 0 = the autotuner may pick Winograd F(2x2,3x3) "
+                    "for the eligible 3x3 layers (default), 1 = implicit GEMM only")
     ap.add_argument("--plans", default=None, help="JSON file of tuned conv plans: loaded when it exists (profiler runs "
                     "then use exactly the kernels of the timed run), written after warm-up otherwise")
     ap.add_argument("--streams", type=int, default=4,
@@ -342,6 +354,7 @@ def main(argv=None):
         # frames resident in HBM: rank r gets frames r, r+world, ... (BASELINE configs[4]: seeds 0..7 on 8 GPUs)
         frames_host = [synthetic_frame(rank + world * i) for i in range(n_resident)]
         frames = [torch.from_numpy(f).to(device) for f in frames_host]
+        _ops.set_conv_algo(args.conv_algo)
         plans_loaded = False
         if args.plans and os.path.exists(args.plans):
             with open(args.plans) as f:
@@ -507,7 +520,17 @@ def main(argv=None):
                 "avg_launch_us": 1e3 * conv["ms_per_frame"] / conv["launches_per_frame"],
                 "main_kernel_avg_us": conv["main_kernel_avg_us"],
                 "second_pass_launches_per_frame": conv["second_pass_launches_per_frame"],
-                "second_pass_avg_us": conv["second_pass_avg_us"]}
+                "second_pass_avg_us": conv["second_pass_avg_us"],
+                "flops_what": "achieved / frac count the ALGORITHMIC FLOPs of the convolutions (direct form, BASELINE.md section 3); "
+                              "%d of the %d calls per frame ran as Winograd F(2x2,3x3) (autotuned; same fp32 arithmetic, "
+                              "2.25x fewer multiplications), so the MFMA pipe executed executed_flops_per_frame: "
+                              "frac_executed is its utilisation" % (round(conv["winograd_calls_per_frame"]),
+                                                                    round(conv["launches_per_frame"])),
+                "executed_flops_per_frame": conv["executed_flops_per_frame"],
+                "frac_executed": conv["executed_flops_per_frame"] / (1e-3 * conv["ms_per_frame"]) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                "winograd_calls_per_frame": conv["winograd_calls_per_frame"],
+                "winograd_transform_launches_per_frame": conv["winograd_transform_launches_per_frame"],
+                "winograd_transform_us_per_frame": conv["winograd_transform_us_per_frame"]}
             if args.layers:
                 for k, v in sorted(conv["per_layer"].items(), key=lambda kv: -kv[1]["us_per_call"] * kv[1]["calls_per_frame"]):
                     print("%-40s x%-4.0f %9.1f us/call %7.1f TFLOP/s" % (k, v["calls_per_frame"], v["us_per_call"], v["tflops"]),

@@ -20,8 +20,12 @@ PROTOTYPES = {
     "frcnn_last_error": (c_char_p, []),
     "frcnn_conv2d_fwd_ws_bytes": (c_size_t, [c_int] * 10),
     "frcnn_conv2d_fwd": (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 11 + [_P, c_size_t, _P]),
+    "frcnn_conv2d_fwd_pre": (c_int, [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 11 + [_P, c_size_t, _P]),
+    "frcnn_conv2d_winograd_filter_bytes": (c_size_t, [c_int, c_int]),
+    "frcnn_conv2d_winograd_filter": (c_int, [_P, _P, c_int, c_int, _P]),
     "frcnn_conv2d_set_tile": (c_int, [c_int, c_int]),
     "frcnn_conv2d_set_staging": (c_int, [c_int]),
+    "frcnn_conv2d_set_algo": (c_int, [c_int]),
     "frcnn_conv2d_set_autotune": (c_int, [c_int]),
     "frcnn_conv2d_profile_begin": (c_int, []),
     "frcnn_conv2d_profile_end": (c_int, [POINTER(c_float), POINTER(c_int), POINTER(c_int), c_int]),

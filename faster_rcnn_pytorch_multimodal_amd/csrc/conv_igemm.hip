@@ -60,6 +60,10 @@ struct ConvParams {
   int tiles_m, tiles_n;
   int relu;
   int ys, Hy, Wy;  // output pixel (ho, wo) is written at (ho*ys, wo*ys) of an Hy x Wy map (ys = 1: dense)
+  // grouped launch (blockIdx.y = group): element offsets of a group's activations / filter / output.  Used by the
+  // Winograd path (16 independent GEMMs in one launch); 0 for an ordinary convolution (gridDim.y = 1).
+  size_t gx, gw, gy;
+  const float* u_pre;   // host side: Winograd-transformed filter supplied by the caller (frcnn_conv2d_fwd_pre) or nullptr
 };
 
 // XCD-aware bijective remap (guide T1): blocks b and b+8 share an XCD; give each XCD a contiguous
@@ -90,6 +94,7 @@ __device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, 
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc,
                                               int lane) {
+  const size_t goff = (size_t)blockIdx.y * p.gy;   // grouped launches have neither a residual nor split-K slabs
   // The MFMA operands are (weights, activations), so D has the PIXEL on the lane (col = lane&31) and
   // the CHANNEL in the registers: row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Registers 4g..4g+3 are four
   // consecutive channels -> every access of the epilogue is a 16-byte vector per lane, and all
@@ -103,12 +108,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + (wr * TM + i) * 32 + mlane;
     if (m >= p.M) continue;
-    size_t orow = (size_t)m * p.K;  // row of y / residual
+    size_t orow = (size_t)m * p.K + goff;  // row of y / residual
     if (p.ys != 1) {
       const int img = m / (p.Ho * p.Wo);
       const int rem = m - img * p.Ho * p.Wo;
       const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-      orow = ((size_t)(img * p.Hy + ho * p.ys) * p.Wy + wo * p.ys) * p.K;
+      orow = ((size_t)(img * p.Hy + ho * p.ys) * p.Wy + wo * p.ys) * p.K + goff;
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -176,6 +181,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wr = wave / WN, wc = wave % WN;
+  const float* const px = p.x + (size_t)blockIdx.y * p.gx;
+  const float* const pw = p.w + (size_t)blockIdx.y * p.gw;
 
   const int ntiles = p.tiles_m * p.tiles_n;
   const int tile = xcd_remap(blockIdx.x, ntiles);
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
       for (int i = 0; i < PA; ++i) {
         const int hi = a_hi0[i] + tr, wi = a_wi0[i] + ts;
         const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        ra[i] = ok ? *reinterpret_cast<const f32x4*>(p.x + a_base[i] + koff) : f32x4{0.f, 0.f, 0.f, 0.f};
+        ra[i] = ok ? *reinterpret_cast<const f32x4*>(px + a_base[i] + koff) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       tc += BK;
       if (tc == p.C) {
@@ -243,14 +250,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
       for (int i = 0; i < PA; ++i) {
         const int hi = a_hi0[i] + r, wi = a_wi0[i] + s;
         const bool ok = kok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        ra[i] = ok ? *reinterpret_cast<const f32x4*>(p.x + a_base[i] + koff) : f32x4{0.f, 0.f, 0.f, 0.f};
+        ra[i] = ok ? *reinterpret_cast<const f32x4*>(px + a_base[i] + koff) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
       const int n = n0 + j * RPP + row0;
       const bool ok = n < p.K && kflat < p.Ktot;
-      rb[j] = ok ? *reinterpret_cast<const f32x4*>(p.w + (size_t)n * p.Ktot + kflat) : f32x4{0.f, 0.f, 0.f, 0.f};
+      rb[j] = ok ? *reinterpret_cast<const f32x4*>(pw + (size_t)n * p.Ktot + kflat) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto store_tiles = [&](int buf) {
@@ -348,6 +355,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_f32(const ConvParams p)
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wr = wave / WN, wc = wave % WN;
+  const float* const px = p.x + (size_t)blockIdx.y * p.gx;
+  const float* const pw = p.w + (size_t)blockIdx.y * p.gw;
   const int ntiles = p.tiles_m * p.tiles_n;
   const int tile = xcd_remap(blockIdx.x, ntiles);
   int tile_m, tile_n;
@@ -383,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_f32(const ConvParams p)
   for (int j = 0; j < PB; ++j) {
     const int row = (wave * PB + j) * 8 + lrow;
     const int n = n0 + row;
-    b_src[j] = n < p.K ? p.w + (size_t)n * p.Ktot + (lchunk ^ ((row >> 1) & 7)) * 4 : nullptr;
+    b_src[j] = n < p.K ? pw + (size_t)n * p.Ktot + (lchunk ^ ((row >> 1) & 7)) * 4 : nullptr;
   }
   int tr, ts, tc;
   {
@@ -404,7 +413,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_f32(const ConvParams p)
     for (int j = 0; j < PA; ++j) {
       const int hi = a_hi0[j] + tr, wi = a_wi0[j] + ts;
       const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      const float* src = ok ? p.x + a_base[j] + koff + a_swz[j] : g_zero_page;
+      const float* src = ok ? px + a_base[j] + koff + a_swz[j] : g_zero_page;
       __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(sA + j * 8 * 32), 16, 0, 0);
     }
 #pragma unroll
@@ -532,7 +541,12 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 struct Plan {
   int cfg, splits, steps_per_split;
+  int algo = 0;   // 0 = implicit GEMM; 1 = Winograd F(2x2, 3x3) around a grouped GEMM that uses tile `cfg` (splits = 1)
 };
+bool winograd_ok(int r, int s, int stride, int pad, int c, int k, int out_stride);
+size_t winograd_ws_bytes(int n, int h, int w, int c, int k);
+// test / tuning hook: 0 = the autotuner may pick either form, 1 = implicit GEMM only, 2 = Winograd wherever it applies
+int g_algo_mode = 0;
 
 // test / tuning hook: force the block tile (0 = automatic choice)
 int g_force_tm = 0, g_force_tn = 0;
@@ -592,6 +606,7 @@ std::map<ShapeKey, Plan> g_plan_cache;
 std::mutex g_plan_mutex;
 int g_autotune = 0;
 constexpr size_t kTuneWsCap = (size_t)256 << 20;   // candidates whose split-K slabs exceed this are not tried
+constexpr size_t kTuneWinoCap = (size_t)768 << 20;  // same for the Winograd workspace (16 x (tiles x (C + K)) floats)
 
 ShapeKey shape_key(int n, int h, int w, int c, int k, int r, int s, int stride, int pad, int out_stride) {
   return ShapeKey{n, h, w, c, k, r, s, stride, pad, out_stride};
@@ -641,7 +656,7 @@ bool prof_events(int kind, hipEvent_t* e0, hipEvent_t* e1) {
 }
 
 template <int WM, int WN, int TM, int TN, bool ALIGNED>
-int launch_conv(const ConvParams& p, int splits, hipStream_t stream) {
+int launch_conv(const ConvParams& p, int splits, int groups, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_PITCH * sizeof(float);
   static bool configured = false;
@@ -651,7 +666,7 @@ int launch_conv(const ConvParams& p, int splits, hipStream_t stream) {
     if (e != hipSuccess) return frcnn::fail(FRCNN_ERR_LAUNCH, "conv: set LDS size: %s", hipGetErrorString(e));
     configured = true;
   }
-  dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
+  dim3 grid(p.tiles_m * p.tiles_n, groups, splits);
   hipEvent_t e0, e1;
   if (prof_events(0, &e0, &e1))
     hipExtLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, ALIGNED>), grid, dim3(64 * WM * WN), (uint32_t)lds, stream, e0, e1,
@@ -662,7 +677,7 @@ int launch_conv(const ConvParams& p, int splits, hipStream_t stream) {
 }
 
 template <int WM, int WN>
-int launch_conv_dma(const ConvParams& p, int splits, hipStream_t stream) {
+int launch_conv_dma(const ConvParams& p, int splits, int groups, hipStream_t stream) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr size_t lds = (size_t)3 * (BM + BN) * 32 * sizeof(float);
   static bool configured = false;
@@ -672,7 +687,7 @@ int launch_conv_dma(const ConvParams& p, int splits, hipStream_t stream) {
     if (e != hipSuccess) return frcnn::fail(FRCNN_ERR_LAUNCH, "conv: set LDS size: %s", hipGetErrorString(e));
     configured = true;
   }
-  dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
+  dim3 grid(p.tiles_m * p.tiles_n, groups, splits);
   hipEvent_t e0, e1;
   if (prof_events(0, &e0, &e1))
     hipExtLaunchKernelGGL((conv_igemm_dma_f32<WM, WN>), grid, dim3(512), (uint32_t)lds, stream, e0, e1, 0, p);
@@ -701,6 +716,12 @@ extern "C" int frcnn_conv2d_set_tile(int tm, int tn) {
   return FRCNN_OK;
 }
 
+extern "C" int frcnn_conv2d_set_algo(int mode) {
+  FRCNN_REQUIRE(mode >= 0 && mode <= 2, "conv2d_set_algo: mode %d (0 auto, 1 implicit GEMM only, 2 Winograd where it applies)", mode);
+  g_algo_mode = mode;
+  return FRCNN_OK;
+}
+
 extern "C" int frcnn_conv2d_set_staging(int use_lds_dma) {
   g_use_dma = use_lds_dma ? 1 : 0;
   return FRCNN_OK;
@@ -712,17 +733,25 @@ extern "C" size_t frcnn_conv2d_fwd_ws_bytes(int n, int h, int w, int c, int k, i
   const int ho = (h + 2 * pad - r) / stride + 1, wo = (w + 2 * pad - s) / stride + 1;
   const long M = (long)n * ho * wo;
   const int ksteps = (r * s * c + BK - 1) / BK;
+  // a Winograd plan can only be chosen for a call without a residual; the caller does not say here whether it has one,
+  // so the eligible shapes get room for it whenever it may be picked
+  const bool wino = winograd_ok(r, s, stride, pad, c, k, 1) && g_algo_mode != 1;
+  const size_t wino_bytes = wino ? winograd_ws_bytes(n, h, w, c, k) : 0;
   if (split_k <= 0 && g_force_tm == 0) {
     Plan cached;
-    if (lookup_plan(shape_key(n, h, w, c, k, r, s, stride, pad, 1), &cached))
-      return cached.splits > 1 ? (size_t)cached.splits * M * k * sizeof(float) : 0;
+    if (lookup_plan(shape_key(n, h, w, c, k, r, s, stride, pad, 1), &cached)) {
+      if (cached.algo == 1) return wino_bytes;
+      const size_t direct = cached.splits > 1 ? (size_t)cached.splits * M * k * sizeof(float) : 0;
+      return g_algo_mode == 2 ? std::max(direct, wino_bytes) : direct;
+    }
   }
   if (split_k <= 0 && g_force_tm == 0 && g_autotune) {
-    size_t need = 0;   // not tuned yet: room for the largest split-K candidate the tuner may try
+    size_t need = wino_bytes <= kTuneWinoCap ? wino_bytes : 0;   // not tuned yet: room for every candidate the tuner may try
     for (const Plan& cand : tune_candidates(M, k, ksteps, true))
       if (cand.splits > 1) need = std::max(need, (size_t)cand.splits * M * k * sizeof(float));
     return need;
   }
+  if (g_algo_mode == 2 && split_k <= 0 && g_force_tm == 0 && wino) return wino_bytes;
   const Plan pl = choose_plan((int)M, k, ksteps, split_k);
   return pl.splits > 1 ? (size_t)pl.splits * M * k * sizeof(float) : 0;
 }
@@ -743,14 +772,15 @@ extern "C" int frcnn_conv2d_clear_plans(void) {
   return FRCNN_OK;
 }
 
-// Plan table as plain ints, 13 per entry: the 10-int shape key, then tile index, splits, steps per split.
+// Plan table as plain ints, 13 per entry: the 10-int shape key, then tile index (+ 16 for a Winograd plan), splits,
+// steps per split.
 extern "C" int frcnn_conv2d_export_plans(int* out, int capacity_entries) {
   std::lock_guard<std::mutex> lock(g_plan_mutex);
   int n = 0;
   for (const auto& kv : g_plan_cache) {
     if (out && n < capacity_entries) {
       for (int i = 0; i < 10; ++i) out[n * 13 + i] = kv.first[i];
-      out[n * 13 + 10] = kv.second.cfg;
+      out[n * 13 + 10] = kv.second.cfg + 16 * kv.second.algo;
       out[n * 13 + 11] = kv.second.splits;
       out[n * 13 + 12] = kv.second.steps_per_split;
     }
@@ -764,37 +794,194 @@ extern "C" int frcnn_conv2d_import_plans(const int* in, int entries) {
   std::lock_guard<std::mutex> lock(g_plan_mutex);
   for (int e = 0; e < entries; ++e) {
     const int* row = in + e * 13;
-    FRCNN_REQUIRE(row[10] >= 0 && row[10] < kNumTiles && row[11] >= 1 && row[11] <= 64 && row[12] >= 1,
+    const int algo = row[10] >> 4, cfg = row[10] & 15;
+    FRCNN_REQUIRE(row[10] >= 0 && cfg < kNumTiles && algo <= 1 && row[11] >= 1 && row[11] <= 64 && row[12] >= 1 &&
+                      (algo == 0 || (row[11] == 1 && winograd_ok(row[5], row[6], row[7], row[8], row[3], row[4], row[9]))),
                   "conv2d_import_plans: entry %d is not a valid plan (tile %d, splits %d)", e, row[10], row[11]);
     ShapeKey key;
     for (int i = 0; i < 10; ++i) key[i] = row[i];
-    g_plan_cache[key] = Plan{row[10], row[11], row[12]};
+    Plan pl{cfg, row[11], row[12]};
+    pl.algo = algo;
+    g_plan_cache[key] = pl;
   }
   return FRCNN_OK;
 }
 
 namespace {
-// launch one plan: main kernel + the split-K second pass
-int launch_plan(ConvParams p, const Plan& pl, long M, int k, const float* scale, const float* shift,
-                const float* residual, float* y, int relu, void* ws, hipStream_t stream) {
+// ------------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) for the 3x3 / stride 1 / pad 1 layers with large GEMMs (layer4's conv2 on the 300 RoIs, the RPN
+// 3x3): Y = A^T [ (G g G^T) . (B^T d B) ] A per 2x2 output tile, i.e. 16 independent GEMMs over (tiles x C) x (C x K)
+// instead of one over (pixels x 9C) x (9C x K): 2.25x fewer multiplications (1.72x on a 7x7 map, whose 4x4 tiles cover
+// 8x8).  Same fp32 arithmetic type; the transforms only add and halve, and the reduction is 9x shorter, so the
+// rounding error is that of the direct form or smaller (tests/test_gpu_parity.py compares both with float64).
+// Four launches: filter transform (stateless ABI: recomputed per call, 16 KC floats), input transform, ONE grouped
+// launch of the implicit-GEMM kernels as a 1x1 convolution (blockIdx.y = transform component), output transform with
+// the BatchNorm scale / shift and ReLU.  Only the autotuner selects it (choose_plan never does).
+// ------------------------------------------------------------------------------------------------
+bool winograd_ok(int r, int s, int stride, int pad, int c, int k, int out_stride) {
+  return r == 3 && s == 3 && stride == 1 && pad == 1 && (c % 4) == 0 && (k % 4) == 0 && out_stride == 1;
+}
+
+struct WinoGeom {
+  int th, tw;        // 2x2 output tiles per image
+  long T;            // tiles in the batch
+  size_t u_off, v_off, m_off, bytes;   // workspace layout (bytes)
+};
+WinoGeom wino_geom(int n, int h, int w, int c, int k) {
+  WinoGeom g;
+  g.th = (h + 1) / 2;
+  g.tw = (w + 1) / 2;
+  g.T = (long)n * g.th * g.tw;
+  g.u_off = 0;
+  g.v_off = frcnn::align_up((size_t)16 * k * c * sizeof(float), 256);
+  g.m_off = g.v_off + frcnn::align_up((size_t)16 * g.T * c * sizeof(float), 256);
+  g.bytes = g.m_off + frcnn::align_up((size_t)16 * g.T * k * sizeof(float), 256);
+  return g;
+}
+
+size_t winograd_ws_bytes(int n, int h, int w, int c, int k) { return wino_geom(n, h, w, c, k).bytes; }
+
+// U[i*4+j][k][c] = (G g G^T)[i][j],  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]];  one thread per (k, 4 channels)
+__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int K,
+                                                         int C4) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)K * C4) return;
+  const int c4 = (int)(idx % C4);
+  const int k = (int)(idx / C4);
+  const f32x4* src = reinterpret_cast<const f32x4*>(w) + (size_t)k * 9 * C4 + c4;
+  f32x4 g[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) g[r][q] = src[(size_t)(r * 3 + q) * C4];
+  f32x4 t[4][3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    t[0][q] = g[0][q];
+    t[1][q] = (g[0][q] + g[1][q] + g[2][q]) * 0.5f;
+    t[2][q] = (g[0][q] - g[1][q] + g[2][q]) * 0.5f;
+    t[3][q] = g[2][q];
+  }
+  f32x4* dst = reinterpret_cast<f32x4*>(U) + (size_t)k * C4 + c4;
+  const size_t plane = (size_t)K * C4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    dst[(size_t)(i * 4 + 0) * plane] = t[i][0];
+    dst[(size_t)(i * 4 + 1) * plane] = (t[i][0] + t[i][1] + t[i][2]) * 0.5f;
+    dst[(size_t)(i * 4 + 2) * plane] = (t[i][0] - t[i][1] + t[i][2]) * 0.5f;
+    dst[(size_t)(i * 4 + 3) * plane] = t[i][2];
+  }
+}
+
+// V[i*4+j][t][c] = (B^T d B)[i][j] of the 4x4 input patch of tile t (rows 2ty-1.., cols 2tx-1.., zero outside the map);
+// B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]].  One thread per (tile, 4 channels): lanes run along the channels.
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int H, int W,
+                                                        int C4, int th, int tw, long T) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)T * C4) return;
+  const int c4 = (int)(idx % C4);
+  const long t = (long)(idx / C4);
+  const int tx = (int)(t % tw);
+  const long t2 = t / tw;
+  const int ty = (int)(t2 % th);
+  const int n = (int)(t2 / th);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 d[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int hi = 2 * ty - 1 + i;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int wi = 2 * tx - 1 + j;
+      const bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+      d[i][j] = ok ? reinterpret_cast<const f32x4*>(x)[((size_t)(n * H + hi) * W + wi) * C4 + c4] : zero;
+    }
+  }
+  f32x4 r[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    r[0][j] = d[0][j] - d[2][j];
+    r[1][j] = d[1][j] + d[2][j];
+    r[2][j] = d[2][j] - d[1][j];
+    r[3][j] = d[1][j] - d[3][j];
+  }
+  f32x4* dst = reinterpret_cast<f32x4*>(V) + (size_t)t * C4 + c4;
+  const size_t plane = (size_t)T * C4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    dst[(size_t)(i * 4 + 0) * plane] = r[i][0] - r[i][2];
+    dst[(size_t)(i * 4 + 1) * plane] = r[i][1] + r[i][2];
+    dst[(size_t)(i * 4 + 2) * plane] = r[i][2] - r[i][1];
+    dst[(size_t)(i * 4 + 3) * plane] = r[i][1] - r[i][3];
+  }
+}
+
+// y[2ty+a][2tx+b] = act((A^T m A)[a][b] * scale + shift),  A^T = [[1,1,1,0],[0,1,-1,-1]];  one thread per (tile, 4 channels)
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mo, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float* __restrict__ y, int H,
+                                                         int W, int K4, int th, int tw, long T, int relu) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)T * K4) return;
+  const int k4 = (int)(idx % K4);
+  const long t = (long)(idx / K4);
+  const int tx = (int)(t % tw);
+  const long t2 = t / tw;
+  const int ty = (int)(t2 % th);
+  const int n = (int)(t2 / th);
+  const f32x4* src = reinterpret_cast<const f32x4*>(Mo) + (size_t)t * K4 + k4;
+  const size_t plane = (size_t)T * K4;
+  f32x4 s0[4], s1[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x4 m0 = src[(size_t)(0 * 4 + j) * plane], m1 = src[(size_t)(1 * 4 + j) * plane];
+    const f32x4 m2 = src[(size_t)(2 * 4 + j) * plane], m3 = src[(size_t)(3 * 4 + j) * plane];
+    s0[j] = m0 + m1 + m2;
+    s1[j] = m1 - m2 - m3;
+  }
+  f32x4 o[2][2];
+  o[0][0] = s0[0] + s0[1] + s0[2];
+  o[0][1] = s0[1] - s0[2] - s0[3];
+  o[1][0] = s1[0] + s1[1] + s1[2];
+  o[1][1] = s1[1] - s1[2] - s1[3];
+  const f32x4 sc = scale ? reinterpret_cast<const f32x4*>(scale)[k4] : f32x4{1.f, 1.f, 1.f, 1.f};
+  const f32x4 sh = shift ? reinterpret_cast<const f32x4*>(shift)[k4] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int ho = 2 * ty + a;
+    if (ho >= H) continue;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int wo = 2 * tx + b;
+      if (wo >= W) continue;
+      f32x4 v = o[a][b] * sc + sh;
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      reinterpret_cast<f32x4*>(y)[((size_t)(n * H + ho) * W + wo) * K4 + k4] = v;
+    }
+  }
+}
+
+// launch one plan: main kernel + the split-K second pass (or the four launches of a Winograd plan)
+int launch_gemm(ConvParams p, const Plan& pl, long M, int k, int groups, hipStream_t stream) {
   const TileCfg& tc = kTiles[pl.cfg];
   p.steps_per_split = pl.steps_per_split;
   const int bm = 64 * tc.tm, bn = 64 * tc.tn;
   p.tiles_m = (p.M + bm - 1) / bm;
   p.tiles_n = (k + bn - 1) / bn;
-  p.partial = pl.splits > 1 ? static_cast<float*>(ws) : nullptr;
   const bool aligned = (p.C % BK) == 0;
   int rc;
-#define FRCNN_CONV_CASE(WM_, WN_, TM_, TN_)                                   \
-  rc = aligned ? launch_conv<WM_, WN_, TM_, TN_, true>(p, pl.splits, stream) \
-               : launch_conv<WM_, WN_, TM_, TN_, false>(p, pl.splits, stream)
+#define FRCNN_CONV_CASE(WM_, WN_, TM_, TN_)                                           \
+  rc = aligned ? launch_conv<WM_, WN_, TM_, TN_, true>(p, pl.splits, groups, stream) \
+               : launch_conv<WM_, WN_, TM_, TN_, false>(p, pl.splits, groups, stream)
   switch (pl.cfg) {
     case 0:
-      if (aligned && g_use_dma) rc = launch_conv_dma<4, 2>(p, pl.splits, stream);
+      if (aligned && g_use_dma) rc = launch_conv_dma<4, 2>(p, pl.splits, groups, stream);
       else FRCNN_CONV_CASE(4, 2, 2, 2);
       break;
     case 1:
-      if (aligned && g_use_dma) rc = launch_conv_dma<2, 4>(p, pl.splits, stream);
+      if (aligned && g_use_dma) rc = launch_conv_dma<2, 4>(p, pl.splits, groups, stream);
       else FRCNN_CONV_CASE(2, 4, 2, 2);
       break;
     case 2: FRCNN_CONV_CASE(2, 2, 2, 2); break;
@@ -803,6 +990,57 @@ int launch_plan(ConvParams p, const Plan& pl, long M, int k, const float* scale,
     default: FRCNN_CONV_CASE(2, 2, 1, 1); break;
   }
 #undef FRCNN_CONV_CASE
+  return rc;
+}
+
+// launches a 1-D grid kernel through the profiling events when a profile is open (kind 2 = Winograd transform)
+template <typename... Args, typename... Actual>
+int launch_1d(const char* what, void (*kernel)(Args...), size_t threads, hipStream_t stream, Actual... args) {
+  const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+  hipEvent_t e0, e1;
+  if (prof_events(2, &e0, &e1)) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, e0, e1, 0, args...);
+  else hipLaunchKernelGGL(kernel, grid, block, 0, stream, args...);
+  return frcnn::check_launch(what);
+}
+
+int launch_winograd(const ConvParams& p, const Plan& pl, const float* scale, const float* shift, float* y, int relu,
+                    void* ws, hipStream_t stream) {
+  const int n = p.M / (p.Ho * p.Wo);
+  const WinoGeom g = wino_geom(n, p.H, p.W, p.C, p.K);
+  char* base = static_cast<char*>(ws);
+  float* U = reinterpret_cast<float*>(base + g.u_off);
+  float* V = reinterpret_cast<float*>(base + g.v_off);
+  float* Mo = reinterpret_cast<float*>(base + g.m_off);
+  int rc = FRCNN_OK;
+  if (p.u_pre) U = const_cast<float*>(p.u_pre);   // read-only from here on
+  else rc = launch_1d("wino_filter_kernel", wino_filter_kernel, (size_t)p.K * (p.C / 4), stream, p.w, U, p.K, p.C / 4);
+  if (rc != FRCNN_OK) return rc;
+  rc = launch_1d("wino_input_kernel", wino_input_kernel, (size_t)g.T * (p.C / 4), stream, p.x, V, p.H, p.W, p.C / 4, g.th,
+                 g.tw, g.T);
+  if (rc != FRCNN_OK) return rc;
+  // 16 GEMMs  Mo[xi] (T x K) = V[xi] (T x C) . U[xi]^T (K x C)  as ONE grouped 1x1 convolution over a 1 x T "image"
+  ConvParams q;
+  q.x = V; q.w = U; q.scale = nullptr; q.shift = nullptr; q.res = nullptr; q.y = Mo; q.partial = nullptr;
+  q.H = 1; q.W = (int)g.T; q.C = p.C; q.K = p.K; q.R = 1; q.S = 1; q.stride = 1; q.pad = 0; q.Ho = 1; q.Wo = (int)g.T;
+  q.M = (int)g.T;
+  q.Ktot = p.C;
+  q.ksteps = (p.C + BK - 1) / BK;
+  q.relu = 0;
+  q.ys = 1; q.Hy = 0; q.Wy = 0;
+  q.gx = (size_t)g.T * p.C; q.gw = (size_t)p.K * p.C; q.gy = (size_t)g.T * p.K;
+  q.u_pre = nullptr;
+  Plan gp{pl.cfg, 1, q.ksteps};
+  rc = launch_gemm(q, gp, g.T, p.K, 16, stream);
+  if (rc != FRCNN_OK) return rc;
+  return launch_1d("wino_output_kernel", wino_output_kernel, (size_t)g.T * (p.K / 4), stream, (const float*)Mo, scale, shift, y,
+                   p.Ho, p.Wo, p.K / 4, g.th, g.tw, g.T, relu);
+}
+
+int launch_plan(ConvParams p, const Plan& pl, long M, int k, const float* scale, const float* shift,
+                const float* residual, float* y, int relu, void* ws, hipStream_t stream) {
+  if (pl.algo == 1) return launch_winograd(p, pl, scale, shift, y, relu, ws, stream);
+  p.partial = pl.splits > 1 ? static_cast<float*>(ws) : nullptr;
+  int rc = launch_gemm(p, pl, M, k, 1, stream);
   if (rc != FRCNN_OK) return rc;
   if (pl.splits > 1) {
     const size_t mk = (size_t)M * k;
@@ -819,9 +1057,14 @@ int launch_plan(ConvParams p, const Plan& pl, long M, int k, const float* scale,
   return FRCNN_OK;
 }
 
+size_t plan_ws_bytes(const Plan& pl, const ConvParams& p, long M, int k) {
+  if (pl.algo == 1) return wino_geom(p.M / (p.Ho * p.Wo), p.H, p.W, p.C, p.K).bytes;
+  return pl.splits > 1 ? (size_t)pl.splits * M * k * sizeof(float) : 0;
+}
+
 // time every candidate plan on the caller's tensors; returns false when tuning is not possible here
 bool tune_plan(const ConvParams& p, long M, int k, const float* scale, const float* shift, const float* residual,
-               float* y, int relu, void* ws, size_t ws_bytes, hipStream_t stream, bool allow_split, Plan* best) {
+               float* y, int relu, void* ws, size_t ws_bytes, hipStream_t stream, bool allow_split, bool wino, Plan* best) {
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;
   hipEvent_t e0, e1;
@@ -829,12 +1072,21 @@ bool tune_plan(const ConvParams& p, long M, int k, const float* scale, const flo
   if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return false; }
   // two passes over the candidates, each keeps its best time: a one-off disturbance (clock ramp, a neighbour stream)
   // can then neither crown a slow plan nor bury the fast one
-  const std::vector<Plan> cands = tune_candidates(M, k, p.ksteps, allow_split);
+  std::vector<Plan> cands;
+  if (g_algo_mode != 2 || !wino) cands = tune_candidates(M, k, p.ksteps, allow_split);
+  if (wino && g_algo_mode != 1) {
+    // Winograd around the grouped GEMM, one candidate per GEMM tile that makes sense for (tiles x C) x (C x K)
+    for (int cfg : {0, 1, 2, 5}) {
+      Plan pl{cfg, 1, (p.C + BK - 1) / BK};
+      pl.algo = 1;
+      cands.push_back(pl);
+    }
+  }
   std::vector<float> best_of(cands.size(), 1e30f);
   for (int pass = 0; pass < 2; ++pass) {
     for (size_t ci = 0; ci < cands.size(); ++ci) {
       const Plan& pl = cands[ci];
-      const size_t need = pl.splits > 1 ? (size_t)pl.splits * M * k * sizeof(float) : 0;
+      const size_t need = plan_ws_bytes(pl, p, M, k);
       if (need > ws_bytes || (need > 0 && !ws)) continue;
       if (pass == 0 && launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, stream) != FRCNN_OK) continue;   // warm-up
       (void)hipEventRecord(e0, stream);
@@ -862,8 +1114,9 @@ bool tune_plan(const ConvParams& p, long M, int k, const float* scale, const flo
 // a (hy x wy) map at stride out_stride (the map must be zero-filled by the caller); split-K is disabled then.
 int run_conv(const float* x, const float* wgt, const float* scale, const float* shift, const float* residual,
              float* y, int n, int h, int w, int c, int k, int r, int s, int stride, int pad, int relu, int split_k,
-             void* ws, size_t ws_bytes, hipStream_t stream, int out_stride, int hy, int wy) {
+             void* ws, size_t ws_bytes, hipStream_t stream, int out_stride, int hy, int wy, const float* u_pre = nullptr) {
   ConvParams p;
+  p.u_pre = u_pre;
   p.x = x; p.w = wgt; p.scale = scale; p.shift = shift; p.res = residual; p.y = y; p.partial = nullptr;
   p.H = h; p.W = w; p.C = c; p.K = k; p.R = r; p.S = s; p.stride = stride; p.pad = pad;
   p.Ho = (h + 2 * pad - r) / stride + 1;
@@ -876,22 +1129,32 @@ int run_conv(const float* x, const float* wgt, const float* scale, const float* 
   p.relu = relu;
   p.ys = out_stride; p.Hy = hy; p.Wy = wy;
   p.steps_per_split = p.ksteps; p.tiles_m = p.tiles_n = 0;
+  p.gx = p.gw = p.gy = 0;
   const bool allow_split = out_stride == 1;
   Plan pl;
   bool have = false;
   if (split_k <= 0 && g_force_tm == 0) {   // cached plans always apply; new shapes are tuned only in autotune mode
     const ShapeKey key = shape_key(n, h, w, c, k, r, s, stride, pad, out_stride);
     have = lookup_plan(key, &pl);
-    if (!have && g_autotune && tune_plan(p, M, k, scale, shift, residual, y, relu, ws, ws_bytes, stream, allow_split, &pl)) {
+    const bool wino = residual == nullptr && winograd_ok(r, s, stride, pad, c, k, out_stride);
+    if (have && ((pl.algo == 1 && (!wino || g_algo_mode == 1)) || (pl.algo == 0 && wino && g_algo_mode == 2))) have = false;
+    if (!have && g_autotune && tune_plan(p, M, k, scale, shift, residual, y, relu, ws, ws_bytes, stream, allow_split, wino, &pl)) {
       std::lock_guard<std::mutex> lock(g_plan_mutex);
       g_plan_cache[key] = pl;
       have = true;
     }
   }
-  if (!have) pl = choose_plan(p.M, k, p.ksteps, allow_split ? split_k : 1);
-  if (pl.splits > 1) {
-    const size_t need = (size_t)pl.splits * M * k * sizeof(float);
-    if (!ws || ws_bytes < need)
+  if (!have) {
+    pl = choose_plan(p.M, k, p.ksteps, allow_split ? split_k : 1);
+    if (g_algo_mode == 2 && split_k <= 0 && g_force_tm == 0 && residual == nullptr &&
+        winograd_ok(r, s, stride, pad, c, k, out_stride)) {
+      pl = Plan{M >= 2048 ? 2 : 5, 1, (c + BK - 1) / BK};   // forced Winograd without tuning: a mid-size GEMM tile
+      pl.algo = 1;
+    }
+  }
+  {
+    const size_t need = plan_ws_bytes(pl, p, M, k);
+    if (need > 0 && (!ws || ws_bytes < need))
       return frcnn::fail(FRCNN_ERR_WS, "conv2d: workspace %zu < %zu bytes", ws_bytes, need);
   }
   return launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, stream);
@@ -909,6 +1172,35 @@ extern "C" int frcnn_conv2d_fwd(const float* x, const float* wgt, const float* s
   if (g_prof_on) ++g_prof_call;
   return run_conv(x, wgt, scale, shift, residual, y, n, h, w, c, k, r, s, stride, pad, relu, split_k, ws, ws_bytes,
                   static_cast<hipStream_t>(stream_), 1, 0, 0);
+}
+
+extern "C" size_t frcnn_conv2d_winograd_filter_bytes(int k, int c) {
+  if (k <= 0 || c <= 0 || (k % 4) || (c % 4)) return 0;
+  return (size_t)16 * k * c * sizeof(float);
+}
+
+extern "C" int frcnn_conv2d_winograd_filter(const float* w_krsc, float* u, int k, int c, void* stream_) {
+  FRCNN_REQUIRE(w_krsc && u && k > 0 && c > 0 && (k % 4) == 0 && (c % 4) == 0,
+                "conv2d_winograd_filter: need a (k,3,3,c) filter with k%%4 == 0 and c%%4 == 0 (k=%d c=%d)", k, c);
+  const size_t threads = (size_t)k * (c / 4);
+  hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), w_krsc, u, k, c / 4);
+  return frcnn::check_launch("wino_filter_kernel");
+}
+
+extern "C" int frcnn_conv2d_fwd_pre(const float* x, const float* wgt, const float* w_winograd, const float* scale,
+                                    const float* shift, const float* residual, float* y, int n, int h, int w, int c,
+                                    int k, int r, int s, int stride, int pad, int relu, int split_k, void* ws,
+                                    size_t ws_bytes, void* stream_) {
+  FRCNN_REQUIRE(x && wgt && y, "conv2d_fwd_pre: null tensor");
+  FRCNN_REQUIRE(conv_args_ok(n, h, w, c, k, r, s, stride, pad),
+                "conv2d_fwd_pre: bad shape n=%d h=%d w=%d c=%d k=%d r=%d s=%d stride=%d pad=%d (need c%%4==0)", n, h, w, c,
+                k, r, s, stride, pad);
+  FRCNN_REQUIRE(!w_winograd || winograd_ok(r, s, stride, pad, c, k, 1),
+                "conv2d_fwd_pre: a Winograd filter only goes with a 3x3 / stride 1 / pad 1 layer, c%%4 == 0, k%%4 == 0");
+  if (g_prof_on) ++g_prof_call;
+  return run_conv(x, wgt, scale, shift, residual, y, n, h, w, c, k, r, s, stride, pad, relu, split_k, ws, ws_bytes,
+                  static_cast<hipStream_t>(stream_), 1, 0, 0, w_winograd);
 }
 
 extern "C" int frcnn_conv2d_profile_begin(void) {

@@ -66,7 +66,23 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, use_bn=True):
         x = ops.pad_channels(x, w.shape[-1])
     stride = conv.stride[0] if isinstance(conv.stride, (tuple, list)) else conv.stride
     pad = conv.padding[0] if isinstance(conv.padding, (tuple, list)) else conv.padding
-    return ops.conv2d_nhwc(x, w, scale, shift, residual, stride=stride, pad=pad, relu=relu)
+    return ops.conv2d_nhwc(x, w, scale, shift, residual, stride=stride, pad=pad, relu=relu,
+                           w_winograd=_winograd_filter(conv, w, stride, pad) if residual is None else None)
+
+
+def _winograd_filter(conv, w_krsc, stride, pad):
+    """The Winograd-transformed filter of an eligible 3x3 layer, cached next to the KRSC filter it was made from
+    (``prepared_conv`` makes a new one per parameter version), so the inference path does not redo the transform
+    per frame.  Only read by the library when the layer's tuned plan is a Winograd plan."""
+    k, r, s, c = w_krsc.shape
+    if not ops.winograd_eligible(k, r, s, c, stride, pad):
+        return None
+    cache = conv.__dict__.get('_frcnn_winograd')
+    if cache is not None and cache[0] is w_krsc:
+        return cache[1]
+    u = ops.winograd_filter(w_krsc)
+    conv.__dict__['_frcnn_winograd'] = (w_krsc, u)
+    return u
 
 
 def to_nhwc(t):

@@ -46,6 +46,12 @@ def set_conv_autotune(enable):
     _hip.check(_hip.load().frcnn_conv2d_set_autotune(int(bool(enable))), "frcnn_conv2d_set_autotune")
 
 
+def set_conv_algo(mode):
+    """0 = the autotuner may choose Winograd F(2x2, 3x3) for the eligible 3x3 layers, 1 = implicit GEMM only,
+    2 = Winograd wherever it applies (frcnn_conv2d_set_algo)."""
+    _hip.check(_hip.load().frcnn_conv2d_set_algo(int(mode)), "frcnn_conv2d_set_algo")
+
+
 def conv_profile_begin():
     """Start per-dispatch timing of the convolution kernels (frcnn_conv2d_profile_begin)."""
     _hip.check(_hip.load().frcnn_conv2d_profile_begin(), "frcnn_conv2d_profile_begin")
@@ -85,8 +91,10 @@ def conv_out_hw(h, w, r, s, stride, pad):
     return (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
 
 
-def conv2d_nhwc(x, w_krsc, scale=None, shift=None, residual=None, stride=1, pad=0, relu=False, split_k=0, out=None):
-    """y = act(conv(x, w) * scale + shift + residual)  —  frcnn_conv2d_fwd."""
+def conv2d_nhwc(x, w_krsc, scale=None, shift=None, residual=None, stride=1, pad=0, relu=False, split_k=0, out=None,
+                w_winograd=None):
+    """y = act(conv(x, w) * scale + shift + residual)  —  frcnn_conv2d_fwd (frcnn_conv2d_fwd_pre when the caller supplies
+    the Winograd-transformed filter of a 3x3 / stride 1 / pad 1 layer, see ``winograd_filter``)."""
     lib = _hip.load()
     _dev_f32(x, "x"); _dev_f32(w_krsc, "w")
     n, h, w, c = x.shape
@@ -111,13 +119,38 @@ def conv2d_nhwc(x, w_krsc, scale=None, shift=None, residual=None, stride=1, pad=
             raise _hip.HipError("conv2d_nhwc: residual shape %s != output shape %s" % (tuple(residual.shape), (n, ho, wo, k)))
     ws_bytes = lib.frcnn_conv2d_fwd_ws_bytes(n, h, w, c, k, r, s, stride, pad, split_k)
     ws = _workspace(ws_bytes, x.device) if ws_bytes else None
-    _hip.check(lib.frcnn_conv2d_fwd(_ptr(x), _ptr(w_krsc), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out), n, h, w,
-                                    c, k, r, s, stride, pad, int(bool(relu)), split_k, _ptr(ws), ws_bytes, _stream()),
-               "frcnn_conv2d_fwd")
+    if w_winograd is not None:
+        _dev_f32(w_winograd, "w_winograd")
+        if tuple(w_winograd.shape) != (16, k, c):
+            raise _hip.HipError("conv2d_nhwc: w_winograd has shape %s, expected %s" % (tuple(w_winograd.shape), (16, k, c)))
+        _hip.check(lib.frcnn_conv2d_fwd_pre(_ptr(x), _ptr(w_krsc), _ptr(w_winograd), _ptr(scale), _ptr(shift), _ptr(residual),
+                                            _ptr(out), n, h, w, c, k, r, s, stride, pad, int(bool(relu)), split_k, _ptr(ws),
+                                            ws_bytes, _stream()), "frcnn_conv2d_fwd_pre")
+    else:
+        _hip.check(lib.frcnn_conv2d_fwd(_ptr(x), _ptr(w_krsc), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out), n, h, w,
+                                        c, k, r, s, stride, pad, int(bool(relu)), split_k, _ptr(ws), ws_bytes, _stream()),
+                   "frcnn_conv2d_fwd")
     if PROFILE is not None:
         PROFILE.append({"n": n, "h": h, "w": w, "c": c, "k": k, "r": r, "s": s, "stride": stride, "pad": pad,
                         "flops": 2.0 * n * ho * wo * k * r * s * c})
     return out
+
+
+def winograd_eligible(k, r, s, c, stride, pad):
+    """The layers frcnn_conv2d_set_algo's Winograd F(2x2, 3x3) form applies to (no residual operand)."""
+    return r == 3 and s == 3 and stride == 1 and pad == 1 and c % 4 == 0 and k % 4 == 0
+
+
+def winograd_filter(w_krsc):
+    """(K,3,3,C) filter -> its Winograd transform U (16,K,C) (frcnn_conv2d_winograd_filter); constant while the weights are."""
+    lib = _hip.load()
+    _dev_f32(w_krsc, "w")
+    k, r, s, c = w_krsc.shape
+    if not winograd_eligible(k, r, s, c, 1, 1):
+        raise _hip.HipError("winograd_filter: need a (k,3,3,c) filter with k%4 == 0 and c%4 == 0")
+    u = torch.empty((16, k, c), dtype=torch.float32, device=w_krsc.device)
+    _hip.check(lib.frcnn_conv2d_winograd_filter(_ptr(w_krsc), _ptr(u), k, c, _stream()), "frcnn_conv2d_winograd_filter")
+    return u
 
 
 def conv2d_transpose_filter(w_krsc):

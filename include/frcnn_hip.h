@@ -89,7 +89,7 @@ int frcnn_conv2d_profile_begin(void);
 int frcnn_conv2d_profile_end(float* us, int* call, int* kind, int capacity);
 int frcnn_conv2d_set_autotune(int enable);
 int frcnn_conv2d_clear_plans(void);
-/* The plan cache as a table of 13 ints per entry (shape key n,h,w,c,k,r,s,stride,pad,out_stride; tile index, splits,
+/* The plan cache as a table of 13 ints per entry (shape key n,h,w,c,k,r,s,stride,pad,out_stride; tile index [+16], splits,
  * K-steps per split), so that a tuned table can be saved and replayed (e.g. under a profiler, whose instrumentation
  * would otherwise perturb the tuning).  export returns the number of cached entries (fills at most capacity_entries);
  * import validates and inserts. */
@@ -99,6 +99,23 @@ int frcnn_conv2d_import_plans(const int* in, int entries);
 /* Tuning / test hook: 1 (default) stages the 8-wave tiles with LDS-DMA (global_load_lds) when C % 32 == 0,
  * 0 uses the register-staged kernel everywhere.  Results are bit-identical for split_k = 1. */
 int frcnn_conv2d_set_staging(int use_lds_dma);
+
+/* Algorithm of the 3x3 / stride 1 / pad 1 convolutions without a residual (lib/nets/resnet.py:119-121 conv2 of a
+ * Bottleneck, the RPN 3x3 of the Network):  0 (default) = the autotuner times the implicit GEMM and Winograd F(2x2, 3x3)
+ * (same fp32 arithmetic, 2.25x fewer multiplications, four launches) and keeps the faster; without autotuning the
+ * implicit GEMM runs;  1 = implicit GEMM only;  2 = Winograd wherever it applies (tests).  A Winograd plan is exported
+ * with 16 added to its tile index. */
+int frcnn_conv2d_set_algo(int mode);
+
+/* The filter side of a Winograd plan is constant while the weights are: U[16][k][c] = G g G^T of a (k,3,3,c) filter,
+ * computed once per parameter version by the caller and handed to frcnn_conv2d_fwd_pre, which is frcnn_conv2d_fwd
+ * with that one extra operand (NULL = transform inside the call, as frcnn_conv2d_fwd does).  The operand is only read
+ * when the layer's plan is a Winograd plan. */
+size_t frcnn_conv2d_winograd_filter_bytes(int k, int c);
+int frcnn_conv2d_winograd_filter(const float* w_krsc, float* u, int k, int c, void* stream);
+int frcnn_conv2d_fwd_pre(const float* x, const float* w_krsc, const float* w_winograd, const float* scale,
+                         const float* shift, const float* residual, float* y, int n, int h, int w, int c, int k, int r,
+                         int s, int stride, int pad, int relu, int split_k, void* ws, size_t ws_bytes, void* stream);
 
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1)  (lib/nets/resnet.py:156), NHWC. */
 int frcnn_maxpool3x3s2_fwd(const float* x, float* y, int n, int h, int w, int c, void* stream);

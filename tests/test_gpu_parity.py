@@ -110,6 +110,88 @@ def test_conv2d_is_deterministic_and_tile_independent(hip):
     assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
+@pytest.mark.parametrize("shape", [
+    (8, 7, 7, 64, 96),        # layer4-like: 7x7 maps (the 4x4 tiles cover 8x8, the odd row / column is dropped)
+    (1, 38, 63, 64, 64),      # RPN-like map, odd width
+    (2, 5, 9, 32, 128),       # odd x odd
+    (1, 2, 2, 8, 4),          # a single tile, C % 32 != 0 (unaligned GEMM kernel)
+    (3, 1, 1, 32, 32),        # 1x1 maps: every patch is mostly padding
+])
+def test_conv2d_winograd_matches_direct_and_float64(hip, shape):
+    """frcnn_conv2d_set_algo(2): Winograd F(2x2, 3x3) for the 3x3 / stride 1 / pad 1 layers (resnet.py:119-121 conv2, the RPN
+    3x3) against the implicit GEMM and against a float64 convolution: same arithmetic type, the error against float64
+    must not exceed the direct form's by more than a small factor."""
+    ops = _ops()
+    n, h, w, c, k = shape
+    g = torch.Generator().manual_seed(h * 131 + w)
+    x = torch.randn(n, h, w, c, generator=g)
+    wt = torch.randn(k, 3, 3, c, generator=g) / (3.0 * c ** 0.5)
+    sc = torch.rand(k, generator=g) + 0.5
+    sh = torch.randn(k, generator=g)
+    ref64 = F.conv2d(x.double().permute(0, 3, 1, 2), wt.double().permute(0, 3, 1, 2), padding=1)
+    ref64 = torch.relu(ref64 * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    xd, wd, scd, shd = x.to(DEV), wt.to(DEV), sc.to(DEV), sh.to(DEV)
+    try:
+        ops.set_conv_algo(1)
+        direct = ops.conv2d_nhwc(xd, wd, scd, shd, stride=1, pad=1, relu=True).cpu().double()
+        ops.set_conv_algo(2)
+        wino = ops.conv2d_nhwc(xd, wd, scd, shd, stride=1, pad=1, relu=True).cpu().double()
+        wino2 = ops.conv2d_nhwc(xd, wd, scd, shd, stride=1, pad=1, relu=True).cpu().double()
+        # frcnn_conv2d_fwd_pre: the filter transform done once by the caller (what the inference modules cache)
+        u = ops.winograd_filter(wd)
+        wino_pre = ops.conv2d_nhwc(xd, wd, scd, shd, stride=1, pad=1, relu=True, w_winograd=u).cpu().double()
+        # a residual makes the layer ineligible: the call must fall back to the implicit GEMM, not fail
+        res = torch.randn(n, h, w, k, generator=g).to(DEV)
+        with_res = ops.conv2d_nhwc(xd, wd, scd, shd, res, stride=1, pad=1, relu=True).cpu().double()
+        ops.set_conv_algo(1)
+        with_res_direct = ops.conv2d_nhwc(xd, wd, scd, shd, res, stride=1, pad=1, relu=True).cpu().double()
+    finally:
+        ops.set_conv_algo(0)
+    assert torch.equal(wino, wino2)                       # deterministic
+    assert torch.equal(wino, wino_pre)
+    assert torch.equal(with_res, with_res_direct)
+    scale = float(ref64.abs().max())
+    err_d = float((direct - ref64).abs().max())
+    err_w = float((wino - ref64).abs().max())
+    print("winograd %s: max err vs float64 %.3g (direct %.3g), scale %.3g" % (shape, err_w, err_d, scale))
+    assert err_w <= max(3.0 * err_d, 2e-6 * scale)
+    assert float((wino - direct).abs().max()) <= 1e-5 * scale
+
+
+def test_conv2d_autotune_may_pick_winograd_and_plans_round_trip(hip):
+    """With the autotuner on, an eligible layer is timed in both forms; whatever wins is exported with the algorithm in the
+    tile index (+16) and imports back."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(64, 7, 7, 256, generator=g).to(DEV)
+    wt = (torch.randn(256, 3, 3, 256, generator=g) / 48).to(DEV)
+    hip.frcnn_conv2d_clear_plans()
+    try:
+        ops.set_conv_autotune(True)
+        a = ops.conv2d_nhwc(x, wt, stride=1, pad=1, relu=True)
+        ops.set_conv_autotune(False)
+        b = ops.conv2d_nhwc(x, wt, stride=1, pad=1, relu=True)        # cached plan, same bits
+        assert torch.equal(a, b)
+        plans = ops.export_conv_plans()
+        row = [r for r in plans if list(r[:10]) == [64, 7, 7, 256, 256, 3, 3, 1, 1, 1]]
+        assert len(row) == 1 and (row[0][10] >> 4) in (0, 1) and (row[0][10] & 15) < 6
+        hip.frcnn_conv2d_clear_plans()
+        ops.import_conv_plans(plans)
+        c = ops.conv2d_nhwc(x, wt, stride=1, pad=1, relu=True)
+        assert torch.equal(a, c)
+        # forcing the implicit GEMM overrides a cached Winograd plan
+        ops.set_conv_algo(1)
+        d = ops.conv2d_nhwc(x, wt, stride=1, pad=1, relu=True)
+        ops.set_conv_algo(0)
+        ref = F.conv2d(x.cpu().double().permute(0, 3, 1, 2), wt.cpu().double().permute(0, 3, 1, 2), padding=1).relu().permute(0, 2, 3, 1)
+        for got in (a, d):
+            assert float((got.cpu().double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    finally:
+        ops.set_conv_autotune(False)
+        ops.set_conv_algo(0)
+        hip.frcnn_conv2d_clear_plans()
+
+
 def test_conv2d_rejects_bad_arguments(hip):
     ops = _ops()
     from faster_rcnn_pytorch_multimodal_amd._hip import HipError

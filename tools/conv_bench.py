@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="frames per launch (n is multiplied; us/frame is per frame)")
     ap.add_argument("--autotune", action="store_true", help="time every (tile, split-K) candidate first")
     ap.add_argument("--shape", action="append", default=[], help="extra shape n,h,w,c,k,r,stride,pad (replaces the table)")
+    ap.add_argument("--algo", type=int, default=0, help="frcnn_conv2d_set_algo: 0 auto, 1 implicit GEMM only, 2 Winograd where it applies")
     ap.add_argument("--nores", action="store_true", help="drop the residual operand (epilogue traffic experiment)")
     ap.add_argument("--graph", action="store_true", help="replay the launches from a hipGraph also with one stream")
     ap.add_argument("--streams", type=int, default=1, help="launch the same convolution on S HIP streams at once (own "
@@ -87,6 +88,7 @@ def main():
     tm, tn = (int(v) for v in args.tile.split(","))
     _hip.check(lib.frcnn_conv2d_set_tile(tm, tn), "set_tile")
     _hip.check(lib.frcnn_conv2d_set_staging(args.staging), "set_staging")
+    _hip.check(lib.frcnn_conv2d_set_algo(args.algo), "set_algo")
     dev = "cuda:0"
     g = torch.Generator(device="cpu").manual_seed(0)
     tot_us = tot_fl = 0.0
