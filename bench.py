@@ -32,7 +32,7 @@ THRESH, MAX_DETS = 0.5, 100          # tools/test_net.py:290
 WEIGHT_SEED, BN_MODE = 3, "tame"     # cfg.RNG_SEED; see DESIGN.md "workload" for why BN is damped
 MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix peak
 HBM_PEAK_GBS = 8000.0
-PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")   # committed rocprofv3 PMC passes, newest first
+PMC_FILES = ("r02b_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # committed rocprofv3 PMC passes, newest first
 
 
 def synthetic_frame(seed):

@@ -1076,7 +1076,7 @@ bool tune_plan(const ConvParams& p, long M, int k, const float* scale, const flo
   if (g_algo_mode != 2 || !wino) cands = tune_candidates(M, k, p.ksteps, allow_split);
   if (wino && g_algo_mode != 1) {
     // Winograd around the grouped GEMM, one candidate per GEMM tile that makes sense for (tiles x C) x (C x K)
-    for (int cfg : {0, 1, 2, 5}) {
+    for (int cfg = 0; cfg < kNumTiles; ++cfg) {
       Plan pl{cfg, 1, (p.C + BK - 1) / BK};
       pl.algo = 1;
       cands.push_back(pl);

@@ -22,7 +22,8 @@ import sys
 FAMILIES = {"conv_igemm": "conv_igemm", "roi_align_fwd": "roi_align_fwd", "conv_wgrad_f32": "conv_wgrad_f32"}
 # kernels whose bytes are ADDED to a family without counting as launches of it: one RoIAlign operation = the plan kernel
 # + the pooling kernel, reported per operation
-COMPANIONS = {"roi_plan_kernel": "roi_align_fwd"}
+# (same for the other launches of one frcnn_conv2d_fwd call: the split-K second pass and the Winograd transforms)
+COMPANIONS = {"roi_plan_kernel": "roi_align_fwd", "conv_splitk_epilogue": "conv_igemm", "wino_": "conv_igemm"}
 
 
 # bench.py tunes its conv plans during the first frames (extra candidate launches); its roofline is timed over the
@@ -41,7 +42,7 @@ def per_kernel(directory, counter):
                 continue
             for sub, fam in COMPANIONS.items():
                 if sub in row["Kernel_Name"]:
-                    extra[fam] = extra.get(fam, 0.0) + float(row["Counter_Value"])
+                    extra.setdefault(fam, []).append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
             for fam, sub in FAMILIES.items():
                 if sub in row["Kernel_Name"]:
                     vals.setdefault(fam, []).append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
@@ -51,7 +52,11 @@ def per_kernel(directory, counter):
         rows.sort()
         if fam in LAST:
             rows = rows[-LAST[fam]:]
-        acc[fam] = (len(rows), sum(v for _, v in rows) + extra.get(fam, 0.0))
+        first = rows[0][0]
+        # companions of the selected dispatches only (a companion may precede its family kernel by a few dispatches:
+        # the Winograd input transform runs before the grouped GEMM of the same call)
+        comp = sum(v for d, v in extra.get(fam, []) if d >= first - 2)
+        acc[fam] = (len(rows), sum(v for _, v in rows) + comp)
     return acc
 
 

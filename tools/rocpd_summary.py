@@ -31,7 +31,7 @@ def conv_cross_check(path, frames=5, launches_per_frame=106):
     per-dispatch table, for comparison with bench.py's kernel_ms_per_frame / avg_launch_us."""
     db = sqlite3.connect(path)
     rows = list(db.execute("select name, start, end from kernels where name like '%conv_igemm%' or name like "
-                           "'%conv_splitk_epilogue%' order by start"))
+                           "'%conv_splitk_epilogue%' or name like '%wino_%' order by start"))
     main = [r for r in rows if "conv_igemm" in r[0]]
     if len(main) < frames * launches_per_frame:
         return
@@ -39,13 +39,16 @@ def conv_cross_check(path, frames=5, launches_per_frame=106):
     sel = [r for r in rows if r[1] >= first]
     igemm = sum(e - s for n, s, e in sel if "conv_igemm" in n) / 1e3
     epi = sum(e - s for n, s, e in sel if "splitk" in n) / 1e3
+    wino = sum(e - s for n, s, e in sel if "wino_" in n) / 1e3
     print("\n## cross-check with bench.py's roofline (last %d eager frames, %d conv launches each)\n" % (frames, launches_per_frame))
     print("| quantity | value |\n|---|---:|")
     print("| conv_igemm* kernel time per frame | %.1f us |" % (igemm / frames))
     print("| + conv_splitk_epilogue per frame | %.1f us |" % (epi / frames))
-    print("| average per frcnn_conv2d_fwd call (main kernel + second pass) | %.2f us |"
-          % ((igemm + epi) / (frames * launches_per_frame)))
-    print("| => conv rate at 628.4 GFLOP/frame | %.1f TFLOP/s |" % (628.4e9 / ((igemm + epi) / frames * 1e-6) / 1e12))
+    print("| + Winograd transform kernels per frame | %.1f us |" % (wino / frames))
+    print("| average per frcnn_conv2d_fwd call (all its launches) | %.2f us |"
+          % ((igemm + epi + wino) / (frames * launches_per_frame)))
+    print("| => conv rate at 628.4 algorithmic GFLOP/frame | %.1f TFLOP/s |"
+          % (628.4e9 / ((igemm + epi + wino) / frames * 1e-6) / 1e12))
 
 
 if __name__ == "__main__":
