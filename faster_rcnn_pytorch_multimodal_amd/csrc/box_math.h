@@ -71,6 +71,29 @@ __device__ __forceinline__ bool iou_gt(const float* a, const float* b, float thr
   return NMS_SUPPRESS_AT_EQUAL ? iou >= thresh : iou > thresh;
 }
 
+// The same predicate, bit for bit, with the IEEE division (~25 instructions) taken only near the threshold: inter against
+// thresh * union decides every other pair with a margin (1e-6 relative, against 2^-24 rounding in each of the two
+// products and half an ulp in the quotient); degenerate boxes (union <= 0, NaN) always take the division.  Pays where the
+// IoU count per lane is small and instruction-bound (the per-class filter); the 64-deep serial loop of nms_mask_kernel
+// is faster with the plain form.
+__device__ __forceinline__ bool iou_gt_lazy_div(const float* a, const float* b, float thresh) {
+  const float xx1 = fmaxf(a[0], b[0]), yy1 = fmaxf(a[1], b[1]);
+  const float xx2 = fminf(a[2], b[2]), yy2 = fminf(a[3], b[3]);
+  const float w = fmaxf(xx2 - xx1, 0.f), h = fmaxf(yy2 - yy1, 0.f);
+  const float inter = w * h;
+  const float sa = (a[2] - a[0]) * (a[3] - a[1]);
+  const float sb = (b[2] - b[0]) * (b[3] - b[1]);
+  const float uni = sa + sb - inter;
+  const float tu = thresh * uni;
+  const bool sure_yes = inter > tu * 1.000001f, sure_no = inter < tu * 0.999999f;
+  bool hit = sure_yes;
+  if (!(uni > 0.f) || !(sure_yes || sure_no)) {   // rarely taken (skipped when no lane of the wave needs it)
+    const float iou = inter / uni;
+    hit = NMS_SUPPRESS_AT_EQUAL ? iou >= thresh : iou > thresh;
+  }
+  return hit;
+}
+
 // fp32 -> u32 key whose ASCENDING order is DESCENDING score (-0 is folded into +0 first).
 __device__ __forceinline__ uint32_t desc_key(float s) {
   if (s == 0.f) s = 0.f;
@@ -109,7 +132,10 @@ __device__ __forceinline__ void block_bitonic_sort(uint64_t* keys, int npad) {
 // mask[i*nb + w] bit b set  <=>  box (w*64+b) has IoU > thresh with box i and (w*64+b) > i.
 // Boxes are in descending-score order.  Writes survivors' positions to keep_idx (first max_keep of them)
 // and optional per-box bytes to keep_mask (pre-zeroed by the caller).  nb <= 256.
-__device__ __forceinline__ int wave_nms_scan(const uint64_t* mask, int nb, int n, int max_keep, int64_t* keep_idx,
+// MaskPtr: `const uint64_t*` (global) or an address_space(3) pointer when the matrix lives in LDS - a generic pointer
+// would turn every row fetch into a flat load (40 of the 75 us of the per-class filter kernel were that).
+template <typename MaskPtr, typename KeepPtr>
+__device__ __forceinline__ int wave_nms_scan(MaskPtr mask, int nb, int n, int max_keep, KeepPtr keep_idx,
                                              uint8_t* keep_mask) {
   const int lane = threadIdx.x & 63;
   uint64_t rm0 = 0, rm1 = 0, rm2 = 0, rm3 = 0;  // removed bits of words lane, lane+64, lane+128, lane+192
@@ -150,21 +176,31 @@ __device__ __forceinline__ int wave_nms_scan(const uint64_t* mask, int nb, int n
     if (count >= max_keep) break;
     uint64_t todo = kept;
     while (todo != 0) {
-      const uint64_t* rows[4];
+      MaskPtr rows[4];
       int nr = 0;
       for (; nr < 4 && todo != 0; ++nr) {
         rows[nr] = mask + (size_t)(c * 64 + __builtin_ctzll(todo)) * nb;
         todo &= todo - 1ull;
       }
       for (int q = nr; q < 4; ++q) rows[q] = rows[0];      // duplicates: OR is idempotent
+      // unconditional loads at a clamped word index (issued back to back), masked afterwards; slots beyond the row
+      // length are skipped by a wave-uniform branch
       uint64_t v[4][4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
+      for (int s4 = 0; s4 < 4; ++s4) {
+        if (s4 * 64 < nb) {
           const int w = lane + 64 * s4;
-          v[q][s4] = (w > c && w < nb) ? rows[q][w] : 0ull;
+          const int wc = min(w, nb - 1);
+          const bool ok = w > c && w < nb;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q][s4] = rows[q][wc];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q][s4] = ok ? v[q][s4] : 0ull;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q][s4] = 0ull;
         }
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         rm0 |= v[q][0];

@@ -598,7 +598,7 @@ __global__ __launch_bounds__(FILTER_SMALL_THREADS) void filter_class_small_kerne
   float4* sboxes = reinterpret_cast<float4*>(keys + num_rois);
   int64_t* keep_idx = reinterpret_cast<int64_t*>(sboxes + num_rois);
   uint64_t* mask = reinterpret_cast<uint64_t*>(keep_idx + num_rois);
-  __shared__ int s_n, s_keep;
+  __shared__ int s_n;
   const int cls = blockIdx.x + 1;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int R = roi_count ? min(*roi_count, num_rois) : num_rois;
@@ -624,51 +624,105 @@ __global__ __launch_bounds__(FILTER_SMALL_THREADS) void filter_class_small_kerne
                                         pb[1] + pb[4] / 2.0f);
   }
   __syncthreads();
-  // suppression bit-matrix (words on/right of the diagonal): one wave per word, one IoU per lane
+  // PREDECESSOR matrix P[j] = bits i < j with IoU(i, j) > nms_thresh (boxes in descending-score order): one wave per
+  // 64-box word of the upper triangle, one IoU per lane, the hits scattered to the transposed position by LDS atomics
+  // (sparse).  Greedy NMS is then the unique fixed point of  keep(j) <=> no kept predecessor in P[j] , found by rounds
+  // in which every undecided box looks at the decided sets: a kept predecessor removes it, all predecessors removed keeps
+  // it.  Every round decides at least the first undecided box; a frame's boxes take a handful of rounds, against one
+  // serial step per kept box in a scan (which cost 40 of this kernel's 75 us).
   const int nbl = (n + 63) / 64;
-  for (int wi = wave; wi < n * nbl; wi += FILTER_SMALL_THREADS / 64) {
-    const int i = wi / nbl, w = wi - i * nbl;
-    if (w < (i >> 6)) continue;
+  uint64_t* const P = mask;
+  __shared__ unsigned long long s_sets[2 * (FILTER_SMALL_MAX / 64)];
+  unsigned long long* const kept_set = s_sets;                          // [nbl]
+  unsigned long long* const rem_set = s_sets + FILTER_SMALL_MAX / 64;   // [nbl]
+  for (int e = t; e < n * nbl; e += FILTER_SMALL_THREADS) P[e] = 0ull;
+  __syncthreads();
+  // work unit = (word w of boxes j, chunk c <= w of predecessors i, quarter of the chunk): lane j keeps its box in
+  // registers, the 16 predecessor boxes are LDS broadcasts, the hits are collected in a register word - one LDS atomic
+  // per lane and unit
+  constexpr int PARTS = 4, ROWS = 64 / PARTS;
+  const int units = nbl * (nbl + 1) / 2 * PARTS;
+  for (int u = wave; u < units; u += FILTER_SMALL_THREADS / 64) {
+    int pair = u / PARTS, w = 0;
+    const int part = u - pair * PARTS;
+    while (pair > w) { pair -= w + 1; ++w; }
+    const int c = pair;
     const int j = w * 64 + lane;
-    const float4 bi = sboxes[i];
-    bool hit = false;
-    if (j < n && j > i) {
-      const float4 bj = sboxes[j];
-      const float a[4] = {bi.x, bi.y, bi.z, bi.w}, b[4] = {bj.x, bj.y, bj.z, bj.w};
-      hit = iou_gt(a, b, nms_thresh);
+    const float4 bj = sboxes[min(j, n - 1)];
+    const float b[4] = {bj.x, bj.y, bj.z, bj.w};
+    const int i0 = c * 64 + part * ROWS;
+    uint64_t word = 0ull;
+#pragma unroll 4
+    for (int ii = 0; ii < ROWS; ++ii) {
+      const int i = i0 + ii;
+      if (i >= n) break;
+      const float4 bi = sboxes[i];
+      const float a[4] = {bi.x, bi.y, bi.z, bi.w};
+      if (j < n && j > i && iou_gt_lazy_div(a, b, nms_thresh)) word |= 1ull << (i & 63);
     }
-    const uint64_t bits = __ballot(hit);
-    if (lane == 0) mask[(size_t)i * nbl + w] = bits;
+    if (word != 0ull) atomicOr(reinterpret_cast<unsigned long long*>(&P[(size_t)j * nbl + c]), word);
   }
   __syncthreads();
-  if (wave == 0) {
-    const int cnt = wave_nms_scan(mask, nbl, n, n, keep_idx, nullptr);
-    if (lane == 0) s_keep = cnt;
+  if (t < 2 * (FILTER_SMALL_MAX / 64)) s_sets[t] = 0ull;
+  bool undecided = t < n;
+  const int my_words = (t >> 6) + 1;            // predecessors of box t live in words 0 .. t / 64
+  for (;;) {
+    __syncthreads();
+    if (undecided) {
+      bool any_kept = false, all_removed = true;
+      for (int w = 0; w < my_words; ++w) {
+        const uint64_t pre = P[(size_t)t * nbl + w];
+        any_kept |= (pre & kept_set[w]) != 0ull;
+        all_removed &= (pre & ~rem_set[w]) == 0ull;
+      }
+      if (any_kept) {
+        atomicOr(&rem_set[t >> 6], 1ull << (t & 63));
+        undecided = false;
+      } else if (all_removed) {
+        atomicOr(&kept_set[t >> 6], 1ull << (t & 63));
+        undecided = false;
+      }
+    }
+    if (__syncthreads_count(undecided ? 1 : 0) == 0) break;
   }
+  // positions: survivors in ascending box order
+  uint64_t my_kept_word = 0;
+  int before = 0, total = 0;
+  for (int w = 0; w < nbl; ++w) {
+    const uint64_t kw = kept_set[w];
+    const int pc = __builtin_popcountll(kw);
+    if (w < (t >> 6)) before += pc;
+    if (w == (t >> 6)) my_kept_word = kw;
+    total += pc;
+  }
+  if (t < n && ((my_kept_word >> (t & 63)) & 1ull))
+    keep_idx[before + __builtin_popcountll(my_kept_word & ((1ull << (t & 63)) - 1ull))] = t;
   __syncthreads();
-  int kept = s_keep;
-  // test.py:213-221: if more than max_dets survive keep score >= the max_dets-th best (ties stay)
+  int kept = total;
+  // test.py:213-221: if more than max_dets survive keep score >= the max_dets-th best (ties stay).  Keys ascend along
+  // keep_idx, so the survivors of the cut are a prefix: count the ties in parallel
   if (max_dets > 0 && kept > max_dets) {
     const uint32_t cut = (uint32_t)(keys[keep_idx[max_dets - 1]] >> 32);     // ascending key = descending score
-    int m = max_dets;
-    while (m < kept && (uint32_t)(keys[keep_idx[m]] >> 32) <= cut) ++m;
-    kept = m;
+    int ties = 0;
+    for (int base = max_dets; base < kept; base += FILTER_SMALL_THREADS) {
+      const int m = base + t;
+      ties += __syncthreads_count(m < kept && (uint32_t)(keys[keep_idx[m]] >> 32) <= cut);
+    }
+    kept = max_dets + ties;
   }
   kept = min(kept, max_out);
   float* out = dets + (size_t)cls * max_out * (E + 1);
-  for (int i = t; i < max_out; i += FILTER_SMALL_THREADS) {
-    float v[E + 1];
-    for (int q = 0; q <= E; ++q) v[q] = 0.f;
+  for (int e = t; e < max_out * (E + 1); e += FILTER_SMALL_THREADS) {     // one output element per thread: coalesced
+    const int i = e / (E + 1), q = e - i * (E + 1);
+    float v = 0.f;
     int roi = -1;
     if (i < kept) {
       const uint32_t r = (uint32_t)(keys[keep_idx[i]] & 0xFFFFFFFFu);
-      const float* pb = pred_boxes + ((size_t)r * num_classes + cls) * E;
-      for (int q = 0; q < E; ++q) v[q] = pb[q];
-      v[E] = cls_prob[(size_t)r * num_classes + cls];
+      v = q < E ? pred_boxes[((size_t)r * num_classes + cls) * E + q] : cls_prob[(size_t)r * num_classes + cls];
       roi = (int)r;
     }
-    for (int q = 0; q <= E; ++q) out[i * (E + 1) + q] = v[q];
-    if (det_roi) det_roi[(size_t)cls * max_out + i] = roi;
+    out[e] = v;
+    if (det_roi && q == 0) det_roi[(size_t)cls * max_out + i] = roi;
   }
   if (t == 0) det_count[cls] = kept;
 }
@@ -1025,3 +1079,4 @@ extern "C" int frcnn_clip_boxes(const float* boxes, int num_boxes, const float* 
                      static_cast<hipStream_t>(stream_), boxes, num_boxes, clip, out);
   return check_launch("clip_boxes_kernel");
 }
+

@@ -1137,8 +1137,14 @@ int run_conv(const float* x, const float* wgt, const float* scale, const float* 
     const ShapeKey key = shape_key(n, h, w, c, k, r, s, stride, pad, out_stride);
     have = lookup_plan(key, &pl);
     const bool wino = residual == nullptr && winograd_ok(r, s, stride, pad, c, k, out_stride);
-    if (have && ((pl.algo == 1 && (!wino || g_algo_mode == 1)) || (pl.algo == 0 && wino && g_algo_mode == 2))) have = false;
-    if (!have && g_autotune && tune_plan(p, M, k, scale, shift, residual, y, relu, ws, ws_bytes, stream, allow_split, wino, &pl)) {
+    // a cached plan of the other form than this call may use (a residual operand, or a forced mode) is left in the cache
+    // for the calls it was tuned for; this call runs the analytic plan
+    bool keep_cache = false;
+    if (have && ((pl.algo == 1 && (!wino || g_algo_mode == 1)) || (pl.algo == 0 && wino && g_algo_mode == 2))) {
+      have = false;
+      keep_cache = true;
+    }
+    if (!have && !keep_cache && g_autotune && tune_plan(p, M, k, scale, shift, residual, y, relu, ws, ws_bytes, stream, allow_split, wino, &pl)) {
       std::lock_guard<std::mutex> lock(g_plan_mutex);
       g_plan_cache[key] = pl;
       have = true;
@@ -1151,6 +1157,11 @@ int run_conv(const float* x, const float* wgt, const float* scale, const float* 
       pl = Plan{M >= 2048 ? 2 : 5, 1, (c + BK - 1) / BK};   // forced Winograd without tuning: a mid-size GEMM tile
       pl.algo = 1;
     }
+  }
+  if (!have && split_k <= 0 && pl.splits > 1 && (!ws || ws_bytes < plan_ws_bytes(pl, p, M, k))) {
+    // the workspace was sized for this shape's cached plan, which does not apply to THIS call (a Winograd plan and a call
+    // with a residual): run unsplit rather than fail
+    pl = choose_plan(p.M, k, p.ksteps, 1);
   }
   {
     const size_t need = plan_ws_bytes(pl, p, M, k);
