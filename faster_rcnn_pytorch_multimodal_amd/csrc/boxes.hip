@@ -413,7 +413,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 // NMS (torchvision.ops.nms semantics) on score-ordered boxes: bit-matrix + single-wave greedy scan.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ n_dev,
-                                                     int n_max, int nb, float thresh, uint64_t* __restrict__ mask) {
+                                                     int n_max, int nb, float thresh, uint64_t* __restrict__ mask,
+                                                     uint64_t* __restrict__ diag_t) {
   const int bi = blockIdx.y, bj = blockIdx.x;
   if (bj < bi) return;  // only words on or right of the diagonal are ever read
   const int n = n_dev ? min(*n_dev, n_max) : n_max;
@@ -430,21 +431,255 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
   if (i >= n) return;
   const float4 bq = reinterpret_cast<const float4*>(boxes)[i];
   const float me[4] = {bq.x, bq.y, bq.z, bq.w};
-  uint64_t bits = 0;
+  uint64_t bits = 0, pre = 0;
   const int jn = min(64, n - j0);
-  for (int b = 0; b < jn; ++b) {
-    if (j0 + b > i && iou_gt(me, &cols[b * 4], thresh)) bits |= 1ull << b;
+  if (bi == bj && diag_t) {
+    // diagonal block: the IoU test is symmetric, so the same pass also yields the PREDECESSOR word of box i (the boxes
+    // of its own chunk ranked above it that overlap it), which is what the scan's parallel resolve reads
+    for (int b = 0; b < jn; ++b) {
+      if (j0 + b == i) continue;
+      const bool hit = iou_gt(me, &cols[b * 4], thresh);
+      if (hit) {
+        if (j0 + b > i) bits |= 1ull << b;
+        else pre |= 1ull << b;
+      }
+    }
+    diag_t[i] = pre;
+  } else {
+    for (int b = 0; b < jn; ++b) {
+      if (j0 + b > i && iou_gt(me, &cols[b * 4], thresh)) bits |= 1ull << b;
+    }
   }
   mask[(size_t)i * nb + bj] = bits;
 }
 
-__global__ __launch_bounds__(64) void nms_scan_kernel(const uint64_t* __restrict__ mask, const int* __restrict__ n_dev,
-                                                     int n_max, int nb, int max_keep, int64_t* __restrict__ keep_idx,
-                                                     uint8_t* __restrict__ keep_mask, int* __restrict__ keep_count) {
-  const int n = n_dev ? min(*n_dev, n_max) : n_max;
-  const int cnt = wave_nms_scan(mask, nb, n, max_keep, keep_idx, keep_mask);
-  if (threadIdx.x == 0) keep_count[0] = cnt;
+// ------------------------------------------------------------------------------------------------
+// Greedy scan of the RPN NMS (torchvision.ops.nms at proposal_layer.py:46) over the bit-matrix, one workgroup:
+// wave 0 walks the 64-box chunks, waves 1..15 only help fetching rows.  Per chunk:
+//  * resolve - which boxes of the chunk survive - is the fixed point of  keep(j) <=> no kept predecessor overlaps j
+//    over the chunk's 64 boxes, found in a few ballot rounds from the transposed diagonal word nms_mask_kernel wrote
+//    (lane j: the boxes of the chunk ranked above j that overlap it).  The serial form (one step of ~170 cycles per
+//    SURVIVOR) cost 51K cycles when an untrained RPN keeps 60 boxes of every chunk;
+//  * the diagonal words and the two following words (c+1, c+2) of every row are requested FOUR chunks ahead - nothing
+//    the scan computes feeds those addresses;
+//  * a chunk with few survivors (<= 8, the trained-RPN regime: thousands of boxes, almost all suppressed) stays inside
+//    wave 0: what its survivors remove from chunks c+1 / c+2 is an OR over registers (carry_a / carry_b), their words
+//    >= c+3 are requested now and merged into the removed set two chunks later (ring of two pending batches);
+//  * a chunk with many survivors wakes the helper waves: wave w fetches the rows of the survivors at bit positions
+//    w, w+8, ..., w+56 and ORs them into its LDS slice, wave 0 combines the 8 slices - two memory latencies per chunk
+//    instead of one per four rows (86K of the scan's 142K cycles before).
+// Same survivors in the same order as wave_nms_scan (box_math.h, still used by the general per-class filter).
+// The chunk body is stamped out four times by a macro so that every ring slot is a fixed set of registers.
+// ------------------------------------------------------------------------------------------------
+constexpr int SCAN_WAVES = 8;       // 512 threads: wave 0 may use 256 VGPRs (its rings), no scratch
+constexpr int SCAN_DENSE = 8;      // more survivors than this in a chunk: cooperative row fetch
+
+// rows of the survivors this wave owns (bit positions wave, wave + 8, ...: two batches of four rows), words > c,
+// OR-ed per word into part[w]
+__device__ __forceinline__ void scan_coop_fetch(const uint64_t* __restrict__ mask, int nb, int c, uint64_t kept, int wave,
+                                                int lane, uint64_t* part) {
+  uint64_t acc[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (((kept >> (wave + 32 * half)) & 0x01010101ull) == 0ull) continue;   // none of this batch's four rows survives
+    uint64_t v[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int b = wave + SCAN_WAVES * (4 * half + q);
+      const bool on = (kept >> b) & 1ull;                      // wave-uniform
+      const uint64_t* row = mask + (size_t)(c * 64 + (on ? b : wave)) * nb;   // any valid row when off (masked below)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        if (s4 * 64 < nb) {
+          const int w = lane + 64 * s4;
+          const uint64_t val = row[min(w, nb - 1)];
+          v[q][s4] = (on && w > c && w < nb) ? val : 0ull;
+        } else {
+          v[q][s4] = 0ull;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc[s4] |= v[q][s4];
+  }
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4)
+    if (s4 * 64 < nb) part[lane + 64 * s4] = acc[s4];
 }
+
+#define FRCNN_SCAN_FETCH4(V, FIRST_WORD)                                               \
+  _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                   \
+    if (s4 * 64 < nb) {                                                                \
+      const int w_ = lane + 64 * s4;                                                   \
+      const int wc_ = min(w_, nb - 1);                                                 \
+      const bool ok_ = w_ >= (FIRST_WORD) && w_ < nb;                                  \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) V[q][s4] = rows[q][wc_];           \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) V[q][s4] = ok_ ? V[q][s4] : 0ull;  \
+    } else {                                                                           \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) V[q][s4] = 0ull;                   \
+    }                                                                                  \
+  }
+#define FRCNN_SCAN_MERGE4(V)                      \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) { \
+    rm0 |= V[q][0];                               \
+    rm1 |= V[q][1];                               \
+    rm2 |= V[q][2];                               \
+    rm3 |= V[q][3];                               \
+  }
+#define FRCNN_SCAN_ROWS4()                                                      \
+  const uint64_t* rows[4];                                                      \
+  {                                                                             \
+    int nr_ = 0;                                                                \
+    for (; nr_ < 4 && todo != 0; ++nr_) {                                       \
+      rows[nr_] = mask + (size_t)(c * 64 + __builtin_ctzll(todo)) * nb;         \
+      todo &= todo - 1ull;                                                      \
+    }                                                                           \
+    for (int q = nr_; q < 4; ++q) rows[q] = rows[0]; /* OR is idempotent */     \
+  }
+#define FRCNN_SCAN_CHUNK(C, PEND, K)                                                                                \
+  {                                                                                                                 \
+    const int c = (C);                                                                                              \
+    if (!(c < nb && c * 64 < n && count < max_keep)) break;                                                         \
+    const int i = c * 64 + lane;                                                                                    \
+    const uint64_t pre = pq[K], n1 = n1q[K], n2 = n2q[K];                                                           \
+    {                                                                                                               \
+      const int in = i + 64 * 4, cn = c + 4;                                                                        \
+      pq[K] = in < n ? diag_t[in] : 0ull;                                                                           \
+      n1q[K] = (in < n && cn + 1 < nb) ? mask[(size_t)in * nb + (cn + 1)] : 0ull;                                   \
+      n2q[K] = (in < n && cn + 2 < nb) ? mask[(size_t)in * nb + (cn + 2)] : 0ull;                                   \
+    }                                                                                                               \
+    const int slot = c >> 6;                                                                                        \
+    const uint64_t mine = slot == 0 ? rm0 : slot == 1 ? rm1 : slot == 2 ? rm2 : rm3;                                \
+    const uint64_t rw = readlane_u64(mine, c & 63) | carry_a;                                                       \
+    const int live = n - c * 64;                                                                                    \
+    const uint64_t valid = live >= 64 ? ~0ull : ((1ull << live) - 1ull);                                            \
+    const uint64_t alive = ~rw & valid;                                                                             \
+    /* fixed point of the greedy rule over the chunk (boxes removed by earlier chunks count as removed) */           \
+    uint64_t kept = 0, rem = ~alive;                                                                                \
+    bool und = (alive >> lane) & 1ull;                                                                              \
+    for (;;) {                                                                                                      \
+      const bool k_ = und && (pre & ~rem) == 0ull;                                                                  \
+      const bool r_ = und && (pre & kept) != 0ull;                                                                  \
+      const uint64_t kb = __ballot(k_), rb = __ballot(r_);                                                          \
+      if ((kb | rb) == 0ull) break;                                                                                 \
+      kept |= kb;                                                                                                   \
+      rem |= rb;                                                                                                    \
+      und = und && !k_ && !r_;                                                                                      \
+    }                                                                                                               \
+    int nk = __builtin_popcountll(kept);                                                                            \
+    while (count + nk > max_keep) { /* the cap cuts the lowest-ranked survivors of the last chunk */                \
+      kept &= ~(1ull << (63 - __builtin_clzll(kept)));                                                              \
+      --nk;                                                                                                         \
+    }                                                                                                               \
+    if ((kept >> lane) & 1ull) {                                                                                    \
+      const int pos = count + __builtin_popcountll(kept & ((1ull << lane) - 1ull));                                 \
+      keep_idx[pos] = i;                                                                                            \
+      if (keep_mask) keep_mask[i] = 1;                                                                              \
+    }                                                                                                               \
+    count += nk;                                                                                                    \
+    if (count >= max_keep) break;                                                                                   \
+    /* the batch requested two chunks ago (words >= c+1 of chunk c-2's survivors) lands in the removed set now */   \
+    FRCNN_SCAN_MERGE4(PEND)                                                                                         \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) PEND[q][s4] = 0ull; \
+    if (nk > SCAN_DENSE) {                                                                                          \
+      if (lane == 0) {                                                                                              \
+        s_kept = kept;                                                                                              \
+        s_cmd = c;                                                                                                  \
+      }                                                                                                             \
+      __syncthreads();                                                                                              \
+      scan_coop_fetch(mask, nb, c, kept, 0, lane, s_part[0]);                                                       \
+      __syncthreads();                                                                                              \
+      _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                                            \
+        if (s4 * 64 < nb) {                                                                                         \
+          uint64_t a_ = 0ull;                                                                                       \
+          _Pragma("unroll") for (int w_ = 0; w_ < SCAN_WAVES; ++w_) a_ |= s_part[w_][lane + 64 * s4];               \
+          if (s4 == 0) rm0 |= a_;                                                                                   \
+          else if (s4 == 1) rm1 |= a_;                                                                              \
+          else if (s4 == 2) rm2 |= a_;                                                                              \
+          else rm3 |= a_;                                                                                           \
+        }                                                                                                           \
+      }                                                                                                             \
+      carry_a = carry_b; /* this chunk's words c+1, c+2 are in rm already */                                        \
+      carry_b = 0ull;                                                                                               \
+    } else {                                                                                                        \
+      uint64_t k1 = 0ull, k2 = 0ull;                                                                                \
+      for (uint64_t t_ = kept; t_ != 0ull; t_ &= t_ - 1ull) {                                                       \
+        const int b = __builtin_ctzll(t_);                                                                          \
+        k1 |= readlane_u64(n1, b);                                                                                  \
+        k2 |= readlane_u64(n2, b);                                                                                  \
+      }                                                                                                             \
+      carry_a = carry_b | k1; /* word c+1: chunk c-1's second look-ahead word and this chunk's first */             \
+      carry_b = k2;           /* word c+2 */                                                                        \
+      uint64_t todo = kept;                                                                                         \
+      if (todo != 0ull) {                                                                                           \
+        FRCNN_SCAN_ROWS4()                                                                                          \
+        FRCNN_SCAN_FETCH4(PEND, c + 3) /* merged at the end of chunk c+2 */                                         \
+      }                                                                                                             \
+      if (todo != 0ull) { /* survivors five to eight: waited for */                                                 \
+        FRCNN_SCAN_ROWS4()                                                                                          \
+        uint64_t v[4][4];                                                                                           \
+        FRCNN_SCAN_FETCH4(v, c + 3)                                                                                 \
+        FRCNN_SCAN_MERGE4(v)                                                                                        \
+      }                                                                                                             \
+    }                                                                                                               \
+  }
+
+__global__ __launch_bounds__(64 * SCAN_WAVES) void nms_scan_kernel(const uint64_t* __restrict__ mask,
+                                                                  const uint64_t* __restrict__ diag_t,
+                                                                  const int* __restrict__ n_dev, int n_max, int nb,
+                                                                  int max_keep, int64_t* __restrict__ keep_idx,
+                                                                  uint8_t* __restrict__ keep_mask,
+                                                                  int* __restrict__ keep_count) {
+  __shared__ uint64_t s_part[SCAN_WAVES][256];
+  __shared__ uint64_t s_kept;
+  __shared__ int s_cmd;
+  const int n = n_dev ? min(*n_dev, n_max) : n_max;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave != 0) {
+    // helpers sleep at the barrier until wave 0 posts a chunk (s_cmd >= 0) or the end of the scan (s_cmd < 0)
+    for (;;) {
+      __syncthreads();
+      const int c = s_cmd;
+      if (c < 0) return;
+      scan_coop_fetch(mask, nb, c, s_kept, wave, lane, s_part[wave]);
+      __syncthreads();
+    }
+  }
+  uint64_t rm0 = 0, rm1 = 0, rm2 = 0, rm3 = 0;   // removed bits of words lane, lane+64, lane+128, lane+192
+  uint64_t carry_a = 0, carry_b = 0;             // removed bits of words c and c+1 not yet merged into rm
+  uint64_t pend_a[4][4], pend_b[4][4];           // ring of two pending batches [row][word slot]: even / odd chunks
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) pend_a[q][s4] = pend_b[q][s4] = 0ull;
+  int count = 0;
+  uint64_t pq[4], n1q[4], n2q[4];                // predecessor word + two look-ahead words of the next four chunks' rows
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = k * 64 + lane;
+    pq[k] = i < n ? diag_t[i] : 0ull;
+    n1q[k] = (i < n && k + 1 < nb) ? mask[(size_t)i * nb + (k + 1)] : 0ull;
+    n2q[k] = (i < n && k + 2 < nb) ? mask[(size_t)i * nb + (k + 2)] : 0ull;
+  }
+  for (int c4 = 0;; c4 += 4) {
+    FRCNN_SCAN_CHUNK(c4, pend_a, 0)
+    FRCNN_SCAN_CHUNK(c4 + 1, pend_b, 1)
+    FRCNN_SCAN_CHUNK(c4 + 2, pend_a, 2)
+    FRCNN_SCAN_CHUNK(c4 + 3, pend_b, 3)
+  }
+  for (int i = count + lane; i < max_keep; i += 64) keep_idx[i] = 0;   // the unused tail is defined (callers pass empty buffers)
+  if (lane == 0) {
+    s_cmd = -1;
+    keep_count[0] = count;
+  }
+  __syncthreads();   // releases the helpers
+}
+#undef FRCNN_SCAN_CHUNK
+#undef FRCNN_SCAN_ROWS4
+#undef FRCNN_SCAN_MERGE4
+#undef FRCNN_SCAN_FETCH4
 
 __global__ __launch_bounds__(256) void make_rois_kernel(const float* __restrict__ boxes, const float* __restrict__ scs,
                                                        const int64_t* __restrict__ keep_idx,
@@ -486,6 +721,17 @@ constexpr int FILTER_THREADS = 256;
 // One workgroup per foreground class.  ws per class: sorted boxes [R][4] floats, mask [R][nb] u64,
 // keep_idx [R] int64.  E = 4: image boxes; E = 7: LiDAR boxes [xc,yc,zc,l,w,h,ry], suppressed on the
 // yaw-less BEV rectangle xc -+ l/2, yc -+ w/2 (filter_predictions.py:55-62,67); rows of dets are E+1 wide.
+// Class 0 (background) never has detections (filter_predictions.py:45 loops over classes 1..K-1): block 0 of the
+// per-class filter kernels writes that class's slice of every output, so the callers need no zero-filled buffers.
+template <int E>
+__device__ __forceinline__ void filter_fill_background(int t, int threads, int max_out, float* __restrict__ dets,
+                                                       int* __restrict__ det_count, int* __restrict__ det_roi) {
+  for (int e = t; e < max_out * (E + 1); e += threads) dets[e] = 0.f;
+  if (det_roi)
+    for (int e = t; e < max_out; e += threads) det_roi[e] = -1;
+  if (t == 0) det_count[0] = 0;
+}
+
 template <int E>
 __global__ __launch_bounds__(FILTER_THREADS) void filter_class_kernel(
     const float* __restrict__ pred_boxes, const float* __restrict__ cls_prob, const int* __restrict__ roi_count,
@@ -495,11 +741,15 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_class_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char filt_smem[];
   uint64_t* keys = reinterpret_cast<uint64_t*>(filt_smem);  // [npad]
   __shared__ int s_n, s_keep;
-  const int cls = blockIdx.x + 1;
+  const int cls = blockIdx.x;
   const int t = threadIdx.x;
+  if (cls == 0) {   // background rows of the outputs (see filter_fill_background)
+    filter_fill_background<E>(t, FILTER_THREADS, max_out, dets, det_count, det_roi);
+    return;
+  }
   const int R = roi_count ? min(*roi_count, num_rois) : num_rois;
 
-  unsigned char* my = ws + (size_t)blockIdx.x * ws_per_class;
+  unsigned char* my = ws + (size_t)(blockIdx.x - 1) * ws_per_class;
   float* sboxes = reinterpret_cast<float*>(my);
   uint64_t* mask = reinterpret_cast<uint64_t*>(my + align_up((size_t)num_rois * 16, 16));
   int64_t* keep_idx = reinterpret_cast<int64_t*>(reinterpret_cast<unsigned char*>(mask) + (size_t)num_rois * nb * 8);
@@ -599,8 +849,12 @@ __global__ __launch_bounds__(FILTER_SMALL_THREADS) void filter_class_small_kerne
   int64_t* keep_idx = reinterpret_cast<int64_t*>(sboxes + num_rois);
   uint64_t* mask = reinterpret_cast<uint64_t*>(keep_idx + num_rois);
   __shared__ int s_n;
-  const int cls = blockIdx.x + 1;
+  const int cls = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (cls == 0) {   // the background class has no detections: its rows of the outputs are written here, not by the caller
+    filter_fill_background<E>(t, FILTER_SMALL_THREADS, max_out, dets, det_count, det_roi);
+    return;
+  }
   const int R = roi_count ? min(*roi_count, num_rois) : num_rois;
   if (t == 0) s_n = 0;
   __syncthreads();
@@ -912,7 +1166,7 @@ extern "C" int frcnn_gather_rows(const float* rows, const int64_t* order, const 
 extern "C" size_t frcnn_nms_ws_bytes(int n_max) {
   if (n_max <= 0) return 0;
   const size_t nb = (size_t)(n_max + 63) / 64;
-  return (size_t)n_max * nb * sizeof(uint64_t);
+  return (size_t)n_max * nb * sizeof(uint64_t) + (size_t)n_max * sizeof(uint64_t);   // bit-matrix + predecessor words
 }
 
 extern "C" int frcnn_nms(const float* boxes, const int* n_dev, int n_max, float thresh, int max_keep,
@@ -925,15 +1179,16 @@ extern "C" int frcnn_nms(const float* boxes, const int* n_dev, int n_max, float 
   const size_t need = frcnn_nms_ws_bytes(n_max);
   if (!ws || ws_bytes < need) return fail(FRCNN_ERR_WS, "nms: workspace %zu < %zu bytes", ws_bytes, need);
   uint64_t* mask = static_cast<uint64_t*>(ws);
+  uint64_t* diag_t = mask + (size_t)n_max * nb;
   if (keep_mask) {
     hipError_t e = hipMemsetAsync(keep_mask, 0, (size_t)n_max, stream);
     if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "nms: memset: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb), dim3(64), 0, stream, boxes, n_dev, n_max, nb, thresh, mask);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb), dim3(64), 0, stream, boxes, n_dev, n_max, nb, thresh, mask, diag_t);
   int rc = check_launch("nms_mask_kernel");
   if (rc != FRCNN_OK) return rc;
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, stream, mask, n_dev, n_max, nb, std::min(max_keep, n_max),
-                     keep_idx, keep_mask, keep_count);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64 * SCAN_WAVES), 0, stream, (const uint64_t*)mask,
+                     (const uint64_t*)diag_t, n_dev, n_max, nb, std::min(max_keep, n_max), keep_idx, keep_mask, keep_count);
   return check_launch("nms_scan_kernel");
 }
 
@@ -982,8 +1237,6 @@ static int launch_filter(float* pred_boxes, const float* cls_prob, const int* ro
     int rc = check_launch("clamp_pred_boxes_kernel");
     if (rc != FRCNN_OK) return rc;
   }  // LiDAR boxes are not clamped (filter_predictions.py:92-93)
-  hipError_t e = hipMemsetAsync(det_count, 0, sizeof(int) * num_classes, stream);
-  if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "filter_per_class: memset: %s", hipGetErrorString(e));
   if (num_rois <= FILTER_SMALL_MAX && filter_small_lds(num_rois) <= (size_t)150 * 1024 && g_filter_variant != 1) {
     const size_t lds = filter_small_lds(num_rois);
     static std::atomic<size_t> configured_s{0};
@@ -993,7 +1246,7 @@ static int launch_filter(float* pred_boxes, const float* cls_prob, const int* ro
       if (e2 != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "filter_per_class: set LDS size: %s", hipGetErrorString(e2));
       configured_s.store(lds);
     }
-    hipLaunchKernelGGL(filter_class_small_kernel<E>, dim3(num_classes - 1), dim3(FILTER_SMALL_THREADS), lds, stream,
+    hipLaunchKernelGGL(filter_class_small_kernel<E>, dim3(num_classes), dim3(FILTER_SMALL_THREADS), lds, stream,
                        pred_boxes, cls_prob, roi_count, num_rois, num_classes, thresh, nms_thresh, max_dets, max_out, dets,
                        det_count, det_roi);
     return check_launch("filter_class_small_kernel");
@@ -1008,7 +1261,7 @@ static int launch_filter(float* pred_boxes, const float* cls_prob, const int* ro
     if (e2 != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "filter_per_class: set LDS size: %s", hipGetErrorString(e2));
     configured.store(lds);
   }
-  hipLaunchKernelGGL(filter_class_kernel<E>, dim3(num_classes - 1), dim3(FILTER_THREADS), lds, stream, pred_boxes,
+  hipLaunchKernelGGL(filter_class_kernel<E>, dim3(num_classes), dim3(FILTER_THREADS), lds, stream, pred_boxes,
                      cls_prob, roi_count, num_rois, num_classes, thresh, nms_thresh, max_dets, max_out, npad, nb, dets,
                      det_count, det_roi, static_cast<unsigned char*>(ws), filter_ws_per_class(num_rois));
   return check_launch("filter_class_kernel");

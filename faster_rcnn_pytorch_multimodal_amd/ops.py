@@ -352,7 +352,7 @@ def nms_sorted(boxes, thresh, max_keep=None, n_dev=None, want_mask=False):
     _dev_f32(boxes, "boxes")
     n = boxes.shape[0]
     max_keep = n if max_keep is None or max_keep <= 0 else min(max_keep, n)
-    keep_idx = torch.zeros((max_keep,), dtype=torch.int64, device=boxes.device)
+    keep_idx = torch.empty((max_keep,), dtype=torch.int64, device=boxes.device)     # the kernel zeroes the unused tail
     keep_count = torch.empty((1,), dtype=torch.int32, device=boxes.device)
     keep_mask = torch.empty((n,), dtype=torch.uint8, device=boxes.device) if want_mask else None
     ws_bytes = lib.frcnn_nms_ws_bytes(n)
@@ -444,11 +444,11 @@ def filter_per_class_lidar(pred_boxes, cls_prob, thresh, nms_thresh, max_dets, m
     if pred_boxes.shape[1] != 7 * k:
         raise _hip.HipError("filter_per_class_lidar: pred_boxes must be (R, 7K)")
     max_out = r if max_out is None else max_out
-    dets = torch.zeros((k, max_out, 8), dtype=torch.float32, device=cls_prob.device)
-    det_count = torch.zeros((k,), dtype=torch.int32, device=cls_prob.device)
+    dets = torch.empty((k, max_out, 8), dtype=torch.float32, device=cls_prob.device)    # every row is written by the call
+    det_count = torch.empty((k,), dtype=torch.int32, device=cls_prob.device)
     ws_bytes = lib.frcnn_filter_per_class_ws_bytes(r, k)
     ws = _workspace(ws_bytes, cls_prob.device)
-    det_roi = torch.full((k, max_out), -1, dtype=torch.int32, device=cls_prob.device) if want_rois else None   # class 0 stays -1
+    det_roi = torch.empty((k, max_out), dtype=torch.int32, device=cls_prob.device) if want_rois else None   # -1 = no detection
     _hip.check(lib.frcnn_filter_per_class_lidar(_ptr(pred_boxes), _ptr(cls_prob), _ptr(roi_count), r, k, float(thresh),
                                                 float(nms_thresh), int(max_dets), int(max_out), _ptr(dets),
                                                 _ptr(det_count), _ptr(det_roi), _ptr(ws), ws_bytes, _stream()),
@@ -464,11 +464,11 @@ def filter_per_class(pred_boxes, cls_prob, frame_w, frame_h, scale, thresh, nms_
     _dev_f32(pred_boxes, "pred_boxes"); _dev_f32(cls_prob, "cls_prob")
     r, k = cls_prob.shape
     max_out = r if max_out is None else max_out
-    dets = torch.zeros((k, max_out, 5), dtype=torch.float32, device=cls_prob.device)
-    det_count = torch.zeros((k,), dtype=torch.int32, device=cls_prob.device)
+    dets = torch.empty((k, max_out, 5), dtype=torch.float32, device=cls_prob.device)    # every row is written by the call
+    det_count = torch.empty((k,), dtype=torch.int32, device=cls_prob.device)
     ws_bytes = lib.frcnn_filter_per_class_ws_bytes(r, k)
     ws = _workspace(ws_bytes, cls_prob.device)
-    det_roi = torch.full((k, max_out), -1, dtype=torch.int32, device=cls_prob.device) if want_rois else None   # class 0 stays -1
+    det_roi = torch.empty((k, max_out), dtype=torch.int32, device=cls_prob.device) if want_rois else None   # -1 = no detection
     _hip.check(lib.frcnn_filter_per_class(_ptr(pred_boxes), _ptr(cls_prob), _ptr(roi_count), r, k, float(frame_w),
                                           float(frame_h), float(scale), float(thresh), float(nms_thresh), int(max_dets),
                                           int(max_out), _ptr(dets), _ptr(det_count), _ptr(det_roi), _ptr(ws), ws_bytes,

@@ -191,8 +191,8 @@ int frcnn_gather_rows(const float* rows, const int64_t* order, const int* count,
 /* torchvision.ops.nms (call sites proposal_layer.py:46, filter_predictions.py:67-69) on boxes already
  * sorted by descending score: box j is dropped when IoU(i,j) > thresh for an earlier kept i
  * (areas without +1).  n_dev (device int, may be NULL -> n_max) boxes are live.
- * keep_idx[max_keep] int64 positions of survivors in score order, keep_mask[n_max] bytes,
- * keep_count[0] = min(#survivors, max_keep). */
+ * keep_idx[max_keep] int64 positions of survivors in score order (entries past keep_count are written as 0),
+ * keep_mask[n_max] bytes, keep_count[0] = min(#survivors, max_keep). */
 size_t frcnn_nms_ws_bytes(int n_max);
 int frcnn_nms(const float* boxes, const int* n_dev, int n_max, float thresh, int max_keep,
               int64_t* keep_idx, uint8_t* keep_mask, int* keep_count, void* ws, size_t ws_bytes,
@@ -255,7 +255,8 @@ int frcnn_head_fc_softmax_decode_lidar(const float* x, int num_rois, int pooled,
  * 45-72; lib/model/test.py:210-221) for the image detector, all on the device:
  * clamp to [0, frame/scale-1] in place, per class j>=1 keep score > thresh, NMS(nms_thresh) in
  * descending score order, keep dets with score >= the max_dets-th best.
- * dets (K, max_out, 5) [x1,y1,x2,y2,score], det_count (K) ints. roi_count device int or NULL.
+ * dets (K, max_out, 5) [x1,y1,x2,y2,score], det_count (K) ints: EVERY row is written by the call (rows past a class's
+ * count and the whole background class 0 are zero), the caller need not clear them.  roi_count device int or NULL.
  * det_roi (K, max_out) ints or NULL: RoI row of every detection (-1 past det_count) - what nms_hstack_var_torch
  * (filter_predictions.py:23-43) needs to gather the per-RoI uncertainties of the kept detections. */
 /* Test hook: 0 = automatic (num_rois <= 1024: LDS-resident kernel), 1 = always the general workspace kernel. */
