@@ -207,8 +207,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_topk_desc_kernel(const floa
 //   3 x { topk_hist_kernel (all CUs: 11/11/10-bit digit histogram of the keys that still match the prefix)
 //         topk_pick_kernel (one wave: bucket holding the top_n-th key -> extends the prefix) }
 //   topk_count_eq_kernel  per-workgroup count of keys == kth over a contiguous index range
-//   topk_scan_eq_kernel   exclusive scan of those counts (ties are taken lowest index first)
-//   topk_compact_kernel   keys < kth (any slot) and the first need_eq ties (ordered slots) -> u64 candidates
+//   topk_compact_kernel   keys < kth (any slot) and the first need_eq ties (ordered slots: ties are taken lowest index
+//                         first, each workgroup adds up the counts of the workgroups before it) -> u64 candidates
 //   topk_rank_sort_kernel   every CU ranks 16 candidates against all <= 16384 of them; outputs in the canonical order
 // ------------------------------------------------------------------------------------------------
 constexpr int TOPK_BINS = 2048;
@@ -298,33 +298,9 @@ __global__ __launch_bounds__(256) void topk_count_eq_kernel(const float* __restr
   if (threadIdx.x == 0) block_eq[blockIdx.x] = s_cnt;
 }
 
-__global__ __launch_bounds__(1024) void topk_scan_eq_kernel(uint32_t* __restrict__ block_eq, int nblocks) {
-  // exclusive scan in place (nblocks <= 16384 handled in chunks of 1024 with a running carry)
-  __shared__ uint32_t buf[1024];
-  __shared__ uint32_t carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < nblocks; base += 1024) {
-    const int i = base + threadIdx.x;
-    const uint32_t v = i < nblocks ? block_eq[i] : 0u;
-    buf[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      const uint32_t u = threadIdx.x >= off ? buf[threadIdx.x - off] : 0u;
-      __syncthreads();
-      buf[threadIdx.x] += u;
-      __syncthreads();
-    }
-    if (i < nblocks) block_eq[i] = carry + buf[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry += buf[1023];
-    __syncthreads();
-  }
-}
-
 __global__ __launch_bounds__(256) void topk_compact_kernel(const float* __restrict__ scores, int n, int take,
                                                           TopkState* __restrict__ st,
-                                                          const uint32_t* __restrict__ block_eq_excl,
+                                                          const uint32_t* __restrict__ block_eq,
                                                           uint64_t* __restrict__ cand) {
   // thread t owns the contiguous range [lo + 16t, lo + 16t + 16): ties stay in index order
   __shared__ uint32_t scan[256];
@@ -350,7 +326,18 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(const float* __restri
     scan[threadIdx.x] += v;
     __syncthreads();
   }
-  uint32_t rank = block_eq_excl[blockIdx.x] + scan[threadIdx.x] - my_eq;
+  // ties before this workgroup's range: sum of the earlier workgroups' counts (<= 256 of them; a separate one-workgroup
+  // scan kernel did this before, 4.4 us of launch for a handful of adds)
+  __shared__ uint32_t s_before;
+  if (threadIdx.x == 0) s_before = 0;
+  __syncthreads();
+  {
+    uint32_t part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) part += block_eq[b];
+    if (part) atomicAdd(&s_before, part);
+  }
+  __syncthreads();
+  uint32_t rank = s_before + scan[threadIdx.x] - my_eq;
   for (int i = lo; i < hi && rank < need_eq; ++i) {
     const uint32_t k = desc_key(scores[i]);
     if (k == kth) {
@@ -415,8 +402,18 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ n_dev,
                                                      int n_max, int nb, float thresh, uint64_t* __restrict__ mask,
                                                      uint64_t* __restrict__ diag_t) {
-  const int bi = blockIdx.y, bj = blockIdx.x;
-  if (bj < bi) return;  // only words on or right of the diagonal are ever read
+  // 1-D grid over the blocks on / right of the diagonal only (row bi holds nb - bi of them): the square grid spent its
+  // time dispatching the empty half
+  int bi, bj;
+  {
+    const int t = blockIdx.x;
+    const float a = 2.0f * nb + 1.0f;
+    bi = (int)((a - sqrtf(a * a - 8.0f * t)) * 0.5f);
+    bi = max(0, min(bi, nb - 1));
+    while (bi > 0 && bi * (2 * nb - bi + 1) / 2 > t) --bi;
+    while ((bi + 1) * (2 * nb - bi) / 2 <= t) ++bi;
+    bj = bi + (t - bi * (2 * nb - bi + 1) / 2);
+  }
   const int n = n_dev ? min(*n_dev, n_max) : n_max;
   if (bi * 64 >= n) return;
   __shared__ float cols[64 * 4];
@@ -1125,7 +1122,6 @@ extern "C" int frcnn_sort_topk_desc(const float* scores, int n, int top_n, int64
       hipLaunchKernelGGL(topk_pick_kernel, dim3(1), dim3(64), 0, stream, st, pass);
     }
     hipLaunchKernelGGL(topk_count_eq_kernel, dim3(nblocks), dim3(256), 0, stream, scores, n, st, block_eq);
-    hipLaunchKernelGGL(topk_scan_eq_kernel, dim3(1), dim3(1024), 0, stream, block_eq, nblocks);
     hipLaunchKernelGGL(topk_compact_kernel, dim3(nblocks), dim3(256), 0, stream, scores, n, take, st, block_eq, cand);
     int rc = check_launch("topk multi-workgroup select");
     if (rc != FRCNN_OK) return rc;
@@ -1184,7 +1180,7 @@ extern "C" int frcnn_nms(const float* boxes, const int* n_dev, int n_max, float 
     hipError_t e = hipMemsetAsync(keep_mask, 0, (size_t)n_max, stream);
     if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "nms: memset: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb), dim3(64), 0, stream, boxes, n_dev, n_max, nb, thresh, mask, diag_t);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(nb * (nb + 1) / 2), dim3(64), 0, stream, boxes, n_dev, n_max, nb, thresh, mask, diag_t);
   int rc = check_launch("nms_mask_kernel");
   if (rc != FRCNN_OK) return rc;
   hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64 * SCAN_WAVES), 0, stream, (const uint64_t*)mask,
