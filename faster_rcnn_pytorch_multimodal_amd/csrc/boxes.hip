@@ -1138,7 +1138,7 @@ extern "C" int frcnn_sort_topk_desc(const float* scores, int n, int top_n, int64
     return check_launch("topk_rank_sort_kernel");
   }
   const size_t lds = (size_t)npad * 8 + 256 * 4 + SORT_THREADS * 4;
-  static size_t configured = 0;
+  static std::atomic<size_t> configured{0};
   if (lds > configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_topk_desc_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

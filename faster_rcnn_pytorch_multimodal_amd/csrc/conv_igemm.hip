@@ -28,6 +28,7 @@
 // of the tile configuration for split_k == 1.
 #include "common.h"
 
+#include <atomic>
 #include <hip/hip_ext.h>
 
 #include <array>
@@ -659,7 +660,7 @@ template <int WM, int WN, int TM, int TN, bool ALIGNED>
 int launch_conv(const ConvParams& p, int splits, int groups, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_PITCH * sizeof(float);
-  static bool configured = false;
+  static std::atomic<bool> configured{false};   // idempotent attribute call: a race only repeats it
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, TM, TN, ALIGNED>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -680,7 +681,7 @@ template <int WM, int WN>
 int launch_conv_dma(const ConvParams& p, int splits, int groups, hipStream_t stream) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr size_t lds = (size_t)3 * (BM + BN) * 32 * sizeof(float);
-  static bool configured = false;
+  static std::atomic<bool> configured{false};   // idempotent attribute call: a race only repeats it
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_f32<WM, WN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -9,6 +9,8 @@
 #include "box_math.h"
 #include "rng.h"
 
+#include <atomic>
+
 using namespace frcnn;
 
 namespace {
@@ -418,7 +420,7 @@ int launch_ptl(const float* rois, const float* roi_scores, const int* roi_count,
   for (int q = 0; q < 7; ++q) { norm.means[q] = q < E ? means_host[q] : 0.f; norm.stds[q] = q < E ? stds_host[q] : 1.f; }
   const int npad = next_pow2(std::max(num_rois, 2));
   const size_t lds = (size_t)npad * 16 + (size_t)num_rois * 4;
-  static size_t configured = 0;
+  static std::atomic<size_t> configured{0};
   if (lds > configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ptl_kernel<E>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -66,7 +66,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     rc = lib.frcnn_conv2d_fwd(None, None, None, None, None, None, 1, 8, 8, 4, 8, 3, 3, 1, 1, 0, 0, None, 0, None)
     assert rc == -1 and b"null" in lib.frcnn_last_error()
     assert lib.frcnn_conv2d_fwd_ws_bytes(1, 8, 8, 3, 8, 3, 3, 1, 1, 0) == 0      # c % 4 != 0 -> invalid
-    assert lib.frcnn_nms_ws_bytes(6000) == 6000 * 94 * 8
+    assert lib.frcnn_nms_ws_bytes(6000) == 6000 * 94 * 8 + 6000 * 8      # bit-matrix + one predecessor word per box
     assert lib.frcnn_conv2d_fwd_ws_bytes(1, 38, 63, 256, 256, 3, 3, 1, 1, 3) == 3 * 38 * 63 * 256 * 4
 
 
