@@ -209,7 +209,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_topk_desc_kernel(const floa
 //   topk_count_eq_kernel  per-workgroup count of keys == kth over a contiguous index range
 //   topk_compact_kernel   keys < kth (any slot) and the first need_eq ties (ordered slots: ties are taken lowest index
 //                         first, each workgroup adds up the counts of the workgroups before it) -> u64 candidates
-//   topk_rank_sort_kernel   every CU ranks 16 candidates against all <= 16384 of them; outputs in the canonical order
+//   topk_rank_sort_kernel   every CU ranks 32 candidates against all <= 16384 of them; outputs in the canonical order
 // ------------------------------------------------------------------------------------------------
 constexpr int TOPK_BINS = 2048;
 constexpr int TOPK_BLOCK_ITEMS = 4096;  // scores per workgroup (256 threads x 16)
@@ -302,58 +302,69 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(const float* __restri
                                                           TopkState* __restrict__ st,
                                                           const uint32_t* __restrict__ block_eq,
                                                           uint64_t* __restrict__ cand) {
-  // thread t owns the contiguous range [lo + 16t, lo + 16t + 16): ties stay in index order
-  __shared__ uint32_t scan[256];
+  // thread t owns the contiguous range [lo + 16t, lo + 16t + 16): ties stay in index order.  Slots for the keys < kth
+  // are handed out per WORKGROUP (one global atomic each, after a block scan of the per-thread counts) - one atomic per
+  // key on a single address was 10 of this kernel's 16 us.
+  __shared__ uint32_t scan_lt[256], scan_eq[256];
+  __shared__ uint32_t s_before, s_base;
   const uint32_t kth = st->prefix, need_eq = st->need;
   const uint32_t base_eq = (uint32_t)take - need_eq;   // number of keys < kth
   const int lo = blockIdx.x * TOPK_BLOCK_ITEMS + threadIdx.x * 16;
   const int hi = min(lo + 16, min((blockIdx.x + 1) * TOPK_BLOCK_ITEMS, n));
-  uint32_t my_eq = 0;
-  for (int i = lo; i < hi; ++i) {
-    const uint32_t k = desc_key(scores[i]);
-    if (k < kth) {
-      const uint32_t pos = atomicAdd(&st->fill, 1u);
-      cand[pos] = ((uint64_t)k << 32) | (uint32_t)i;
-    } else if (k == kth) {
-      ++my_eq;
+  uint32_t key[16];
+  uint32_t my_lt = 0, my_eq = 0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = lo + q;
+    key[q] = i < hi ? desc_key(scores[i]) : 0xFFFFFFFFu;
+    if (i < hi) {
+      my_lt += key[q] < kth ? 1u : 0u;
+      my_eq += key[q] == kth ? 1u : 0u;
     }
   }
-  scan[threadIdx.x] = my_eq;
+  scan_lt[threadIdx.x] = my_lt;
+  scan_eq[threadIdx.x] = my_eq;
+  if (threadIdx.x == 0) s_before = 0;
   __syncthreads();
   for (int off = 1; off < 256; off <<= 1) {
-    const uint32_t v = threadIdx.x >= off ? scan[threadIdx.x - off] : 0u;
+    const uint32_t v = threadIdx.x >= off ? scan_lt[threadIdx.x - off] : 0u;
+    const uint32_t w = threadIdx.x >= off ? scan_eq[threadIdx.x - off] : 0u;
     __syncthreads();
-    scan[threadIdx.x] += v;
+    scan_lt[threadIdx.x] += v;
+    scan_eq[threadIdx.x] += w;
     __syncthreads();
   }
   // ties before this workgroup's range: sum of the earlier workgroups' counts (<= 256 of them; a separate one-workgroup
   // scan kernel did this before, 4.4 us of launch for a handful of adds)
-  __shared__ uint32_t s_before;
-  if (threadIdx.x == 0) s_before = 0;
-  __syncthreads();
   {
     uint32_t part = 0;
     for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) part += block_eq[b];
     if (part) atomicAdd(&s_before, part);
   }
+  if (threadIdx.x == 255) s_base = scan_lt[255] ? atomicAdd(&st->fill, scan_lt[255]) : 0u;
   __syncthreads();
-  uint32_t rank = s_before + scan[threadIdx.x] - my_eq;
-  for (int i = lo; i < hi && rank < need_eq; ++i) {
-    const uint32_t k = desc_key(scores[i]);
-    if (k == kth) {
-      cand[base_eq + rank] = ((uint64_t)k << 32) | (uint32_t)i;
+  uint32_t pos = s_base + scan_lt[threadIdx.x] - my_lt;
+  uint32_t rank = s_before + scan_eq[threadIdx.x] - my_eq;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = lo + q;
+    if (i >= hi) break;
+    if (key[q] < kth) {
+      cand[pos++] = ((uint64_t)key[q] << 32) | (uint32_t)i;
+    } else if (key[q] == kth && rank < need_eq) {
+      cand[base_eq + rank] = ((uint64_t)key[q] << 32) | (uint32_t)i;
       ++rank;
     }
   }
 }
 
 // Final ordering of the <= 16384 selected candidates by RANK: keys are unique (the index is in the low word), so the
-// position of a key in the sorted order is the number of candidates smaller than it.  One workgroup ranks 16 keys:
+// position of a key in the sorted order is the number of candidates smaller than it.  One workgroup ranks 32 keys:
 // thread (key k, partition p) counts the keys of partition p below key k against an LDS copy of all candidates
-// (16 lanes read the same LDS word: broadcast), the 16 partial counts of a key are summed in a fixed order, and the
-// key is scattered to its rank.  n^2 / 2^12 compares per thread on every CU of the chip (6000 candidates: 375
-// workgroups, ~4 us) instead of a 91-stage bitonic network inside ONE workgroup (78 us, profiles/r01h_kernel_stats.md).
-constexpr int RANK_KEYS = 16, RANK_PARTS = 16;
+// (32 lanes read the same LDS word: broadcast), the 32 partial counts of a key are summed, and the key is scattered to
+// its rank.  6000 candidates: 188 workgroups of 1024 threads, one round on the chip, 188 compares per thread: 12.7 us
+// (16 keys x 16 partitions: 375 workgroups in two rounds, 26 us; the round-1 bitonic network in ONE workgroup: 78 us).
+constexpr int RANK_KEYS = 32, RANK_PARTS = 32;
 __global__ __launch_bounds__(RANK_KEYS * RANK_PARTS) void topk_rank_sort_kernel(const float* __restrict__ scores,
                                                                               const uint64_t* __restrict__ cand, int take,
                                                                               int64_t* __restrict__ order_out,
