@@ -509,6 +509,175 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_f32(const ConvParams p)
   conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA 128x128 tile, 4 waves, TWO LDS stages (64 KB): two workgroups per CU.  For the GEMMs with many
+// output channels and a short reduction (layer4's 512 -> 2048 / 1024 -> 2048 expansions, the Winograd GEMMs): the
+// 64x64 tile the autotuner otherwise picks there pulls 4x the bytes per FLOP from the L2s (6.4 TB/s, 1.88 GB per call),
+// the 256x128 tile keeps one workgroup per CU whose epilogue nobody overlaps.  Same operand layout, swizzle, zero page
+// and k order as conv_igemm_dma_f32: bit-identical results for split_k == 1.
+// ------------------------------------------------------------------------------------------------
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_dma2_f32(const ConvParams p) {
+  constexpr int TM = 2, TN = 2;
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int PA = BM / 32, PB = BN / 32;          // LDS-DMA instructions (8 rows each) per wave per K-step
+  constexpr int STAGE = (BM + BN) * 32;              // floats per stage
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][BM + BN][32]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wr = wave / WN, wc = wave % WN;
+  const float* const px = p.x + (size_t)blockIdx.y * p.gx;
+  const float* const pw = p.w + (size_t)blockIdx.y * p.gw;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  int tile_m, tile_n;
+  tile_coords(tile, p.tiles_m, p.tiles_n, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int step_begin = blockIdx.z * p.steps_per_split;
+  const int step_end = min(step_begin + p.steps_per_split, p.ksteps);
+  const int nsteps = step_end - step_begin;
+
+  // ---- per-lane sources: lane i of instruction q feeds row 8q + (i >> 3), physical chunk i & 7 -------------
+  const int lrow = lane >> 3, lchunk = lane & 7;
+  int a_base[PA], a_hi0[PA], a_wi0[PA], a_swz[PA];
+#pragma unroll
+  for (int j = 0; j < PA; ++j) {
+    const int row = (wave * PA + j) * 8 + lrow;
+    const int m = m0 + row;
+    a_swz[j] = (lchunk ^ ((row >> 1) & 7)) * 4;
+    if (m < p.M) {
+      const int img = m / (p.Ho * p.Wo);
+      const int rem = m - img * p.Ho * p.Wo;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      a_hi0[j] = ho * p.stride - p.pad;
+      a_wi0[j] = wo * p.stride - p.pad;
+      a_base[j] = ((img * p.H + a_hi0[j]) * p.W + a_wi0[j]) * p.C;
+    } else {
+      a_hi0[j] = -(1 << 20);
+      a_wi0[j] = 0;
+      a_base[j] = 0;
+    }
+  }
+  const float* b_src[PB];
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const int row = (wave * PB + j) * 8 + lrow;
+    const int n = n0 + row;
+    b_src[j] = n < p.K ? pw + (size_t)n * p.Ktot + (lchunk ^ ((row >> 1) & 7)) * 4 : nullptr;
+  }
+  int tr, ts, tc;
+  {
+    const int kf = step_begin * BK;
+    const int tap = kf / p.C;
+    tc = kf - tap * p.C;
+    tr = tap / p.S;
+    ts = tap - tr * p.S;
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  // issue() is called for consecutive steps (the tap state advances by one step per call)
+  auto issue = [&](int step, int stage) {
+    float* sA = smem + stage * STAGE + (wave * PA) * 8 * 32;
+    float* sB = smem + stage * STAGE + BM * 32 + (wave * PB) * 8 * 32;
+    const int koff = (tr * p.W + ts) * p.C + tc;
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+      const int hi = a_hi0[j] + tr, wi = a_wi0[j] + ts;
+      const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      const float* src = ok ? px + a_base[j] + koff + a_swz[j] : g_zero_page;
+      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(sA + j * 8 * 32), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const float* src = b_src[j] ? b_src[j] + step * BK : g_zero_page;
+      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(sB + j * 8 * 32), 16, 0, 0);
+    }
+    tc += BK;
+    if (tc == p.C) {
+      tc = 0;
+      if (++ts == p.S) { ts = 0; ++tr; }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment reads: row = tile row of lane & 31, chunk 2*kk + (lane >> 5), XOR-swizzled
+  int fa_row[TM], fa_x[TM], fb_row[TN], fb_x[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row = (wr * TM + i) * 32 + (lane & 31);
+    fa_row[i] = row * 32;
+    fa_x[i] = (row >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int row = (wc * TN + j) * 32 + (lane & 31);
+    fb_row[j] = BM * 32 + row * 32;
+    fb_x[j] = (row >> 1) & 7;
+  }
+  const int lh = lane >> 5;
+  f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+  auto read_frags = [&](f32x4* fa, f32x4* fb, int stage, int kk) {
+    const float* base = smem + stage * STAGE;
+    const int c = 2 * kk + lh;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(base + fa_row[i] + ((c ^ fa_x[i]) << 2));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(base + fb_row[j] + ((c ^ fb_x[j]) << 2));
+  };
+  auto mma = [&](const f32x4* fa, const f32x4* fb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][q], fa[i][q], acc[i][j], 0, 0, 0);
+  };
+
+  // Two stages, one K-step of look-ahead: the barrier at the END of step s says "every wave has its last fragments of
+  // stage s in registers and every wave's part of stage s+1 has landed", so the loads of step s+2 may overwrite stage s
+  // right after it.  The fragment reads that follow a barrier leave a bubble in this workgroup's MFMA stream; the
+  // second workgroup of the CU (64 KB of LDS each) fills it.
+  if (nsteps > 0) {
+    issue(step_begin, 0);
+    if (nsteps > 1) issue(step_begin + 1, 1);
+    if (nsteps > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int s = 0; s < nsteps; ++s) {
+    const int stage = s & 1;
+    read_frags(fa0, fb0, stage, 0);
+    read_frags(fa1, fb1, stage, 1);
+    mma(fa0, fb0);
+    read_frags(fa0, fb0, stage, 2);
+    mma(fa1, fb1);
+    read_frags(fa1, fb1, stage, 3);
+    mma(fa0, fb0);
+    if (s + 1 < nsteps) {
+      // the last fragments of this stage are in registers (the MFMAs below only read registers): wait for the loads of
+      // step s+1 (the only ones outstanding), meet the other waves, refill this stage with step s+2
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 2 < nsteps) issue(step_begin + s + 2, stage);
+    }
+    mma(fa1, fb1);
+  }
+  conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
+}
+
+
 // Split-K second pass: y = act((sum_z partial[z]) * scale + shift + res), slabs summed in z order.
 __global__ __launch_bounds__(256) void conv_splitk_epilogue(const float* __restrict__ partial, int splits,
                                                            size_t mk, int K, const float* scale,
@@ -537,6 +706,7 @@ constexpr TileCfg kTiles[] = {
     {2, 1, 2, 2, 2, 1},  // 128x64
     {1, 2, 2, 2, 1, 2},  // 64x128
     {1, 1, 2, 2, 1, 1},  // 64x64
+    {2, 2, 2, 2, 2, 2},  // 128x128, 4 waves, LDS-DMA with two stages: two workgroups per CU (C % 32 == 0; else as index 2)
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -588,8 +758,8 @@ Plan choose_plan(int M, int K, int ksteps, int forced_splits) {
   }
   if (forced_splits > 0 && best_t == 1e300) {
     const int sps = (ksteps + forced_splits - 1) / forced_splits;
-    int ci = kNumTiles - 1;
-    for (int i = 0; i < kNumTiles; ++i)
+    int ci = 5;   // 64x64
+    for (int i = kNumTiles - 1; i >= 0; --i)   // first entry with the forced tile (index 6 repeats the 128x128 shape)
       if (g_force_tm > 0 && kTiles[i].tm == g_force_tm && kTiles[i].tn == g_force_tn) ci = i;
     best = Plan{ci, (ksteps + sps - 1) / sps, sps};
   }
@@ -697,6 +867,24 @@ int launch_conv_dma(const ConvParams& p, int splits, int groups, hipStream_t str
   return frcnn::check_launch("conv_igemm_dma_f32");
 }
 
+int launch_conv_dma2(const ConvParams& p, int splits, int groups, hipStream_t stream) {
+  constexpr size_t lds = (size_t)2 * (128 + 128) * 32 * sizeof(float);
+  static std::atomic<bool> configured{false};   // idempotent attribute call: a race only repeats it
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma2_f32<2, 2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return frcnn::fail(FRCNN_ERR_LAUNCH, "conv: set LDS size: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, groups, splits);
+  hipEvent_t e0, e1;
+  if (prof_events(0, &e0, &e1))
+    hipExtLaunchKernelGGL((conv_igemm_dma2_f32<2, 2>), grid, dim3(256), (uint32_t)lds, stream, e0, e1, 0, p);
+  else
+    hipLaunchKernelGGL((conv_igemm_dma2_f32<2, 2>), grid, dim3(256), lds, stream, p);
+  return frcnn::check_launch("conv_igemm_dma2_f32");
+}
+
 // tuning hook: 0 = register-staged kernels only, 1 = LDS-DMA kernel for the 8-wave tiles when C % 32 == 0
 int g_use_dma = 1;
 
@@ -724,7 +912,8 @@ extern "C" int frcnn_conv2d_set_algo(int mode) {
 }
 
 extern "C" int frcnn_conv2d_set_staging(int use_lds_dma) {
-  g_use_dma = use_lds_dma ? 1 : 0;
+  FRCNN_REQUIRE(use_lds_dma >= 0 && use_lds_dma <= 2, "conv2d_set_staging: mode %d (0, 1 or 2)", use_lds_dma);
+  g_use_dma = use_lds_dma;
   return FRCNN_OK;
 }
 
@@ -985,7 +1174,14 @@ int launch_gemm(ConvParams p, const Plan& pl, long M, int k, int groups, hipStre
       if (aligned && g_use_dma) rc = launch_conv_dma<2, 4>(p, pl.splits, groups, stream);
       else FRCNN_CONV_CASE(2, 4, 2, 2);
       break;
-    case 2: FRCNN_CONV_CASE(2, 2, 2, 2); break;
+    case 2:
+      if (aligned && g_use_dma == 2) rc = launch_conv_dma2(p, pl.splits, groups, stream);   // test hook, see set_staging
+      else FRCNN_CONV_CASE(2, 2, 2, 2);
+      break;
+    case 6:
+      if (aligned && g_use_dma) rc = launch_conv_dma2(p, pl.splits, groups, stream);
+      else FRCNN_CONV_CASE(2, 2, 2, 2);
+      break;
     case 3: FRCNN_CONV_CASE(2, 2, 2, 1); break;
     case 4: FRCNN_CONV_CASE(2, 2, 1, 2); break;
     default: FRCNN_CONV_CASE(2, 2, 1, 1); break;

@@ -96,8 +96,10 @@ int frcnn_conv2d_clear_plans(void);
 int frcnn_conv2d_export_plans(int* out, int capacity_entries);
 int frcnn_conv2d_import_plans(const int* in, int entries);
 
-/* Tuning / test hook: 1 (default) stages the 8-wave tiles with LDS-DMA (global_load_lds) when C % 32 == 0,
- * 0 uses the register-staged kernel everywhere.  Results are bit-identical for split_k = 1. */
+/* Tuning / test hook: 1 (default) stages the 8-wave tiles with LDS-DMA (global_load_lds) when C % 32 == 0 (and the
+ * autotuner may pick the two-stage LDS-DMA 128x128 tile, plan tile index 6), 0 uses the register-staged kernels
+ * everywhere, 2 additionally runs a FORCED 128x128 tile (frcnn_conv2d_set_tile(2, 2)) on the two-stage LDS-DMA kernel.
+ * Results are bit-identical for split_k = 1. */
 int frcnn_conv2d_set_staging(int use_lds_dma);
 
 /* Algorithm of the 3x3 / stride 1 / pad 1 convolutions without a residual (lib/nets/resnet.py:119-121 conv2 of a

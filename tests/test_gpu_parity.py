@@ -105,9 +105,22 @@ def test_conv2d_is_deterministic_and_tile_independent(hip):
     for tile in ((2, 2), (1, 1), (2, 1), (4, 2), (2, 4)):
         hip.frcnn_conv2d_set_tile(*tile)
         outs.append(ops.conv2d_nhwc(x, w, stride=1, pad=1, split_k=1).cpu())
+    # the two-stage LDS-DMA 128x128 tile (plan tile index 6; staging mode 2 routes a forced (2, 2) tile to it), with a
+    # residual and an odd map so that M and the tile tails are exercised too
+    hip.frcnn_conv2d_set_tile(2, 2)
+    hip.frcnn_conv2d_set_staging(2)
+    outs.append(ops.conv2d_nhwc(x, w, stride=1, pad=1, split_k=1).cpu())
+    res = torch.randn(1, 38, 63, 256, generator=g).to(DEV)
+    sc, sh = (torch.rand(256, generator=g) + 0.5).to(DEV), torch.randn(256, generator=g).to(DEV)
+    dma2 = ops.conv2d_nhwc(x, w, sc, sh, res, stride=1, pad=1, relu=True, split_k=1).cpu()
+    dma2_split = ops.conv2d_nhwc(x, w, sc, sh, res, stride=1, pad=1, relu=True, split_k=3).cpu()
+    hip.frcnn_conv2d_set_staging(1)
+    plain = ops.conv2d_nhwc(x, w, sc, sh, res, stride=1, pad=1, relu=True, split_k=1).cpu()
+    plain_split = ops.conv2d_nhwc(x, w, sc, sh, res, stride=1, pad=1, relu=True, split_k=3).cpu()
     hip.frcnn_conv2d_set_tile(0, 0)
     # split_k = 1: the MFMA is an exact k-ordered fma chain, so every tile shape gives the same bits
     assert all(torch.equal(outs[0], o) for o in outs[1:])
+    assert torch.equal(dma2, plain) and torch.equal(dma2_split, plain_split)
 
 
 @pytest.mark.parametrize("shape", [
