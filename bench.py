@@ -504,12 +504,13 @@ def main(argv=None):
             achieved = conv["flops_per_frame"] / (conv["ms_per_frame"] * 1e-3) / 1e12
             timed_tflops = conv["flops_per_frame"] / (1e-3 * 1e3 * elapsed / args.steps) / 1e12
             out["roofline"] = {
-                "bound": "mfma", "kernel": "conv_igemm_f32 (all instantiations, %d launches/frame)"
-                % round(conv["launches_per_frame"]), "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
+                "bound": "mfma", "kernel": "frcnn_conv2d_fwd: conv_igemm_* (all instantiations) + split-K second passes + Winograd "
+                "transforms, %d calls/frame" % round(conv["launches_per_frame"]), "achieved": achieved,
+                "peak": MFMA_F32_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic("conv_igemm"),
                 "mode": "isolated kernels: eager launches on one stream, every dispatch bracketed by its own start / stop HIP "
                         "events (hipExtLaunchKernelGGL) = rocprofv3's per-dispatch duration; avg_launch_us is per "
-                        "frcnn_conv2d_fwd call (main kernel + split-K second pass); the timed run overlaps %d frames, see "
+                        "frcnn_conv2d_fwd call (every launch it makes); the timed run overlaps %d frames, see "
                         "frac_timed" % n_streams,
                 "achieved_timed": timed_tflops, "frac_timed": timed_tflops / MFMA_F32_PEAK_TFLOPS,
                 "frac_timed_what": "all conv FLOPs of a frame / ms_per_step of the TIMED run (hipGraph x %d streams) / "
