@@ -29,6 +29,7 @@
 #include "common.h"
 
 #include <atomic>
+#include <type_traits>
 #include <hip/hip_ext.h>
 
 #include <array>
@@ -168,6 +169,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
   }
 }
 
+// 256 zero bytes: out-of-range lanes (padding taps, M / K tails) load from here instead of branching around the load, so
+// every load of a tile is issued unconditionally (and the compiler can count them: partial vmcnt waits)
+__device__ float g_zero_page[64];
+
 template <int WM, int WN, int TM, int TN, bool ALIGNED>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvParams p) {
   constexpr int NT = 64 * WM * WN;
@@ -214,7 +219,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
     }
   }
 
-  f32x4 ra[PA], rb[PB];
+  // two register sets: the tiles of steps s+1 and s+2 are in flight while step s computes
+  f32x4 ra[2][PA], rb[2][PB];
+  typedef std::integral_constant<int, 0> Set0;
+  typedef std::integral_constant<int, 1> Set1;
   // tap state for the ALIGNED path (C % 32 == 0: a K-step never straddles a tap)
   int tr = 0, ts = 0, tc = 0;
   if (ALIGNED) {
@@ -226,7 +234,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
   }
 
   // load_tiles is called for consecutive steps (the ALIGNED tap state advances by one step per call)
-  auto load_tiles = [&](int step) {
+  auto load_tiles = [&](int step, auto set) {
+    constexpr int SL = decltype(set)::value;
     const int kflat = step * BK + kc * 4;
     if (ALIGNED) {
       const int koff = (tr * p.W + ts) * p.C + tc + kc * 4;
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
       for (int i = 0; i < PA; ++i) {
         const int hi = a_hi0[i] + tr, wi = a_wi0[i] + ts;
         const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        ra[i] = ok ? *reinterpret_cast<const f32x4*>(px + a_base[i] + koff) : f32x4{0.f, 0.f, 0.f, 0.f};
+        ra[SL][i] = *reinterpret_cast<const f32x4*>(ok ? px + a_base[i] + koff : g_zero_page);
       }
       tc += BK;
       if (tc == p.C) {
@@ -251,23 +260,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
       for (int i = 0; i < PA; ++i) {
         const int hi = a_hi0[i] + r, wi = a_wi0[i] + s;
         const bool ok = kok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        ra[i] = ok ? *reinterpret_cast<const f32x4*>(px + a_base[i] + koff) : f32x4{0.f, 0.f, 0.f, 0.f};
+        ra[SL][i] = *reinterpret_cast<const f32x4*>(ok ? px + a_base[i] + koff : g_zero_page);
       }
     }
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
       const int n = n0 + j * RPP + row0;
       const bool ok = n < p.K && kflat < p.Ktot;
-      rb[j] = ok ? *reinterpret_cast<const f32x4*>(pw + (size_t)n * p.Ktot + kflat) : f32x4{0.f, 0.f, 0.f, 0.f};
+      rb[SL][j] = *reinterpret_cast<const f32x4*>(ok ? pw + (size_t)n * p.Ktot + kflat : g_zero_page);
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, auto set) {
+    constexpr int SL = decltype(set)::value;
     float* a = As + buf * BM * LDS_PITCH + row0 * LDS_PITCH + kc * 4;
     float* b = Bs + buf * BN * LDS_PITCH + row0 * LDS_PITCH + kc * 4;
 #pragma unroll
-    for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4*>(a + i * RPP * LDS_PITCH) = ra[i];
+    for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4*>(a + i * RPP * LDS_PITCH) = ra[SL][i];
 #pragma unroll
-    for (int j = 0; j < PB; ++j) *reinterpret_cast<f32x4*>(b + j * RPP * LDS_PITCH) = rb[j];
+    for (int j = 0; j < PB; ++j) *reinterpret_cast<f32x4*>(b + j * RPP * LDS_PITCH) = rb[SL][j];
   };
 
   f32x16 acc[TM][TN];
@@ -303,29 +313,43 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][q], fa[i][q], acc[i][j], 0, 0, 0);
   };
 
-  if (step_begin < step_end) {
-    load_tiles(step_begin);
-    store_tiles(0);
-    if (step_begin + 1 < step_end) load_tiles(step_begin + 1);  // stays in registers until group 1 of step 0
+  const int nsteps = step_end - step_begin;
+  if (nsteps > 0) {
+    load_tiles(step_begin, Set0{});
+    store_tiles(0, Set0{});
+    if (nsteps > 1) load_tiles(step_begin + 1, Set0{});  // tile t >= 1 waits in set (t - 1) & 1 until step t - 1 stores it
+    if (nsteps > 2) load_tiles(step_begin + 2, Set1{});
   }
   __syncthreads();
-  if (step_begin < step_end) read_frags(fa0, fb0, 0, 0);
+  if (nsteps > 0) read_frags(fa0, fb0, 0, 0);
 
   int cur = 0;
-  for (int step = step_begin; step < step_end; ++step) {
-    const bool more = step + 1 < step_end;
+  // one K-step; `set` holds tile it + 1 and is refilled with tile it + 3 once that one is in LDS.  STEADY: tiles it+1 and
+  // it+3 exist - no conditions around the loads, so the compiler counts them and waits for the OLDER set only.
+  auto kstep = [&](int it, auto set, auto steady) {
+    constexpr bool STEADY = decltype(steady)::value;
+    const bool more = STEADY || it + 1 < nsteps;
     read_frags(fa1, fb1, cur, 1);
     mma(fa0, fb0);
     read_frags(fa0, fb0, cur, 2);
     mma(fa1, fb1);
-    if (more) store_tiles(cur ^ 1);  // tile step+1: its loads were issued >= 3/4 step ago
+    if (more) store_tiles(cur ^ 1, set);
     read_frags(fa1, fb1, cur, 3);
     mma(fa0, fb0);
-    if (step + 2 < step_end) load_tiles(step + 2);
+    if (STEADY || it + 3 < nsteps) load_tiles(step_begin + it + 3, set);
     __syncthreads();  // buffer cur^1 complete; every wave has its last fragments of buffer cur in registers
     if (more) read_frags(fa0, fb0, cur ^ 1, 0);
     mma(fa1, fb1);
     cur ^= 1;
+  };
+  int it = 0;
+  for (; it + 4 < nsteps; it += 2) {
+    kstep(it, Set0{}, std::true_type{});
+    kstep(it + 1, Set1{}, std::true_type{});
+  }
+  for (; it < nsteps; it += 2) {
+    kstep(it, Set0{}, std::false_type{});
+    if (it + 1 < nsteps) kstep(it + 1, Set1{}, std::false_type{});
   }
 
   conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
@@ -342,7 +366,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
 //   Out-of-range lanes (padding taps, M / K tails) read a zero page instead of branching.
 // Numerics are those of conv_igemm_f32 (same k order), so split_k == 1 results are bit-identical.
 // ------------------------------------------------------------------------------------------------
-__device__ float g_zero_page[64];
 
 template <int WM, int WN>
 __global__ __launch_bounds__(512, 2) void conv_igemm_dma_f32(const ConvParams p) {
