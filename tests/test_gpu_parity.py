@@ -1056,6 +1056,17 @@ def test_conv2d_backward_matches_autograd(hip, case):
     _close_feat(dx.cpu().numpy(), dx_ref.numpy(), "dgrad %s" % (case,), frac=1e-5)
     dx2 = ops.conv2d_bwd_data(dy.to(DEV), w_t, (n, h, w, c), stride=stride, pad=pad, add=add.to(DEV))
     _close_feat(dx2.cpu().numpy(), (dx_ref + add).numpy(), "dgrad+add %s" % (case,), frac=1e-5)
+    if r == 3 and stride == 1 and pad == 1 and k % 4 == 0:
+        # the data gradient of a 3x3 / stride 1 layer is a forward convolution with the flipped filter: the autotuner may
+        # run it as Winograd F(2x2,3x3) too (frcnn_conv2d_set_algo); with an accumulation operand it must fall back
+        try:
+            ops.set_conv_algo(2)
+            dxw = ops.conv2d_bwd_data(dy.to(DEV), w_t, (n, h, w, c), stride=stride, pad=pad)
+            dxw2 = ops.conv2d_bwd_data(dy.to(DEV), w_t, (n, h, w, c), stride=stride, pad=pad, add=add.to(DEV))
+        finally:
+            ops.set_conv_algo(0)
+        _close_feat(dxw.cpu().numpy(), dx_ref.numpy(), "dgrad winograd %s" % (case,), frac=1e-5)
+        assert torch.equal(dxw2, dx2)
     dw, db = ops.conv2d_bwd_weight(x.to(DEV), dy.to(DEV), r, r, stride=stride, pad=pad, want_bias=True)
     _close_feat(dw.cpu().numpy(), dw_ref.numpy(), "wgrad %s" % (case,), frac=2e-5)
     _close_feat(db.cpu().numpy(), db_ref.numpy(), "bias grad %s" % (case,), frac=2e-5)
