@@ -102,10 +102,24 @@ def _pred_boxes_fp64(sd, frame_host, rois_r):
     return pb, cls_prob
 
 
-def test_timed_path_against_cpu_oracle_structured_rpn(hip):
+@pytest.mark.parametrize("conv_algo", [0, 1, 2])
+def test_timed_path_against_cpu_oracle_structured_rpn(hip, conv_algo):
     """Graph x 4 streams vs O.frame_detect on the structured-RPN variant of the frames (injected RPN
     logits / deltas make the ranking of the 59 850 anchors well-conditioned; backbone, RoIAlign, layer4, heads and the
-    per-class filter are each path's own).  Proposal indices bit-exact, detection records within the tolerance."""
+    per-class filter are each path's own).  Proposal indices bit-exact, detection records within the tolerance.
+    conv_algo (frcnn_conv2d_set_algo): 0 = whatever the autotuner picks (the bench's mode), 1 = implicit GEMM only,
+    2 = Winograd F(2x2,3x3) on every eligible 3x3 layer - the same bounds hold for each."""
+    from faster_rcnn_pytorch_multimodal_amd import ops as _ops_mod
+    hip.frcnn_conv2d_clear_plans()
+    _ops_mod.set_conv_algo(conv_algo)
+    try:
+        _timed_path_against_cpu_oracle()
+    finally:
+        _ops_mod.set_conv_algo(0)
+        hip.frcnn_conv2d_clear_plans()
+
+
+def _timed_path_against_cpu_oracle():
     net, sd = bench.build_net(DEV)
     sd = dict(sd)
     sd["cls_score_net.weight"] = sd["cls_score_net.weight"] * 8.0     # spread the scores like a trained head does
