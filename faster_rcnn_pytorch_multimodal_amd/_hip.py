@@ -97,6 +97,8 @@ PROTOTYPES = {
     "frcnn_bayesian_cross_entropy": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_uint32, c_uint32, c_int, c_float, _P, _P, _P,
                                              _P, _P]),
     "frcnn_exp": (c_int, [_P, c_int64, _P, _P]),
+    "frcnn_bbox_transform": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
+    "frcnn_lidar_bbox_transform": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, _P]),
     "frcnn_bbox_overlaps": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, _P]),
     "frcnn_anchor_target_layer_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "frcnn_anchor_target_layer": (c_int, [_P, c_int, _P, c_int, POINTER(c_float), c_int, c_float, c_float, c_float,

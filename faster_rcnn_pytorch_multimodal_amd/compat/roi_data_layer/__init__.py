@@ -1,0 +1,11 @@
+"""Stub for the reference's top-level package ``roi_data_layer`` (lib/roi_data_layer): replaces itself in sys.modules by
+faster_rcnn_pytorch_multimodal_amd.roi_data_layer and aliases its submodules, see ../../reference_names.py."""
+import os
+import sys
+
+_site = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..', '..'))
+if _site not in sys.path:
+    sys.path.append(_site)
+from faster_rcnn_pytorch_multimodal_amd import reference_names  # noqa: E402
+
+reference_names.install()

@@ -338,6 +338,47 @@ extern "C" int frcnn_bbox_overlaps(const float* boxes, int box_ld, int n, const 
   return check_launch("overlaps_kernel");
 }
 
+namespace {
+// the two encoders as stand-alone calls (the target layers above apply them to their sampled rows in place)
+__global__ __launch_bounds__(256) void encode_boxes_kernel(const float* __restrict__ ex, int ex_ld,
+                                                          const float* __restrict__ gt, int gt_ld, int n,
+                                                          float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float o[4];
+  encode_box(ex + (size_t)i * ex_ld, gt + (size_t)i * gt_ld, o);
+  *reinterpret_cast<float4*>(out + (size_t)i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+__global__ __launch_bounds__(256) void encode_boxes_lidar_kernel(const float* __restrict__ rois, int roi_ld,
+                                                                const float* __restrict__ anchors3d,
+                                                                const float* __restrict__ gt, int gt_ld, int n,
+                                                                float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float o[7];
+  encode_box_lidar(rois + (size_t)i * roi_ld, anchors3d + (size_t)i * 7, gt + (size_t)i * gt_ld, o);
+  for (int q = 0; q < 7; ++q) out[(size_t)i * 7 + q] = o[q];
+}
+}  // namespace
+
+extern "C" int frcnn_bbox_transform(const float* ex_rois, int ex_ld, const float* gt_rois, int gt_ld, int n, float* targets,
+                                    void* stream_) {
+  FRCNN_REQUIRE(ex_rois && gt_rois && targets && n > 0 && ex_ld >= 4 && gt_ld >= 4, "bbox_transform: bad arguments");
+  hipLaunchKernelGGL(encode_boxes_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_), ex_rois,
+                     ex_ld, gt_rois, gt_ld, n, targets);
+  return check_launch("encode_boxes_kernel");
+}
+
+extern "C" int frcnn_lidar_bbox_transform(const float* ex_rois, int roi_ld, const float* ex_anchors_3d, const float* gt_rois,
+                                          int gt_ld, int n, float* targets, void* stream_) {
+  FRCNN_REQUIRE(ex_rois && ex_anchors_3d && gt_rois && targets && n > 0 && roi_ld >= 4 && gt_ld >= 7,
+                "lidar_bbox_transform: bad arguments");
+  hipLaunchKernelGGL(encode_boxes_lidar_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     ex_rois, roi_ld, ex_anchors_3d, gt_rois, gt_ld, n, targets);
+  return check_launch("encode_boxes_lidar_kernel");
+}
+
 extern "C" size_t frcnn_anchor_target_layer_ws_bytes(int num_anchors_total, int num_gt, int rpn_batchsize) {
   if (num_anchors_total <= 0 || rpn_batchsize <= 0) return 0;
   const int top_n = std::min(rpn_batchsize, 16384);

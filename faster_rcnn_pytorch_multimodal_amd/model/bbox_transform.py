@@ -26,3 +26,13 @@ def lidar_3d_bbox_transform_inv(rois, boxes, deltas, scales=None):
     if len(boxes) == 0:                      # :181-182
         return deltas.detach() * 0
     return ops.lidar_bbox_transform_inv(rois.contiguous(), boxes.contiguous(), deltas.contiguous(), scales)
+
+
+def bbox_transform(ex_rois, gt_rois):
+    """Targets (N,4) [dx,dy,dw,dh] of gt_rois against ex_rois, row by row.  lib/model/bbox_transform.py:52-70."""
+    return ops.bbox_transform(ex_rois.contiguous(), gt_rois.contiguous())
+
+
+def lidar_3d_bbox_transform(ex_rois, ex_anchors, gt_rois):
+    """Targets (N,7) of the 3-D gt rows against the BEV RoIs and their 3-D anchors.  lib/model/bbox_transform.py:16-49."""
+    return ops.lidar_bbox_transform(ex_rois.contiguous(), ex_anchors.contiguous(), gt_rois.contiguous())

@@ -4,6 +4,7 @@ the reference's lib/model/config.py:11-453 (an attribute dictionary; easydict is
 Only options consumed by the detector forward/backward path are kept; dataset, drawing and output-dir
 options of the reference belong to subsystems outside this package.
 """
+import os
 from ast import literal_eval
 
 import numpy as np
@@ -46,6 +47,11 @@ def _defaults():
     c.USE_LIDAR_FPN = False
     c.ENABLE_FULL_NET = True
     c.NET_TYPE = 'lidar'                   # config.py:55 (the CLIs overwrite it)
+    c.DB_NAME = ''                         # config.py:57
+    # where get_output_dir / get_output_tb_dir put their trees (config.py:349,358); the reference derives ROOT_DIR from
+    # its own checkout, here it is the working directory unless the caller sets it
+    c.ROOT_DIR = os.path.abspath(os.getcwd())
+    c.EXP_DIR = 'res101'
     c.TRAIN = dict(
         LEARNING_RATE=0.001, MOMENTUM=0.5, WEIGHT_DECAY=0.0001, GAMMA=0.1, STEPSIZE=[70000, 140000, 210000],
         BATCH_SIZE=16, VAL_BATCH_SIZE=32, DOUBLE_BIAS=False, TRUNCATED=False, BIAS_DECAY=False, USE_GT=False,
@@ -54,12 +60,12 @@ def _defaults():
         RPN_CLOBBER_POSITIVES=False, RPN_FG_FRACTION=0.5, RPN_BATCHSIZE=256, RPN_NMS_THRESH=0.7,
         RPN_PRE_NMS_TOP_N=12000, RPN_POST_NMS_TOP_N=2000, RPN_BBOX_INSIDE_WEIGHTS=(1.0, 1.0, 1.0, 1.0),
         RPN_POSITIVE_WEIGHT=-1.0, IGNORE_DC=False, ITER=1, DISPLAY=512, SNAPSHOT_KEPT=30, SUMMARY_INTERVAL=15,
-        SNAPSHOT_ITERS=5000, SNAPSHOT_PREFIX='res101_faster_rcnn',
+        SNAPSHOT_ITERS=5000, SNAPSHOT_PREFIX='res101_faster_rcnn', TOD_FILTER_LIST=['Day', 'Night', 'Dawn/Dusk'],
         LIDAR=dict(BBOX_NORMALIZE_MEANS=(0.0,) * 7, BBOX_NORMALIZE_STDS=(0.1, 0.1, 0.1, 0.2, 0.2, 0.2, 1.0)),
         IMAGE=dict(BBOX_NORMALIZE_MEANS=(0.0, 0.0, 0.0, 0.0), BBOX_NORMALIZE_STDS=(0.1, 0.1, 0.2, 0.2)))
     c.TEST = dict(SCALES=(1.0,), NMS_THRESH=0.6, BBOX_REG=True, HAS_RPN=True, RPN_NMS_THRESH=0.7,
                   RPN_PRE_NMS_TOP_N=6000, RPN_POST_NMS_TOP_N=300, MODE='nms', RPN_TOP_N=5000, IGNORE_DC=False,
-                  ITER=1)
+                  ITER=1, AUGMENT_EN=False, TOD_FILTER_LIST=['Day', 'Night', 'Dawn/Dusk'])
     c.RESNET = dict(MAX_POOL=False, FIXED_BLOCKS=1)
     c.PIXEL_MEANS = np.array([[[96.866, 98.76, 93.85]]])
     c.PIXEL_STDDEVS = np.array([[[1, 1, 1]]])
@@ -135,3 +141,36 @@ def cfg_from_list(cfg_list):
         assert type(value) == type(node[leaf]), 'type {} does not match original type {}'.format(
             type(value), type(node[leaf]))
         node[leaf] = value
+
+
+def _run_name(mode):
+    """The directory leaf config.py:462-495 / :508-541 build: enabled-heads prefix + mode + time-of-day filter + ITER."""
+    net_type = '{}_'.format(cfg.NET_TYPE)
+    if cfg.ENABLE_FULL_NET is False:
+        net_type += 'rpn_only_'
+    for flag, tag in (('EN_BBOX_ALEATORIC', 'a_bbox_'), ('EN_CLS_ALEATORIC', 'a_cls_'), ('EN_BBOX_EPISTEMIC', 'e_bbox_'),
+                      ('EN_CLS_EPISTEMIC', 'e_cls_'), ('EN_RPN_BBOX_ALEATORIC', 'a_rpn_bbox_'),
+                      ('EN_RPN_CLS_ALEATORIC', 'a_rpn_cls_'), ('EN_RPN_BBOX_EPISTEMIC', 'e_rpn_bbox_'),
+                      ('EN_RPN_CLS_EPISTEMIC', 'e_rpn_cls_')):
+        if cfg.UC[flag]:
+            net_type += tag
+    tod = cfg.TRAIN.TOD_FILTER_LIST
+    names = {'Day': 'day', 'Night': 'night', 'Dawn/Dusk': 'dawn_dusk'}
+    train_filter = 'all' if len(tod) == 3 else names[tod[0]]
+    return '{}{}_{}_{}'.format(net_type, mode, train_filter, cfg[mode.upper()].ITER)
+
+
+def get_output_dir(db, mode='train', weights_filename=None):
+    """ROOT_DIR/output/EXP_DIR/<db.name>/<run name>, created when missing (reference: config.py:454-498)."""
+    outdir = os.path.join(os.path.abspath(os.path.join(cfg.ROOT_DIR, 'output', cfg.EXP_DIR, db.name)),
+                          weights_filename if weights_filename is not None else _run_name(mode))
+    os.makedirs(outdir, exist_ok=True)
+    return outdir
+
+
+def get_output_tb_dir(db, weights_filename):
+    """ROOT_DIR/tensorboard/EXP_DIR/<db.name>/<run name> (reference: config.py:500-545; the run name is the 'train' one)."""
+    outdir = os.path.join(os.path.abspath(os.path.join(cfg.ROOT_DIR, 'tensorboard', cfg.EXP_DIR, db.name)),
+                          weights_filename if weights_filename is not None else _run_name('train'))
+    os.makedirs(outdir, exist_ok=True)
+    return outdir

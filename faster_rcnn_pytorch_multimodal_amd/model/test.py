@@ -10,8 +10,63 @@ sharded one frame per rank per step.
 import numpy as np
 import torch
 
-from ..model.config import cfg
+from ..model.config import cfg, get_output_dir
+from ..roi_data_layer import minibatch
 from ..utils.filter_predictions import filter_and_draw_prep, filter_device
+
+
+def _get_blobs(filename):
+    """lib/model/test.py:32-44: ``filename`` is a one-element list; returns {'data': (1,H,W,C) device blob, 'info'}."""
+    blobs = {}
+    scale = cfg.TEST.SCALES[0]
+    if cfg.NET_TYPE == 'image':
+        infos, blobs['data'], _ = minibatch._get_image_blob(filename, scale, augment_en=cfg.TEST.AUGMENT_EN, mode='test')
+        blobs['info'] = infos[0]
+    elif cfg.NET_TYPE == 'lidar':
+        infos, blobs['data'], _ = minibatch._get_lidar_blob(filename, lidar_extents(), scale, augment_en=False, mode='test')
+        blobs['info'] = infos[0]
+    return blobs
+
+
+class ReferenceDb:
+    """Adaptor from the reference's dataset protocol to the frame source ``test_net`` iterates.
+
+    The reference's loop (lib/model/test.py:141-147,183-206) reads ``db._val_index`` / ``db._test_index`` for the frame
+    count, ``db.path_at(i, mode)`` for the file of frame i (lib/datasets/db.py:139-148), loads it with ``_get_blobs``
+    and finally calls ``db.evaluate_detections(all_boxes, output_dir, 'val')`` (:256-257).  Any object with those members
+    (the reference's ``waymo_imdb`` / ``kitti_lidb`` / ... classes; dataset classes themselves are outside this package)
+    can be passed to ``test_net`` directly - it is wrapped in this class."""
+
+    def __init__(self, db, get_blobs=None):
+        self.inner = db
+        self._get_blobs = get_blobs or _get_blobs
+
+    @property
+    def num_classes(self):
+        return self.inner.num_classes
+
+    @property
+    def name(self):
+        return self.inner.name
+
+    def _index(self, mode):
+        return self.inner._test_index if mode == 'test' else self.inner._val_index if mode == 'val' else []
+
+    def num_frames(self, mode):
+        return len(self._index(mode))
+
+    def blobs_at(self, i, mode):
+        return self._get_blobs([self.inner.path_at(i, mode)])
+
+    def name_at(self, i, mode):
+        return str(self._index(mode)[i])
+
+    def evaluate_detections(self, all_boxes, out_dir, mode):
+        return self.inner.evaluate_detections(all_boxes, out_dir, mode)
+
+    @staticmethod
+    def wraps(db):
+        return not hasattr(db, 'blobs_at') and (hasattr(db, '_val_index') or hasattr(db, '_test_index'))
 
 
 def frame_detect(net, blobs, num_classes, thresh):
@@ -90,9 +145,11 @@ def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=F
     """Eval loop of lib/model/test.py:138-257 over a frame source, sharded one frame per rank per step when
     torch.distributed is initialised (BASELINE.json configs[4]).
 
-    ``db`` is the caller's dataset adaptor (dataset classes are out of scope): ``num_classes``, ``num_frames(mode)``,
-    ``blobs_at(i, mode)`` -> {'data': (1,H,W,C) blob or None, 'info': 7-vector}, optional ``name_at(i, mode)``,
-    optional ``evaluate_detections(all_boxes, out_dir, mode)``.  Per frame everything stays on the device up to the
+    ``db``: either an object with the reference's dataset protocol (``_val_index`` / ``_test_index``, ``path_at``,
+    ``num_classes``, ``name``, ``evaluate_detections``; wrapped in ``ReferenceDb``, frames loaded by ``_get_blobs``), or a
+    frame source with ``num_classes``, ``num_frames(mode)``, ``blobs_at(i, mode)`` -> {'data': (1,H,W,C) blob or None,
+    'info': 7-vector}, optional ``name_at(i, mode)``, optional ``evaluate_detections(all_boxes, out_dir, mode)``.
+    ``out_dir`` None / '' -> ``get_output_dir(db, mode='test')`` like the reference (:166), which ignores the argument.  Per frame everything stays on the device up to the
     per-class, max_dets-limited record (``detect_frame_device``); ranks exchange the fixed-size records with ONE
     all-gather per step (``collate.gather_records``), so every rank ends with the complete ``all_boxes``.
     LiDAR detections are converted from the voxel grid to metres (:223-224).  Writes ``detections.pkl`` like the
@@ -106,6 +163,10 @@ def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=F
     if draw_det:
         raise NotImplementedError("drawing is dataset tooling, outside the accelerated path")
     np.random.seed(cfg.RNG_SEED)
+    if ReferenceDb.wraps(db):
+        db = ReferenceDb(db)
+    if not out_dir:
+        out_dir = get_output_dir(db, mode='test')
     num_images, k = db.num_frames(mode), db.num_classes
     lidar = cfg.NET_TYPE == 'lidar'
     from ..nets.uncertainty import num_uncertainty_pos
@@ -121,11 +182,13 @@ def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=F
     # rows per class in the exchanged record: the max_dets cut keeps every detection that TIES with the max_dets-th best
     # score (lib/model/test.py:213-221), so a record of max_dets rows could truncate; one row per RoI cannot
     max_out = max(max_dets, int(cfg.TEST.RPN_POST_NMS_TOP_N)) if max_dets > 0 else int(cfg.TEST.RPN_POST_NMS_TOP_N)
+    infos = {}
     for s in range(steps):
         dets = torch.zeros((k, max_out, elem), dtype=torch.float32, device=dev)
         counts = torch.zeros((k,), dtype=torch.int32, device=dev)
         blobs = db.blobs_at(mine[s], mode) if s < len(mine) else None
         if blobs is not None and blobs.get('data') is not None:
+            infos[mine[s]] = blobs['info']
             dets, counts = detect_frame_device(net, blobs['data'], blobs['info'], thresh, max_dets, max_out)
         if distributed:
             rows = collate.unpack_records(collate.gather_records(collate.pack_record(dets, counts)), k, max_out, elem)
@@ -135,7 +198,10 @@ def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=F
             rows = [[d[j, :c[j]].copy() if j > 0 else np.empty((0, elem), np.float32) for j in range(k)]]
             frames_of_step = [(0, mine[s])] if s < len(mine) else []
         for r, i in frames_of_step:
-            info = db.blobs_at(i, mode)['info'] if lidar else None
+            info = None
+            if lidar:
+                # the voxel-grid geometry depends on cfg and the frame scale only: another rank's frame needs no reload
+                info = infos[i] if i in infos else minibatch.lidar_frame_geometry(cfg.TEST.SCALES[0])[2]
             for j in range(1, k):
                 cls_boxes = rows[r][j]
                 if lidar and cls_boxes.size:

@@ -56,7 +56,10 @@ class GradientBucket:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        # one extra element behind the gradients: the FAULT slot.  A rank that hits a fatal frame adds 1 to it; the slot
+        # rides in the same all-reduce, so every rank learns about it at the next optimizer step and all stop together
+        self.flat = torch.zeros(total + 1, dtype=torch.float32, device=dev)
+        self.fault = self.flat[total:]
         off = 0
         for p in self.params:
             if p.dtype != torch.float32 or p.device != dev:
@@ -68,10 +71,14 @@ class GradientBucket:
         self.flat.zero_()
 
     def all_reduce_mean(self, group=None):
-        """Average the accumulated gradients over the ranks (no-op for a single process)."""
+        """Average the accumulated gradients over the ranks (no-op for a single process).  Returns the number of faults
+        the ranks recorded since the last ``zero()``."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            faults = float(self.fault.item())
             self.flat.div_(dist.get_world_size(group))
+            return faults
+        return float(self.fault.item())
 
 
 class DataParallelOptimizer:
@@ -83,6 +90,7 @@ class DataParallelOptimizer:
         self.bucket = bucket
         self.group = group
         self._reduced = False
+        self._fault_text = None
 
     @property
     def param_groups(self):
@@ -93,8 +101,23 @@ class DataParallelOptimizer:
         the clip acts on the gradient of the whole N-GPU batch (the value that is stepped), as in the single-process
         reference, instead of on each rank's share."""
         if not self._reduced:
-            self.bucket.all_reduce_mean(self.group)
+            faults = self.bucket.all_reduce_mean(self.group)
             self._reduced = True
+            if faults > 0:
+                raise RuntimeError("a rank reported a fatal training frame (%d in this batch): %s"
+                                   % (int(round(faults)), self._fault_text or "see that rank's log"))
+
+    def _distributed(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def mark_fault(self, text=None):
+        """Record a fatal frame on this rank.  Returns True when the error is deferred to the next ``reduce()`` (data
+        parallel: all ranks raise there together), False when the caller should raise right away (single process)."""
+        if not self._distributed():
+            return False
+        self.bucket.fault.add_(1.0)
+        self._fault_text = text
+        return True
 
     def step(self):
         self.reduce()
@@ -174,7 +197,7 @@ class SolverWrapper:
         cur, perm = self.data_gen.get_pointer() if hasattr(self.data_gen, 'get_pointer') else (0, None)
         cur_val, perm_val = (self.data_gen_val.get_pointer() if hasattr(self.data_gen_val, 'get_pointer')
                              else (0, None))
-        return (np.random.get_state(), cur, perm, cur_val, perm_val)
+        return (np.random.get_state(), cur, perm, cur_val, perm_val, int(getattr(self.net, '_uc_calls', 0)))
 
     def _sync_batchnorm_statistics(self):
         """Replicas see different frames, so BatchNorm running statistics (LiDAR detector, FIXED_BLOCKS == -1) drift
@@ -200,12 +223,13 @@ class SolverWrapper:
         if self.rank == 0:
             os.makedirs(self.output_dir, exist_ok=True)
             torch.save(self.net.state_dict(), sfile)
-            st0, cur, perm, cur_val, perm_val = self._sampler_state()
+            mine = self._sampler_state()
+            st0, cur, perm, cur_val, perm_val = mine[:5]
             with open(nfile, 'wb') as fid:
                 for obj in (st0, cur, perm, cur_val, perm_val, it):
                     pickle.dump(obj, fid, pickle.HIGHEST_PROTOCOL)
-                if states is not None:
-                    pickle.dump(states, fid, pickle.HIGHEST_PROTOCOL)
+                # seventh object (not in the reference's file): per-rank state incl. the uncertainty heads' draw counter
+                pickle.dump(states if states is not None else [mine], fid, pickle.HIGHEST_PROTOCOL)
             self.log('Wrote snapshot to: %s' % sfile)
         if self._dist():
             dist.barrier()
@@ -222,7 +246,9 @@ class SolverWrapper:
             except EOFError:
                 states = None
         if states is not None and self.rank < len(states):
-            st0, cur, perm, cur_val, perm_val = states[self.rank]
+            st0, cur, perm, cur_val, perm_val = states[self.rank][:5]
+            if len(states[self.rank]) > 5 and hasattr(self.net, '_uc_calls'):
+                self.net._uc_calls = int(states[self.rank][5])      # the masks continue where the snapshot left them
         elif self._dist() and self.rank > 0:
             # a single-process snapshot resumed on several GPUs: decorrelate the replicas deterministically
             np.random.seed((cfg.RNG_SEED + 7919 * self.rank) % (2 ** 32))
@@ -247,7 +273,13 @@ class SolverWrapper:
         return len(sfiles), nfiles, sfiles
 
     def initialize(self):
-        """train_val.py:243-262 (pretrained weights are loaded by the caller through load_state_dict)."""
+        """train_val.py:243-262: a fresh run starts from ``pretrained_model`` when cfg.PRELOAD (backbone only) or
+        cfg.PRELOAD_FULL is set, else from the seeded initialisation."""
+        pretrained = getattr(self, 'pretrained_model', None)
+        if pretrained is not None and cfg.PRELOAD:
+            self.net.load_pretrained_cnn(torch.load(pretrained, map_location=self.net._device))
+        elif pretrained is not None and cfg.PRELOAD_FULL:
+            self.net.load_pretrained_full(torch.load(pretrained, map_location=self.net._device))
         return cfg.TRAIN.LEARNING_RATE, 0, list(cfg.TRAIN.STEPSIZE), [], []
 
     def restore(self, sfile, nfile):
@@ -321,3 +353,38 @@ class SolverWrapper:
         if last_snapshot_iter != it - 1:
             self.snapshot(it - 1)
         return losses
+
+
+class _PointerFrames:
+    """The two frame sources of ``train_net`` behind the iterator ``SolverWrapper`` pulls from."""
+
+    def __init__(self, gen):
+        self.gen = gen
+        self.next = gen.next
+        self.get_pointer = gen.get_pointer
+        self.set_pointer = gen.set_pointer
+
+
+def train_net(network, db, output_dir, tb_dir, pretrained_model=None, max_iters=40000, sum_size=128, val_sum_size=1000,
+              batch_size=16, val_batch_size=16, val_thresh=0.1, augment_en=True, val_augment_en=False):
+    """Reference entry point (lib/model/train_val.py:532-569; called at tools/trainval_net.py:~340): ``db.roidb`` /
+    ``db.val_roidb`` lists of roidb entries ('filename', 'boxes', 'gt_classes', 'ignore', optional 'boxes_dc'),
+    ``db.num_classes``.  ``tb_dir`` is accepted and unused (summaries are kept as (iter, name, value) tuples on the
+    solver instead of tensorboard events).  cfg.PRELOAD / cfg.PRELOAD_FULL load ``pretrained_model`` through the
+    detector's ``load_pretrained_cnn`` / ``load_pretrained_full`` like :249-253.  Returns the solver (losses in
+    ``solver.losses``)."""
+    from .data_layer_generator import data_layer_generator
+    frames = _PointerFrames(data_layer_generator('train', db.roidb, augment_en, db.num_classes))
+    val_roidb = getattr(db, 'val_roidb', None)
+    val_frames = (_PointerFrames(data_layer_generator('val', val_roidb, val_augment_en, db.num_classes))
+                  if val_roidb else None)
+    sw = SolverWrapper(network, db.num_classes, frames, val_frames, output_dir=output_dir, sum_size=sum_size,
+                       val_sum_size=val_sum_size if val_frames is not None else 0, epoch_size=len(db.roidb),
+                       batch_size=batch_size, val_batch_size=val_batch_size)
+    sw.val_thresh = val_thresh
+    if pretrained_model is not None and (cfg.PRELOAD or cfg.PRELOAD_FULL):
+        sw.pretrained_model = pretrained_model
+    print('Solving...')
+    sw.losses = sw.train_model(max_iters)
+    print('done solving')
+    return sw

@@ -40,9 +40,11 @@ from .autograd_ops import (conv_bn_act_train, det_loss_train, fused_head_train, 
 from .hip_modules import conv_bn_act, pad4, to_nchw_view, to_nhwc
 
 ROI_ALIGN_SAMPLING_RATIO = 0
+UC_SEED_RANK_STRIDE = 7919        # decorrelates the uncertainty heads' random draws across data-parallel ranks
 # FPN choices the missing network.py leaves open (DESIGN.md "reconstructed contract"):
 FPN_RPN_LEVEL = 0                 # the RPN runs on p2 only (_feat_stride = 4, lib/nets/imagenet.py:34)
 FPN_POOL_LEVELS = (2, 5)          # MultiScaleRoIAlign over p2..p5 (k_min, k_max of LevelMapper)
+NO_CANDIDATES = "proposal_target_layer: neither foreground nor background candidate RoIs in this frame"
 CUSTOM_TAIL_WIDTH = None          # t_fc1: P*P*C -> _fc7_channels, t_fc2 / t_fc3: _fc7_channels -> _fc7_channels
 
 
@@ -129,7 +131,11 @@ class Network(nn.Module):
         self._uc_seed, self._uc_calls = int(seed), 0
 
     def next_uc_seed(self):
-        s = (self._uc_seed + self._uc_calls) & 0xFFFFFFFF
+        """Seed of this forward's counter-based draws: base + 7919 * rank + forward count, so data-parallel replicas draw
+        different dropout masks / logit noise; ``_uc_calls`` travels in the solver's per-rank snapshot state."""
+        import torch.distributed as dist
+        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        s = (self._uc_seed + UC_SEED_RANK_STRIDE * rank + self._uc_calls) & 0xFFFFFFFF
         self._uc_calls += 1
         return s
 
@@ -495,14 +501,19 @@ class Network(nn.Module):
         optimizer steps only when ``update_weights`` (pseudo-batching, train_val.py:379-382).  Returns the loss."""
         self.forward(blobs['data'], blobs['info'], blobs['gt_boxes'], blobs.get('gt_boxes_dc'), mode='TRAIN')
         counts = self._proposal_targets.get('counts') if isinstance(self._proposal_targets, dict) else None
+        loss = self._losses['total_loss']
+        self.backward(loss)
+        # candidate counts are read AFTER the backward pass has been queued: the host wait overlaps the device work instead
+        # of stalling between forward and backward
         if counts is not None:
             n_fg, n_bg = [int(v) for v in counts[:2].cpu()]
             if n_fg + n_bg == 0:
                 # the reference stops here (pdb.set_trace, proposal_target_layer.py:232-235): no RoI is a foreground or
-                # a background candidate (all masked by IGNORE_DC, or every IoU outside both bands)
-                raise RuntimeError("proposal_target_layer: neither foreground nor background candidate RoIs in this frame")
-        loss = self._losses['total_loss']
-        self.backward(loss)
+                # a background candidate (all masked by IGNORE_DC, or every IoU outside both bands).  Data parallel: the
+                # fault is recorded in the gradient bucket and EVERY rank raises at the next all-reduce, so nobody is
+                # left waiting in the collective.
+                if not (hasattr(optimizer, 'mark_fault') and optimizer.mark_fault()):
+                    raise RuntimeError(NO_CANDIDATES)
         if update_weights:
             if hasattr(optimizer, 'reduce'):
                 optimizer.reduce()        # data parallel: average over the ranks first, clip the batch gradient after

@@ -33,7 +33,8 @@ from .hip_modules import pad4
 # ---- reconstruction constants (the missing network.py) ---------------------------------------------------------------
 UC_FC1_DIVISOR = 2                 # *_fc1: fc7 -> fc7 / 2; *_fc2: fc7 / 2 -> _det_net_channels (= fc7 / 4)
 CLS_VAR_IS_LOG = True              # cls_al_var_net predicts log-variances like the box head ("x = log(bbox_var)", test.py:82)
-E_BBOX_VAR_ON_DENORMALISED = True  # e_bbox_var = variance over the T passes of deltas * STDS + MEANS
+BBOX_VAR_ON_DENORMALISED = True    # both box variances describe deltas * STDS + MEANS (what bbox_transform_inv consumes):
+                                   # e_bbox_var = variance over the T passes, a_bbox_var = exp(log-variance) * STDS^2
 UNCERTAINTY_ORDER = ('a_entropy', 'a_mutual_info', 'a_cls_var', 'e_entropy', 'e_mutual_info', 'e_cls_var',
                      'a_bbox_var', 'e_bbox_var')     # filter_predictions.py:113-124
 # counter-based RNG streams (csrc/rng.h): one per stochastic module
@@ -200,10 +201,11 @@ def classify_test(net, fc7, rois):
     means = torch.tensor(cfg.TRAIN[key].BBOX_NORMALIZE_MEANS, dtype=torch.float32, device=fc7.device).repeat(k)
     if u.EN_BBOX_ALEATORIC:
         lv = _linear(feat_b, net.bbox_al_var_net).view(tb, r, k * e)
-        unc['a_bbox_var'] = ops.exp((ops.mc_mean(lv) if tb > 1 else lv[0]).contiguous())
+        a_var = ops.exp((ops.mc_mean(lv) if tb > 1 else lv[0]).contiguous())
+        unc['a_bbox_var'] = a_var * stds * stds if BBOX_VAR_ON_DENORMALISED else a_var
     if u.EN_BBOX_EPISTEMIC:
         var = ops.mc_bbox_var(box_s.contiguous()) if tb > 1 else torch.zeros((r, k * e), dtype=torch.float32, device=fc7.device)
-        unc['e_bbox_var'] = var * stds * stds if E_BBOX_VAR_ON_DENORMALISED else var
+        unc['e_bbox_var'] = var * stds * stds if BBOX_VAR_ON_DENORMALISED else var
     deltas = (bbox_pred * stds + means).contiguous()
     if lidar:
         pred_boxes = ops.lidar_bbox_transform_inv(rois[:, 1:5].contiguous(), net._predictions['roi_anchors_3d'], deltas,

@@ -778,6 +778,34 @@ def bbox_overlaps(boxes, query_boxes):
     return out
 
 
+def bbox_transform(ex_rois, gt_rois):
+    """Row-wise regression targets (N,4) of gt_rois (N, >=4) against ex_rois (N, >=4) (bbox_transform.py:52-70)."""
+    lib = _hip.load()
+    _dev_f32(ex_rois, "ex_rois"); _dev_f32(gt_rois, "gt_rois")
+    n = ex_rois.shape[0]
+    if gt_rois.shape[0] != n:
+        raise _hip.HipError("bbox_transform: %d ex_rois vs %d gt_rois" % (n, gt_rois.shape[0]))
+    out = torch.empty((n, 4), dtype=torch.float32, device=ex_rois.device)
+    if n:
+        _hip.check(lib.frcnn_bbox_transform(_ptr(ex_rois), ex_rois.shape[1], _ptr(gt_rois), gt_rois.shape[1], n, _ptr(out),
+                                            _stream()), "frcnn_bbox_transform")
+    return out
+
+
+def lidar_bbox_transform(ex_rois, ex_anchors_3d, gt_rois):
+    """Row-wise 7-DoF regression targets (N,7) (bbox_transform.py:16-49)."""
+    lib = _hip.load()
+    _dev_f32(ex_rois, "ex_rois"); _dev_f32(ex_anchors_3d, "ex_anchors_3d"); _dev_f32(gt_rois, "gt_rois")
+    n = ex_rois.shape[0]
+    if gt_rois.shape[0] != n or ex_anchors_3d.shape[0] != n or ex_anchors_3d.shape[1] != 7:
+        raise _hip.HipError("lidar_bbox_transform: row counts / anchor width do not match")
+    out = torch.empty((n, 7), dtype=torch.float32, device=ex_rois.device)
+    if n:
+        _hip.check(lib.frcnn_lidar_bbox_transform(_ptr(ex_rois), ex_rois.shape[1], _ptr(ex_anchors_3d), _ptr(gt_rois),
+                                                  gt_rois.shape[1], n, _ptr(out), _stream()), "frcnn_lidar_bbox_transform")
+    return out
+
+
 def anchor_target_layer(anchors, gt_boxes, info, rpn_batchsize, fg_fraction, neg_ov, pos_ov, seed):
     """Returns labels (N,), targets/inside/outside (N,4) in anchor order and counts (2,) int32 [fg, bg candidates]."""
     lib = _hip.load()

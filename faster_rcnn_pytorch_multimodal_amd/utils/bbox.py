@@ -25,3 +25,28 @@ def bbaa_graphics_gems(bboxes, width=0, height=0, clip=False):
         out[:, 0::2] = np.clip(out[:, 0::2], 0, width - 1)
         out[:, 1::2] = np.clip(out[:, 1::2], 0, height - 1)
     return out
+
+
+def bbox_overlaps(boxes, query_boxes):
+    """(N,4) x (K,4) device tensors -> (N,K) IoU with the +1 area convention.  lib/utils/bbox.py:5-33."""
+    from .. import ops
+    return ops.bbox_overlaps(boxes.contiguous(), query_boxes.contiguous())
+
+
+def bbox_pc_to_voxel_grid(bboxes, bev_extents, info):
+    """lib/utils/bbox.py:113-125: metric [xc,yc,zc,l,w,h,ry] rows -> voxel-grid units of the UNSCALED frame, in place."""
+    scale = info[6]
+    s_info = np.asarray(info[0:6]) * 1 / scale
+    kx = (s_info[1] - s_info[0]) / (bev_extents[3] - bev_extents[0])
+    ky = (s_info[3] - s_info[2]) / (bev_extents[4] - bev_extents[1])
+    bboxes[:, 0] = (bboxes[:, 0] - bev_extents[0]) * kx
+    bboxes[:, 1] = (bboxes[:, 1] - bev_extents[1]) * ky
+    bboxes[:, 3] = bboxes[:, 3] * kx
+    bboxes[:, 4] = bboxes[:, 4] * ky
+    return bboxes
+
+
+def bbox_voxel_grid_to_pc(bboxes, bev_extents, info):
+    """lib/utils/bbox.py:140-162, the inverse (host copy of the detections, lib/model/test.py:223-224)."""
+    from ..model.test import bbox_voxel_grid_to_pc as impl
+    return impl(bboxes, bev_extents, info)

@@ -354,6 +354,17 @@ int frcnn_det_loss(const float* cls_score, const float* labels, int num_rois, in
 int frcnn_bbox_overlaps(const float* boxes, int box_ld, int n, const float* query, int query_ld, int k,
                         float* overlaps, void* stream);
 
+/* bbox_transform (lib/model/bbox_transform.py:52-70): regression targets of gt_rois against ex_rois, row by row
+ * (n rows of ex_ld / gt_ld floats, first 4 = [x1,y1,x2,y2]) -> targets (n,4) [dx,dy,dw,dh]; dx,dy over the box
+ * DIAGONAL, widths with the +1 convention. */
+int frcnn_bbox_transform(const float* ex_rois, int ex_ld, const float* gt_rois, int gt_ld, int n, float* targets,
+                         void* stream);
+
+/* lidar_3d_bbox_transform (lib/model/bbox_transform.py:16-49): ex_rois (n rows, first 4 = BEV [x1,y1,x2,y2]),
+ * ex_anchors_3d (n,7), gt_rois (n rows of gt_ld >= 7 floats [xc,yc,zc,l,w,h,ry]) -> targets (n,7). */
+int frcnn_lidar_bbox_transform(const float* ex_rois, int roi_ld, const float* ex_anchors_3d, const float* gt_rois,
+                               int gt_ld, int n, float* targets, void* stream);
+
 /* anchor_target_layer_torch (lib/layer_utils/anchor_target_layer.py:22-165; IGNORE_DC off, CLOBBER_POSITIVES off,
  * uniform example weights): anchors (n,4) in (H,W,A) order, gt_boxes (num_gt,5) [x1,y1,x2,y2,cls], info HOST
  * [x_min,x_max,y_min,y_max].  Outputs in anchor order: labels (n) in {-1,0,1}, targets/inside/outside (n,4);

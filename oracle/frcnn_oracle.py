@@ -937,7 +937,8 @@ class UcHeadsOracle(nn.Module):
         bbox_pred = box_s.mean(0)
         stds_t, means_t = torch.tensor(stds).repeat(k), torch.tensor(means).repeat(k)
         if f.get('EN_BBOX_ALEATORIC'):
-            unc['a_bbox_var'] = torch.exp(self.bbox_al_var_net(feat_b).view(tb, r, k * e).mean(0))
+            # both box variances in de-normalised delta units (BBOX_VAR_ON_DENORMALISED of the build, a named choice)
+            unc['a_bbox_var'] = torch.exp(self.bbox_al_var_net(feat_b).view(tb, r, k * e).mean(0)) * stds_t * stds_t
         if f.get('EN_BBOX_EPISTEMIC'):
             unc['e_bbox_var'] = (compute_bbox_var(box_s) if tb > 1 else torch.zeros_like(bbox_pred)) * stds_t * stds_t
         return cls_score, cls_prob, bbox_pred, bbox_pred * stds_t + means_t, {n: unc[n] for n in UNCERTAINTY_ORDER if n in unc}

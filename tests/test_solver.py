@@ -229,3 +229,82 @@ def test_data_parallel_resume_restores_each_ranks_own_sampler_state(tmp_path):
     assert torch.equal(r[0]["bn_mean"], r[1]["bn_mean"]) and torch.equal(r[0]["bn_mean"], r[0]["bn_mean_loaded"])
     # the clip acted on the averaged gradient: both ranks saw the same tensor and stepped to the same weights
     assert torch.equal(r[0]["clipped_input"], r[1]["clipped_input"]) and torch.equal(r[0]["weight"], r[1]["weight"])
+
+
+class _FaultyStubNet(_StubNet):
+    """Network.train_step's fatal-frame protocol: the frame is found bad AFTER its backward pass; single process raises at
+    once, data parallel records the fault in the gradient bucket and every rank raises at the next all-reduce."""
+
+    def __init__(self, bad_iteration):
+        super().__init__()
+        self.bad_iteration, self.it = bad_iteration, 0
+        self._uc_calls = 0
+
+    def train_step(self, blobs, optimizer, update_weights=False):
+        self.it += 1
+        self._uc_calls += 1
+        loss = ((self.lin(blobs["data"]) - blobs["y"]) ** 2).sum()
+        loss.backward()
+        if self.it == self.bad_iteration:
+            if not (hasattr(optimizer, "mark_fault") and optimizer.mark_fault("no candidates")):
+                raise RuntimeError("no candidates")
+        if update_weights:
+            optimizer.reduce()
+            optimizer.step()
+            optimizer.zero_grad()
+        return float(loss.item())
+
+
+def _dp_fault_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    C.reset_cfg()
+    C.cfg.NET_TYPE = "image"
+    C.cfg.TRAIN.SNAPSHOT_ITERS = 1000
+    net = _FaultyStubNet(bad_iteration=3 if rank == 1 else -1)        # only rank 1 meets the bad frame
+    solver = train_val.SolverWrapper(net, 2, _Frames(300 + rank), output_dir=os.path.join(out_dir, "snap"),
+                                     batch_size=2, sum_size=0, log=lambda *_: None)
+    try:
+        solver.train_model(8)
+        outcome = "finished"
+    except RuntimeError as err:
+        outcome = "raised at iteration %d: %s" % (net.it, err)
+    with open(os.path.join(out_dir, "fault%d.txt" % rank), "w") as f:
+        f.write(outcome)
+    dist.destroy_process_group()
+
+
+def test_data_parallel_fatal_frame_stops_every_rank_together(tmp_path):
+    """a frame without candidate RoIs raised on ONE rank and left the others blocked in the gradient
+    all-reduce.  Now the fault travels in the bucket: both ranks raise at the optimizer step that follows (iteration 4)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_fault_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [open(tmp_path / ("fault%d.txt" % r)).read() for r in range(2)]
+    assert all(g.startswith("raised at iteration 4: a rank reported a fatal training frame (1 in this batch)") for g in got), got
+    # single process: the same frame raises immediately
+    C.reset_cfg()
+    C.cfg.NET_TYPE = "image"
+    net = _FaultyStubNet(bad_iteration=3)
+    solver = train_val.SolverWrapper(net, 2, _Frames(1), output_dir=str(tmp_path / "single"), batch_size=2, sum_size=0,
+                                     log=lambda *_: None)
+    with pytest.raises(RuntimeError, match="no candidates"):
+        solver.train_model(8)
+    assert net.it == 3
+    C.reset_cfg()
+
+
+def test_snapshot_carries_the_uncertainty_draw_counter(cfg_solver, tmp_path):
+    """the counter behind the uncertainty heads' random draws (Network._uc_calls) is part of the per-rank
+    snapshot state, so a resumed run continues the mask sequence instead of replaying it from step 0."""
+    net = _FaultyStubNet(bad_iteration=-1)
+    solver = train_val.SolverWrapper(net, 2, _Frames(0), output_dir=str(tmp_path), batch_size=4, sum_size=0, log=lambda *_: None)
+    solver.train_model(5)
+    assert net._uc_calls == 5
+    net2 = _FaultyStubNet(bad_iteration=-1)
+    solver2 = train_val.SolverWrapper(net2, 2, _Frames(0), output_dir=str(tmp_path), batch_size=4, sum_size=0,
+                                      log=lambda *_: None)
+    assert solver2.train_model(5) == [] and net2._uc_calls == 5
