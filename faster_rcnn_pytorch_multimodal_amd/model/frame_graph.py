@@ -76,8 +76,11 @@ class FrameRunner:
         self.predictions = self.net._predictions     # this runner's (graph-private) intermediate tensors
         return out
 
-    def run(self, frame, rpn=None):
-        """frame: (1,H,W,C) float32 device tensor (or numpy blob, copied host->device)."""
+    def run(self, frame, rpn=None, poison=False):
+        """frame: (1,H,W,C) float32 tensor - device, or (pinned) host memory: the copy into the graph's input buffer is then
+        the asynchronous host->device upload on the current stream - or a numpy blob.
+        ``poison``: overwrite the graph's output buffers (NaN detections, -1 counts) before the replay, so that a replay
+        which did not execute cannot leave a plausible record behind (bench.py's verification)."""
         if isinstance(frame, np.ndarray):
             frame = torch.from_numpy(frame)
         self.static_in.copy_(frame, non_blocking=True)
@@ -86,6 +89,9 @@ class FrameRunner:
                 raise ValueError("this runner was built with an RPN override buffer: run(frame, rpn=...)")
             self.static_rpn.copy_(rpn, non_blocking=True)
         if self.graph is not None:
+            if poison:
+                self.out[0].fill_(float('nan'))
+                self.out[1].fill_(-1)
             self.graph.replay()
         else:
             self.out = self._frame()

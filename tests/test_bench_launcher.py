@@ -8,6 +8,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
@@ -20,8 +22,12 @@ def _run(args, env_extra=None, timeout=300):
                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
 
 
-def test_gpus_2_self_launches_and_collates_over_gloo():
-    res = _run(["--gpus", "2", "--steps", "6", "--warmup", "2", "--rehearse-collate"])
+@pytest.mark.parametrize("gather_every", [1, 4])
+def test_gpus_2_self_launches_and_collates_over_gloo(gather_every):
+    """Records are collated in blocks of `gather_every` frames (one all-gather per block, a partial last block included);
+    the verification inside bench.py requires step i, row r of what arrived on the host to be rank r's record of ITS
+    i-th frame - collated order = frame order of the sharded loop - for both block sizes."""
+    res = _run(["--gpus", "2", "--steps", "6", "--warmup", "2", "--rehearse-collate", "--gather-every", str(gather_every)])
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout                      # rank 0 only
@@ -37,8 +43,10 @@ def test_gpus_2_self_launches_and_collates_over_gloo():
     col = out["collective"]
     assert col["ranks"] == 2 and col["backend"] == "gloo" and col["is_rccl"] is False and col["self_launched"] is True
     assert len(col["per_rank_frames_per_s"]) == 2
+    assert col["gather_every_frames"] == gather_every and col["allgathers_per_region"] == -(-6 // gather_every)
     ver = out["verification"]
     assert ver["equal_to_eager_path"] is True and ver["timed_steps_checked"] == 6
+    assert ver["distinct_expected_records"] == ver["distinct_frames_per_rank"] >= 2
 
 
 def test_world_size_mismatch_is_rejected():

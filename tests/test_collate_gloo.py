@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -134,3 +135,34 @@ def test_test_net_eval_loop_world2_gloo(tmp_path):
     lines = open(tmp_path / "eval" / "det_test_cls1.txt").read().splitlines()
     assert len(lines) == sum(int(_fake_frame(i)[1][1]) for i in range(FRAMES) if i != 3)
     assert all(l.split(" ")[1].startswith("frame") for l in lines)
+
+
+def _ring_worker(rank, world, port, out_dir, every):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    numel, steps = 7, 11
+    ring = collate.RecordRing(numel, steps, every=every, device="cpu")
+    for i in range(steps):
+        ring.slot(i).copy_(torch.arange(numel, dtype=torch.float32) + 100.0 * (rank + world * i))   # global frame id
+        ring.commit(i)
+    host = ring.drain().clone()
+    torch.save((host, ring.gathers), os.path.join(out_dir, "ring%d_%d.pt" % (every, rank)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("every", [1, 4])
+def test_record_ring_collates_blocks_in_frame_order(tmp_path, every):
+    """RecordRing over gloo, world 2: one all-gather per block of `every` frames (the partial last block too), and the host
+    matrix reads step i, row r = global frame r + 2*i - the order lib/model/test.py:183's loop visits the frames in."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_ring_worker, args=(2, port, str(tmp_path), every), nprocs=2, join=True)
+    got = [torch.load(os.path.join(str(tmp_path), "ring%d_%d.pt" % (every, r))) for r in range(2)]
+    assert torch.equal(got[0][0], got[1][0]) and got[0][0].shape == (11, 2, 7)
+    assert got[0][1] == -(-11 // every)
+    frame_ids = (got[0][0][:, :, 0] / 100.0).round().long()
+    assert frame_ids.reshape(-1).tolist() == list(range(22))
