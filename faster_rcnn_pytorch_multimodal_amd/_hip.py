@@ -51,13 +51,15 @@ PROTOTYPES = {
     "frcnn_sort_topk_desc_ws_bytes": (c_size_t, [c_int, c_int]),
     "frcnn_sort_topk_desc": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "frcnn_gather_rows": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
+    "frcnn_nms_set_suppress_at_equal": (c_int, [c_int]),
+    "frcnn_nms_get_suppress_at_equal": (c_int, []),
     "frcnn_nms_ws_bytes": (c_size_t, [c_int]),
     "frcnn_nms": (c_int, [_P, _P, c_int, c_float, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "frcnn_make_rois": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P]),
     "frcnn_roi_align_set_variant": (c_int, [c_int]),
     "frcnn_roi_align_fwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "frcnn_roi_align_fwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_float, c_int, _P, c_int, _P, _P, c_size_t,
-                                    _P]),
+    "frcnn_roi_align_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_float, c_int, _P, c_int, _P,
+                                    _P, c_size_t, _P]),
     "frcnn_fpn_level_map": (c_int, [_P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P]),
     "frcnn_head_fc_softmax_decode": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, POINTER(c_float),
                                              POINTER(c_float), c_float, _P, _P, _P, _P, _P, _P]),

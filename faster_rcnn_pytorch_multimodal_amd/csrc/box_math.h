@@ -51,15 +51,13 @@ __device__ __forceinline__ void decode_box_lidar(float x1, float y1, float x2, f
 // torch.clamp(v, lo, hi) = min(max(v, lo), hi)
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
-// NAMED CHOICE: what happens when IoU == threshold exactly.  torchvision 0.4.0 (req.txt:283) is
-// not vendored; to the builders' knowledge its CUDA kernel suppresses on `iou > threshold` while its CPU kernel of that
-// release used `>=` (the two were unified on `>` later).  The reference runs its detectors on the GPU whenever one is
-// present (tools/test_net.py:286-288 falls back to 'cpu' only without CUDA), so the device path, the oracle
-// (oracle/frcnn_oracle.py NMS_SUPPRESS_AT_EQUAL) and every fixture follow the strict form.  Flip both constants together;
-// tests/test_gpu_parity.py::test_nms_threshold_edge documents the behaviour.
-constexpr bool NMS_SUPPRESS_AT_EQUAL = false;
+// What happens when IoU == threshold exactly is a RUN-TIME choice (frcnn_nms_set_suppress_at_equal, csrc/boxes.hip; DESIGN.md
+// section 1): torchvision 0.4.0 (req.txt:283, not vendored) suppresses on `iou >= threshold` in its CPU kernel and on
+// `iou > threshold` in its CUDA kernel.  The default follows the CPU kernel - the path the reference is compared against.
+// The kernels below always test `iou > t`; for the inclusive form the entry points hand them t = nextafterf(threshold, -inf):
+// no float lies strictly between the two, so `iou > t` IS `iou >= threshold`, bit for bit, NaN included (both false).
 
-// IoU test of torchvision.ops.nms: areas (x2-x1)*(y2-y1) without +1, suppress when iou > thresh.
+// IoU test of torchvision.ops.nms: areas (x2-x1)*(y2-y1) without +1, suppress when iou > thresh (see above).
 __device__ __forceinline__ bool iou_gt(const float* a, const float* b, float thresh) {
   const float xx1 = fmaxf(a[0], b[0]), yy1 = fmaxf(a[1], b[1]);
   const float xx2 = fminf(a[2], b[2]), yy2 = fminf(a[3], b[3]);
@@ -68,7 +66,7 @@ __device__ __forceinline__ bool iou_gt(const float* a, const float* b, float thr
   const float sa = (a[2] - a[0]) * (a[3] - a[1]);
   const float sb = (b[2] - b[0]) * (b[3] - b[1]);
   const float iou = inter / (sa + sb - inter);
-  return NMS_SUPPRESS_AT_EQUAL ? iou >= thresh : iou > thresh;
+  return iou > thresh;
 }
 
 // The same predicate, bit for bit, with the IEEE division (~25 instructions) taken only near the threshold: inter against
@@ -89,7 +87,7 @@ __device__ __forceinline__ bool iou_gt_lazy_div(const float* a, const float* b, 
   bool hit = sure_yes;
   if (!(uni > 0.f) || !(sure_yes || sure_no)) {   // rarely taken (skipped when no lane of the wave needs it)
     const float iou = inter / uni;
-    hit = NMS_SUPPRESS_AT_EQUAL ? iou >= thresh : iou > thresh;
+    hit = iou > thresh;
   }
   return hit;
 }

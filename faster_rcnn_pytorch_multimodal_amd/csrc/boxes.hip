@@ -1170,6 +1170,18 @@ extern "C" int frcnn_gather_rows(const float* rows, const int64_t* order, const 
   return check_launch("gather_rows_kernel");
 }
 
+// IoU == threshold: 1 = the box is suppressed (torchvision 0.4.0's CPU kernel, `>=`; default), 0 = it survives (its CUDA
+// kernel, `>`).  Read at launch time; a captured hipGraph keeps the setting it was captured under.
+static std::atomic<int> g_nms_at_equal{1};
+extern "C" int frcnn_nms_set_suppress_at_equal(int on) {
+  g_nms_at_equal.store(on ? 1 : 0);
+  return FRCNN_OK;
+}
+extern "C" int frcnn_nms_get_suppress_at_equal(void) { return g_nms_at_equal.load(); }
+static inline float nms_kernel_thresh(float thresh) {
+  return g_nms_at_equal.load() ? nextafterf(thresh, -INFINITY) : thresh;   // `iou > t` then means `iou >= thresh`
+}
+
 extern "C" size_t frcnn_nms_ws_bytes(int n_max) {
   if (n_max <= 0) return 0;
   const size_t nb = (size_t)(n_max + 63) / 64;
@@ -1191,7 +1203,8 @@ extern "C" int frcnn_nms(const float* boxes, const int* n_dev, int n_max, float 
     hipError_t e = hipMemsetAsync(keep_mask, 0, (size_t)n_max, stream);
     if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "nms: memset: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(nb * (nb + 1) / 2), dim3(64), 0, stream, boxes, n_dev, n_max, nb, thresh, mask, diag_t);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(nb * (nb + 1) / 2), dim3(64), 0, stream, boxes, n_dev, n_max, nb,
+                     nms_kernel_thresh(thresh), mask, diag_t);
   int rc = check_launch("nms_mask_kernel");
   if (rc != FRCNN_OK) return rc;
   hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64 * SCAN_WAVES), 0, stream, (const uint64_t*)mask,
@@ -1235,6 +1248,7 @@ static int launch_filter(float* pred_boxes, const float* cls_prob, const int* ro
   FRCNN_REQUIRE(num_rois <= 8192, "filter_per_class: num_rois %d > 8192", num_rois);
   const size_t need = frcnn_filter_per_class_ws_bytes(num_rois, num_classes);
   if (!ws || ws_bytes < need) return fail(FRCNN_ERR_WS, "filter_per_class: workspace %zu < %zu bytes", ws_bytes, need);
+  nms_thresh = nms_kernel_thresh(nms_thresh);
   if (E == 4) {
     // frame_width/scale - 1 evaluated in fp32 like the numpy float32 scalars of filter_predictions.py:77-91
     const float x_hi = frame_w / scale - 1.0f, y_hi = frame_h / scale - 1.0f;

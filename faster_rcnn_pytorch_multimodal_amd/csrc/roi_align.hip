@@ -10,6 +10,8 @@
 #include "common.h"
 
 #include <algorithm>
+#include <atomic>
+#include <type_traits>
 
 namespace {
 
@@ -451,6 +453,304 @@ __global__ __launch_bounds__(256) void roi_align_fwd_planned(const float* __rest
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Map-resident form — the fastest path (P == 7, the map slice fits the LDS).
+//
+// What bounded the planned pair above: every RoI reads its own window through the vector L1 (326 MB per launch for the
+// 300 RoIs of a 1000x600 frame against a 9.8 MB map), one dependent load chain per work item, a static schedule, and a
+// separate plan launch (6.3 us).  Here a workgroup keeps the WHOLE feature map for 16 channels in LDS (38 x 63 pixels x
+// 64 B = 150 KB of the CU's 160 KB) and pools every RoI of its share from there: the map leaves L2 once per workgroup
+// (4 workgroups share a slice), all window re-reads are LDS reads (256 B/clk/CU instead of 64 B/clk through the L1), the
+// plan is built per RoI pair by the consuming wave, and RoI pairs are dealt dynamically from an LDS counter.
+//
+//   grid    (C/16 channel slices x G RoI groups, images); workgroup = 8 waves.  Slices that share 128-byte output lines
+//           sit on the same XCD (speed only).
+//   phase 1 the slice is copied global -> LDS with LDS-DMA (global_load_lds_dwordx4: 16 pixels x 64 B per wave
+//           instruction), pixel s stored at slot s ^ swz(s >> 2) (a permutation inside each group of 4 slots, so that
+//           the pixels 4 lane groups read together do not all sit in the same quarter of the banks).
+//   phase 2 a wave takes a PAIR of RoIs (one per half wave).  14 of its 16 four-lane groups are (RoI, column bin pw)
+//           tasks: lane q of a group owns channels 4q..4q+3, a group reads one pixel = 64 B per ds_read_b128.
+//           tables: lanes evaluate the samples of a bin in parallel (the library's coordinate arithmetic) and add their
+//           weights into compact per-bin tables in LDS (ds_add_f32 after a zero store; one wave = program order).
+//           pooling: rows of the window ascending; inside a row the columns of bin pw ascending:
+//           rowsum = sum_x Wx[pw][x] F[y][x]; then acc[ph] += Wy[ph][y] * rowsum for the 7 row bins (Wy dense over the
+//           window rows, one lane per row, broadcast with v_readlane).  Each map pixel of a bin column range is read once
+//           per (RoI, pw), whatever the number of row bins it feeds.
+//           A RoI whose bin ranges exceed the compact tables (RoIs far larger than the map) is pooled sample by sample
+//           from the LDS map (same arithmetic as the generic kernel).
+// Output: 64-byte segments (16 channels of a bin), the fabric's request size.
+// ------------------------------------------------------------------------------------------------
+constexpr int RES_WAVES = 8;
+constexpr int RES_FX = 11;        // columns a column bin may touch (map width <= 63: bin <= 9 px -> 11 pixels)
+constexpr int RES_FY = 8;         // rows a row bin may touch
+struct ResRoiTab {
+  float wx[PLAN_P][RES_FX];
+  float wy[PLAN_P][RES_FY];
+  short xlo[PLAN_P], ylo[PLAN_P];
+  unsigned char xcnt[PLAN_P], ycnt[PLAN_P];
+  short pad[1];
+};
+static_assert(sizeof(ResRoiTab) % 16 == 0, "table block keeps 16-byte alignment");
+
+__host__ __device__ inline size_t res_map_bytes(int h, int w) { return (size_t)h * w * 64; }
+__host__ __device__ inline size_t res_lds_bytes(int h, int w) {
+  // the tail of the last 1 KB DMA chunk (up to 15 pixel slots past the map) overlaps the table area, which is first
+  // written after the barrier that ends phase 1
+  return frcnn::align_up(res_map_bytes(h, w), 16) + (size_t)RES_WAVES * 2 * sizeof(ResRoiTab) + 16;
+}
+
+// Column x of a row is stored at column x ^ h(x >> 2) of the same row (h in 0..3: a permutation inside each aligned
+// group of 4 columns, an involution; the last, partial group of a row keeps its order).  The four tasks a ds_read_b128
+// serves together are column bins of ONE RoI in ONE row; frame-wide RoIs have bins ~8 px wide, so without the
+// permutation their first columns all fall into the same quarter of the banks (4-way conflict).
+__device__ __forceinline__ int res_col(int x, int W) {
+  const int t = x >> 2;
+  return x < (W & ~3) ? x ^ ((t ^ (t >> 1)) & 3) : x;
+}
+
+__global__ __launch_bounds__(64 * RES_WAVES) void roi_align_fwd_resident(
+    const float* __restrict__ feat, int H, int W, int C, const float* __restrict__ rois, const int* __restrict__ roi_count,
+    int num_rois, int rois_per_image, float spatial_scale, int sampling_ratio, const int* __restrict__ level_of_roi,
+    int level, int nslices, int ngroups, float* __restrict__ out, int dbg) {
+  constexpr int P = PLAN_P;
+  extern __shared__ __attribute__((aligned(16))) unsigned char res_smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int img = blockIdx.y;
+  // (slice, group) of this workgroup: with nslices % 8 == 0 XCD x (= blockIdx.x % 8) owns slices [x*nslices/8, ...)
+  int slice, group;
+  if ((nslices & 7) == 0) {
+    const int per_xcd = nslices >> 3, k = blockIdx.x >> 3;
+    slice = (blockIdx.x & 7) * per_xcd + k % per_xcd;
+    group = k / per_xcd;
+  } else {
+    slice = blockIdx.x % nslices;
+    group = blockIdx.x / nslices;
+  }
+  const int npix = H * W;
+  float* smap = reinterpret_cast<float*>(res_smem);
+  unsigned char* tab_area = res_smem + frcnn::align_up(res_map_bytes(H, W), 16);
+  int* counter = reinterpret_cast<int*>(tab_area + (size_t)RES_WAVES * 2 * sizeof(ResRoiTab));
+  if (threadIdx.x == 0) *counter = 0;
+
+  // ---- phase 1: map slice -> LDS ---------------------------------------------------------------------------
+  {
+    const float* fimg = feat + (size_t)img * npix * C + slice * 16 + (lane & 3) * 4;
+    const int nchunks = (dbg & 1) ? 0 : (npix + 15) >> 4;
+    for (int c = wave; c < nchunks; c += RES_WAVES) {
+      const int slot = min(c * 16 + (lane >> 2), npix - 1);   // slots past the map repeat the last pixel (never read)
+      const int sy = slot / W, sx = slot - sy * W;
+      const int s = sy * W + res_col(sx, W);
+      typedef const __attribute__((address_space(1))) void* gptr;
+      typedef __attribute__((address_space(3))) void* lptr;
+      __builtin_amdgcn_global_load_lds((gptr)(fimg + (size_t)s * C), (lptr)(smap + (size_t)c * 256), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+
+  // ---- phase 2 -----------------------------------------------------------------------------------------------
+  const int half = lane >> 5, sub = lane & 31;
+  const int pw = (lane >> 2) & 7, q = lane & 3;
+  const bool slot_live = pw < P;
+  const int pwc = min(pw, P - 1);
+  const int r_first = rois_per_image > 0 ? img * rois_per_image : 0;
+  const int r_end = rois_per_image > 0 ? min(num_rois, r_first + rois_per_image) : num_rois;
+  const int live_n = roi_count ? min(roi_count[rois_per_image > 0 ? img : 0], r_end - r_first) : r_end - r_first;
+  const int n_mine = (r_end - r_first - group + ngroups - 1) / ngroups;       // RoIs r_first + group + ngroups * k
+  const int npairs = (max(n_mine, 0) + 1) >> 1;
+  ResRoiTab* tabs = reinterpret_cast<ResRoiTab*>(tab_area) + wave * 2;
+  ResRoiTab* T = tabs + half;
+  const int C4 = C >> 2;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool is_x = sub < 16;
+  const int si = sub & 15;                                    // sample index of this lane in the table passes
+
+  for (;;) {
+    int p = 0;
+    if (lane == 0) p = atomicAdd(counter, 1);
+    p = __builtin_amdgcn_readfirstlane(p);
+    if (p >= npairs) break;
+    // ---- RoI of this half wave ----
+    const int k = 2 * p + half;
+    const int r = r_first + group + ngroups * k;
+    enum { ST_SKIP = 0, ST_TABLE = 1, ST_ZERO = 2, ST_DIRECT = 3 };
+    int state = ST_SKIP;
+    float rsw = 0.f, rsh = 0.f, bw = 1.f, bh = 1.f, inv_count = 0.f;
+    int gw = 0, gh = 0;
+    if (k < n_mine) {
+      const float* roi = rois + (size_t)r * 5;
+      const bool lvl_ok = !level_of_roi || level_of_roi[r] == level;
+      const bool dead = (r - r_first) >= live_n;
+      const int bimg = (int)roi[0];
+      if (lvl_ok && dead) state = (img == 0 || rois_per_image > 0) ? ST_ZERO : ST_SKIP;
+      else if (lvl_ok && (rois_per_image > 0 || bimg == img)) {
+        state = ST_TABLE;
+        rsw = roi[1] * spatial_scale; rsh = roi[2] * spatial_scale;
+        const float rew = roi[3] * spatial_scale, reh = roi[4] * spatial_scale;
+        const float roi_width = fmaxf(rew - rsw, 1.0f), roi_height = fmaxf(reh - rsh, 1.0f);
+        bh = roi_height / (float)P; bw = roi_width / (float)P;
+        gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)P);
+        gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)P);
+        inv_count = 1.0f / (float)(gh * gw);
+        if (gw > 16 || gh > 16) state = ST_DIRECT;
+      }
+    }
+    if (__ballot(state != ST_SKIP) == 0ull) continue;
+
+    // ---- compact weight tables: pass t builds column bin t (lanes sub 0..15 = samples) and row bin t (sub 16..31) ----
+    if (!(dbg & 2)) {
+      const float start = is_x ? rsw : rsh, bin = is_x ? bw : bh;
+      const int grid = is_x ? gw : gh, size = is_x ? W : H, cap = is_x ? RES_FX : RES_FY;
+      bool over = false;
+#pragma unroll 1
+      for (int t = 0; t < P; ++t) {
+        int lo = 0, hi = 0;
+        float wl = 0.f, wh = 0.f;
+        bool valid = false;
+        if (state == ST_TABLE && si < grid) valid = axis_sample_pt(start, bin, t, si, grid, size, lo, hi, wl, wh);
+        const unsigned long long m = __ballot(valid);
+        const unsigned f = (unsigned)(m >> (lane & 48)) & 0xFFFFu;       // the 16 lanes of my (RoI, axis)
+        const int first = f ? __builtin_ctz(f) : 0, last = f ? 31 - __builtin_clz(f) : 0;
+        // sample coordinates are non-decreasing: the first valid sample has the smallest pixel, the last the largest
+        const int lo_first = __shfl(lo, (lane & 48) + first), hi_last = __shfl(hi, (lane & 48) + last);
+        const int cnt = f ? hi_last - lo_first + 1 : 0;
+        over = over || cnt > cap;
+        float* row = is_x ? T->wx[t] : T->wy[t];
+        if (si < cap) row[si] = 0.f;
+        if (si == 0) {
+          (is_x ? T->xlo : T->ylo)[t] = (short)lo_first;
+          (is_x ? T->xcnt : T->ycnt)[t] = (short)min(cnt, cap);
+        }
+        if (valid && cnt <= cap) {
+          atomicAdd(&row[lo - lo_first], wl);                 // ds_add_f32: same-wave LDS operations stay in order
+          atomicAdd(&row[hi - lo_first], wh);
+        }
+      }
+      // a bin that does not fit the compact tables sends its whole RoI to the sample-by-sample path
+      const unsigned long long mo = __ballot(over);
+      if (state == ST_TABLE && ((mo >> (lane & 32)) & 0xFFFFFFFFull) != 0ull) state = ST_DIRECT;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    f32x2 acc[P][2];
+#pragma unroll
+    for (int ph = 0; ph < P; ++ph) acc[ph][0] = acc[ph][1] = f32x2{0.f, 0.f};
+
+    // ---- table path ----
+    if (!(dbg & 8) && __ballot(state == ST_TABLE) != 0ull) {
+      // window rows of my RoI and the dense row-weight registers: lane l = row y0 + l
+      int y0 = H, y1 = -1;
+#pragma unroll
+      for (int ph = 0; ph < P; ++ph) {
+        const int c = T->ycnt[ph], l = T->ylo[ph];
+        if (c > 0) { y0 = min(y0, l); y1 = max(y1, l + c - 1); }
+      }
+      const bool tab = state == ST_TABLE;
+      const int nrows = tab && y1 >= y0 ? y1 - y0 + 1 : 0;
+      const int y0a = __builtin_amdgcn_readlane(y0, 0), y0b = __builtin_amdgcn_readlane(y0, 32);
+      float ta[P], tb[P];
+#pragma unroll
+      for (int ph = 0; ph < P; ++ph) {
+        const int ka = lane - ((int)tabs[0].ylo[ph] - y0a), kb = lane - ((int)tabs[1].ylo[ph] - y0b);
+        ta[ph] = (ka >= 0 && ka < (int)tabs[0].ycnt[ph]) ? tabs[0].wy[ph][ka] : 0.f;
+        tb[ph] = (kb >= 0 && kb < (int)tabs[1].ycnt[ph]) ? tabs[1].wy[ph][kb] : 0.f;
+      }
+      const int my_xlo = T->xlo[pwc];
+      const int my_xcnt = (tab && slot_live) ? (int)T->xcnt[pwc] : 0;
+      // per column of my bin: weight and LDS byte offset inside a row (q-th 16 bytes of the pixel).  Columns past the
+      // bin's range have weight 0 and repeat the last column's address, so the row loop needs no lane predicate.
+      float wxr[RES_FX];
+      int off[RES_FX];
+#pragma unroll
+      for (int j = 0; j < RES_FX; ++j) {
+        wxr[j] = j < my_xcnt ? T->wx[pwc][j] : 0.f;
+        const int x = my_xcnt > 0 ? my_xlo + min(j, my_xcnt - 1) : 0;
+        off[j] = res_col(x, W) * 64 + q * 16;
+      }
+      int cnt_max = my_xcnt, rows_max = nrows;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        cnt_max = max(cnt_max, __shfl_xor(cnt_max, o));
+        rows_max = max(rows_max, __shfl_xor(rows_max, o));
+      }
+      cnt_max = __builtin_amdgcn_readfirstlane(cnt_max);
+      rows_max = __builtin_amdgcn_readfirstlane(rows_max);
+      const int ybase = nrows > 0 ? y0 : 0;
+      const unsigned char* smap_b = reinterpret_cast<const unsigned char*>(smap);
+      auto rows = [&](auto nj_tag) {
+        constexpr int NJ = decltype(nj_tag)::value;
+        for (int i = 0; i < rows_max; ++i) {
+          // a half wave whose window is shorter re-reads its last row; the row weights past its window are zero
+          const int rb = min(ybase + i, H - 1) * W * 64;
+          float4 v[NJ];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) v[j] = *reinterpret_cast<const float4*>(smap_b + rb + off[j]);
+          f32x2 r0 = {0.f, 0.f}, r1 = {0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const f32x2 w2 = {wxr[j], wxr[j]};
+            r0 = __builtin_elementwise_fma(w2, f32x2{v[j].x, v[j].y}, r0);
+            r1 = __builtin_elementwise_fma(w2, f32x2{v[j].z, v[j].w}, r1);
+          }
+#pragma unroll
+          for (int ph = 0; ph < P; ++ph) {
+            const float wa = lane_bcast(ta[ph], i), wb = lane_bcast(tb[ph], i);
+            const float wr = half ? wb : wa;
+            const f32x2 w2 = {wr, wr};
+            acc[ph][0] = __builtin_elementwise_fma(w2, r0, acc[ph][0]);
+            acc[ph][1] = __builtin_elementwise_fma(w2, r1, acc[ph][1]);
+          }
+        }
+      };
+      if (cnt_max <= 4) rows(std::integral_constant<int, 4>{});
+      else if (cnt_max <= 8) rows(std::integral_constant<int, 8>{});
+      else rows(std::integral_constant<int, RES_FX>{});
+    }
+
+    // ---- sample-by-sample path (bins too large for the tables) ----
+    if (__ballot(state == ST_DIRECT) != 0ull) {
+      if (state == ST_DIRECT && slot_live) {
+        for (int ph = 0; ph < P; ++ph) {
+          float4 a = zero4;
+          for (int iy = 0; iy < gh; ++iy) {
+            int yl, yh;
+            float hy, ly;
+            if (!axis_sample_pt(rsh, bh, ph, iy, gh, H, yl, yh, hy, ly)) continue;
+            for (int ix = 0; ix < gw; ++ix) {
+              int xl, xh;
+              float hx, lx;
+              if (!axis_sample_pt(rsw, bw, pw, ix, gw, W, xl, xh, hx, lx)) continue;
+              const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+              const float4 v1 = *reinterpret_cast<const float4*>(smap + (size_t)(yl * W + res_col(xl, W)) * 16 + q * 4);
+              const float4 v2 = *reinterpret_cast<const float4*>(smap + (size_t)(yl * W + res_col(xh, W)) * 16 + q * 4);
+              const float4 v3 = *reinterpret_cast<const float4*>(smap + (size_t)(yh * W + res_col(xl, W)) * 16 + q * 4);
+              const float4 v4 = *reinterpret_cast<const float4*>(smap + (size_t)(yh * W + res_col(xh, W)) * 16 + q * 4);
+              a.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
+              a.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+              a.z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
+              a.w += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+            }
+          }
+          // (dynamic ph: written through a switch-free select chain below would cost registers; store directly)
+          float4* ob = reinterpret_cast<float4*>(out) + ((size_t)(r * P + ph) * P + pw) * C4 + slice * 4 + q;
+          *ob = make_float4(a.x * inv_count, a.y * inv_count, a.z * inv_count, a.w * inv_count);
+        }
+      }
+    }
+
+    // ---- stores: bins (ph, pw) of my RoI, 16 channels = 64 B per four-lane group ----
+    if (!(dbg & 4) && slot_live && (state == ST_TABLE || state == ST_ZERO)) {
+      float4* ob = reinterpret_cast<float4*>(out) + ((size_t)r * P * P + pw) * C4 + slice * 4 + q;
+#pragma unroll
+      for (int ph = 0; ph < P; ++ph)
+        ob[(size_t)ph * P * C4] = make_float4(acc[ph][0][0] * inv_count, acc[ph][0][1] * inv_count,
+                                              acc[ph][1][0] * inv_count, acc[ph][1][1] * inv_count);
+    }
+  }
+}
+
 size_t plan_bytes(int h, int w, int c, int num_rois) {
   const int nslices = (c / 4 + 63) / 64;
   return sizeof(RoiPlanHead) + (size_t)num_rois * PLAN_P * nslices * sizeof(RoiItem) +
@@ -461,15 +761,24 @@ bool planned_ok(int pooled) { return pooled == PLAN_P; }
 
 }  // namespace
 
-// tuning hook: 0 = automatic (= 4), 1 = generic, 2 = generic with XCD channel slices, 3 / 4 = planned kernel with 8 / 4
-// loads in flight per lane (needs a workspace)
+// tuning hook: 0 = automatic (map-resident kernel when the map slice fits the LDS, else the planned pair), 1 = generic,
+// 2 = generic with XCD channel slices, 3 / 4 = planned kernel with 8 / 4 loads in flight per lane (needs a workspace),
+// 5 = map-resident kernel (an error when it does not apply)
 static int g_roi_variant = 0;
 // estimated loads per lane above which a RoI is split into its P row bins (variant >= 100 sets it: tuning only)
 static int g_roi_heavy_loads = 64;
+constexpr bool RES_AUTO = false;   // flipped when the map-resident kernel beats the planned pair (profiles/r03_roi_align.md)
+static int g_res_dbg = 0;      // ablation mask of the map-resident kernel (variant 1000 + mask): 1 no map load, 2 no tables,
+                               // 4 no stores, 8 no row loop - timing experiments only, results are then wrong
 extern "C" int frcnn_roi_align_set_variant(int v) {
+  if (v >= 1000) { g_res_dbg = v - 1000; return FRCNN_OK; }
   if (v >= 100) { g_roi_heavy_loads = v; return FRCNN_OK; }
   g_roi_variant = v;
   return FRCNN_OK;
+}
+
+static bool resident_ok(int h, int w, int c, int pooled) {
+  return pooled == PLAN_P && c % 16 == 0 && h <= 64 && w <= 1024 && res_lds_bytes(h, w) <= (size_t)160 * 1024;
 }
 
 extern "C" size_t frcnn_roi_align_fwd_ws_bytes(int h, int w, int c, int num_rois, int pooled) {
@@ -477,14 +786,40 @@ extern "C" size_t frcnn_roi_align_fwd_ws_bytes(int h, int w, int c, int num_rois
   return plan_bytes(h, w, c, num_rois);
 }
 
-extern "C" int frcnn_roi_align_fwd(const float* feat, int h, int w, int c, const float* rois, const int* roi_count,
-                                   int num_rois, int pooled, float spatial_scale, int sampling_ratio,
+extern "C" int frcnn_roi_align_fwd(const float* feat, int n, int h, int w, int c, const float* rois, const int* roi_count,
+                                   int num_rois, int rois_per_image, int pooled, float spatial_scale, int sampling_ratio,
                                    const int* level_of_roi, int level, float* out, void* ws, size_t ws_bytes,
                                    void* stream_) {
-  FRCNN_REQUIRE(feat && rois && out && h > 0 && w > 0 && c > 0 && c % 4 == 0 && num_rois > 0 && pooled > 0,
+  FRCNN_REQUIRE(feat && rois && out && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && num_rois > 0 && pooled > 0,
                 "roi_align_fwd: bad arguments (c%%4==0)");
+  FRCNN_REQUIRE(rois_per_image == 0 || (rois_per_image > 0 && (long)rois_per_image * n >= num_rois),
+                "roi_align_fwd: rois_per_image %d x %d images < %d rois", rois_per_image, n, num_rois);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const bool want_planned = g_roi_variant == 0 || g_roi_variant >= 3;
+  if (g_roi_variant == 5 && !resident_ok(h, w, c, pooled))
+    return frcnn::fail(FRCNN_ERR_ARG, "roi_align_fwd: the map-resident kernel needs pooled 7, c %% 16 == 0, h <= 64 and "
+                       "h*w*64 B of LDS (got %dx%dx%d)", h, w, c);
+  if ((g_roi_variant == 5 || (g_roi_variant == 0 && RES_AUTO)) && resident_ok(h, w, c, pooled)) {
+    const size_t lds = res_lds_bytes(h, w);
+    static std::atomic<size_t> configured{0};
+    if (lds > configured.load()) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_fwd_resident),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return frcnn::fail(FRCNN_ERR_LAUNCH, "roi_align_fwd: set LDS size: %s", hipGetErrorString(e));
+      configured.store(lds);
+    }
+    const int nslices = c / 16;
+    // one workgroup per CU in total: RoI groups share a channel slice (each reloads the map slice from L2)
+    const int per_image_rois = rois_per_image > 0 ? rois_per_image : num_rois;
+    int ngroups = std::max(1, 256 / (nslices * n));
+    ngroups = std::max(1, std::min(ngroups, per_image_rois / 16));
+    hipLaunchKernelGGL(roi_align_fwd_resident, dim3((unsigned)(nslices * ngroups), (unsigned)n), dim3(64 * RES_WAVES), lds,
+                       stream, feat, h, w, c, rois, roi_count, num_rois, rois_per_image, spatial_scale, sampling_ratio,
+                       level_of_roi, level, nslices, ngroups, out, g_res_dbg);
+    return frcnn::check_launch("roi_align_fwd_resident");
+  }
+  // the kernels below index the image through the RoI's batch column and read one live count
+  FRCNN_REQUIRE(rois_per_image == 0 || n == 1, "roi_align_fwd: per-image RoI blocks need the map-resident kernel");
+  const bool want_planned = g_roi_variant == 0 || g_roi_variant == 3 || g_roi_variant == 4;
   if (want_planned && planned_ok(pooled) && ws && ws_bytes >= plan_bytes(h, w, c, num_rois)) {
     const int c4 = c / 4, nslices = (c4 + 63) / 64;
     RoiPlanHead* head = static_cast<RoiPlanHead*>(ws);

@@ -345,6 +345,15 @@ def gather_rows(rows, order, count=None):
     return out
 
 
+def set_nms_suppress_at_equal(on):
+    """IoU == threshold exactly: True (default) suppresses like torchvision 0.4.0's CPU kernel (`>=`), False keeps the box
+    like its CUDA kernel (`>`).  Returns the previous setting."""
+    lib = _hip.load()
+    old = bool(lib.frcnn_nms_get_suppress_at_equal())
+    _hip.check(lib.frcnn_nms_set_suppress_at_equal(1 if on else 0), "frcnn_nms_set_suppress_at_equal")
+    return old
+
+
 def nms_sorted(boxes, thresh, max_keep=None, n_dev=None, want_mask=False):
     """NMS over boxes already in descending-score order.
     Returns (keep_idx int64 (max_keep,), keep_count int32 (1,), keep_mask uint8 (n,) or None)."""
@@ -373,8 +382,9 @@ def make_rois(sorted_boxes, sorted_scores, keep_idx, keep_count):
 
 
 def roi_align_nhwc(feat, rois, pooled, spatial_scale, sampling_ratio=0, roi_count=None, level_of_roi=None, level=-1,
-                   out=None):
-    """feat (N,H,W,C), rois (R,5) -> (R, P, P, C)."""
+                   out=None, rois_per_image=0):
+    """feat (N,H,W,C), rois (R,5) -> (R, P, P, C).  ``rois_per_image`` > 0: rows [i*rpi, (i+1)*rpi) belong to image i and
+    ``roi_count`` holds N live counts (frames batched into one call); 0: the image is the RoI's batch column."""
     lib = _hip.load()
     _dev_f32(feat, "feat"); _dev_f32(rois, "rois")
     n, h, w, c = feat.shape
@@ -383,9 +393,9 @@ def roi_align_nhwc(feat, rois, pooled, spatial_scale, sampling_ratio=0, roi_coun
         out = torch.empty((r, pooled, pooled, c), dtype=torch.float32, device=feat.device)
     ws_bytes = lib.frcnn_roi_align_fwd_ws_bytes(h, w, c, r, pooled)
     ws = _workspace(ws_bytes, feat.device) if ws_bytes else None
-    _hip.check(lib.frcnn_roi_align_fwd(_ptr(feat), h, w, c, _ptr(rois), _ptr(roi_count), r, pooled, float(spatial_scale),
-                                       int(sampling_ratio), _ptr(level_of_roi), level, _ptr(out), _ptr(ws), ws_bytes,
-                                       _stream()), "frcnn_roi_align_fwd")
+    _hip.check(lib.frcnn_roi_align_fwd(_ptr(feat), n, h, w, c, _ptr(rois), _ptr(roi_count), r, int(rois_per_image), pooled,
+                                       float(spatial_scale), int(sampling_ratio), _ptr(level_of_roi), level, _ptr(out),
+                                       _ptr(ws), ws_bytes, _stream()), "frcnn_roi_align_fwd")
     return out
 
 

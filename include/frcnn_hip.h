@@ -190,6 +190,12 @@ int frcnn_sort_topk_desc(const float* scores, int n, int top_n, int64_t* order_o
 int frcnn_gather_rows(const float* rows, const int64_t* order, const int* count, int max_count, int width,
                       float* rows_out, void* stream);
 
+/* torchvision.ops.nms at IoU == threshold exactly (proposal_layer.py:46, filter_predictions.py:67-69): on != 0 (default)
+ * suppresses the box like torchvision 0.4.0's CPU kernel (`iou >= threshold`), 0 keeps it like its CUDA kernel
+ * (`iou > threshold`).  Process-wide, read when frcnn_nms / frcnn_filter_per_class* launch. */
+int frcnn_nms_set_suppress_at_equal(int on);
+int frcnn_nms_get_suppress_at_equal(void);
+
 /* torchvision.ops.nms (call sites proposal_layer.py:46, filter_predictions.py:67-69) on boxes already
  * sorted by descending score: box j is dropped when IoU(i,j) > thresh for an earlier kept i
  * (areas without +1).  n_dev (device int, may be NULL -> n_max) boxes are live.
@@ -208,20 +214,25 @@ int frcnn_make_rois(const float* sorted_boxes, const float* sorted_scores, const
 /* ---------------------------------------------------------------------------------------------
  * RoIAlign (torchvision.ops.roi_align 0.4.0 semantics = aligned=False; call sites
  * lib/utils/torchpoolers.py:165-170,194-197 and the _crop_pool_layer of the missing network.py).
- * feat NHWC (1,H,W,C); rois (R,5) [batch,x1,y1,x2,y2]; out (R,P,P,C) NHWC.
+ * feat NHWC (n,H,W,C); rois (R,5) [batch,x1,y1,x2,y2]; out (R,P,P,C) NHWC.
  * sampling_ratio <= 0 -> adaptive ceil(roi/P).  roi_count (device int, may be NULL) masks rows
  * >= count to zero.  level_of_roi/level (may be NULL/-1): only rois with level_of_roi[r]==level
  * are written (MultiScaleRoIAlign, torchpoolers.py:187-199).
  * ------------------------------------------------------------------------------------------- */
-/* Tuning / test hook: 0 automatic, 1 generic kernel, 2 generic with per-XCD channel slices, 3 / 4 planned kernel with
- * 8 / 4 loads in flight per lane. */
+/* feat holds n images (n,H,W,C).  rois_per_image == 0: the image of a RoI is its batch column and roi_count (may be NULL)
+ * is ONE live count; rois_per_image > 0: rows [i*rois_per_image, (i+1)*rois_per_image) belong to image i whatever their
+ * batch column says, and roi_count points to n live counts (frames batched into one call).
+ * Tuning / test hook: 0 automatic (map-resident kernel when one 16-channel slice of the map fits the LDS: pooled 7,
+ * c % 16 == 0, h <= 64, h*w*64 B + 10 KB <= 160 KB; else the planned pair when a workspace is given; else generic),
+ * 1 generic kernel, 2 generic with per-XCD channel slices, 3 / 4 planned kernel with 8 / 4 loads in flight per lane,
+ * 5 map-resident kernel or an error. */
 int frcnn_roi_align_set_variant(int variant);
-/* Scratch for the planned (fast) kernel pair: the compact work-item list + the per-bin axis weight tables.  Returns 0
- * when the shape has no fast path (pooled != 7: the generic kernel needs no scratch).  Passing ws == NULL to
- * frcnn_roi_align_fwd is always valid and selects the generic kernel. */
+/* Scratch for the planned kernel pair: the compact work-item list + the per-bin axis weight tables.  Returns 0
+ * when the shape has no planned path (pooled != 7).  Passing ws == NULL to frcnn_roi_align_fwd is always valid (the
+ * map-resident and the generic kernels need none). */
 size_t frcnn_roi_align_fwd_ws_bytes(int h, int w, int c, int num_rois, int pooled);
-int frcnn_roi_align_fwd(const float* feat, int h, int w, int c, const float* rois, const int* roi_count,
-                        int num_rois, int pooled, float spatial_scale, int sampling_ratio,
+int frcnn_roi_align_fwd(const float* feat, int n, int h, int w, int c, const float* rois, const int* roi_count,
+                        int num_rois, int rois_per_image, int pooled, float spatial_scale, int sampling_ratio,
                         const int* level_of_roi, int level, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* LevelMapper (lib/utils/torchpoolers.py:20-51) of MultiScaleRoIAlign: levels[i] = clamp(floor(canonical_level +

@@ -153,10 +153,12 @@ def stable_desc_order(scores):
     return torch.sort(s, descending=True, stable=True)[1]
 
 
-# NAMED CHOICE shared with the device code (csrc/box_math.h NMS_SUPPRESS_AT_EQUAL): a box whose IoU with a kept box EQUALS
-# the threshold survives (`>`, the library's CUDA kernel and every release after the pinned one); the pinned release's CPU
-# kernel is believed to have used `>=`.  torchvision is not available here, so the choice is recorded, not verified.
-NMS_SUPPRESS_AT_EQUAL = False
+# IoU == threshold exactly: torchvision 0.4.0's CPU kernel suppresses (`>=`), its CUDA kernel (and every later release) keeps
+# the box (`>`).  The module-level switch mirrors the device library's run-time setting (frcnn_nms_set_suppress_at_equal);
+# the default is the CPU kernel's, the path the reference is compared against.  torchvision is not available here, so the
+# choice is recorded, not verified (PARITY UNPINNED, see the header); on real-valued inputs the two forms differ on a set of
+# measure zero.
+NMS_SUPPRESS_AT_EQUAL = True
 
 
 def nms(boxes, scores, thresh):

@@ -32,6 +32,20 @@ def _close_feat(got, ref, what="", frac=2e-5):
     assert err <= tol, "%s: max abs err %.3e > %.3e (max |ref| %.3e)" % (what, err, tol, np.abs(ref).max())
 
 
+@pytest.fixture(params=[True, False], ids=["iou_ge_thresh_suppresses", "iou_gt_thresh_suppresses"])
+def nms_at_equal(request, hip):
+    """Both readings of torchvision 0.4.0's NMS at IoU == threshold (CPU kernel `>=` = the default, CUDA kernel `>`): the
+    device library and the oracle are switched together, the test body runs once per setting."""
+    ops = _ops()
+    old_dev, old_cpu = ops.set_nms_suppress_at_equal(request.param), O.NMS_SUPPRESS_AT_EQUAL
+    O.NMS_SUPPRESS_AT_EQUAL = request.param
+    try:
+        yield request.param
+    finally:
+        ops.set_nms_suppress_at_equal(old_dev)
+        O.NMS_SUPPRESS_AT_EQUAL = old_cpu
+
+
 def _rand_boxes(n, gen, extent=(1000, 600), max_wh=300):
     xy = torch.rand(n, 2, generator=gen) * torch.tensor([extent[0] - 50.0, extent[1] - 50.0])
     wh = torch.rand(n, 2, generator=gen) * max_wh + 1
@@ -332,7 +346,7 @@ def _nms_inputs(kind, n, gen):
 
 @pytest.mark.parametrize("kind", ["clustered", "random", "degenerate"])
 @pytest.mark.parametrize("n", [6000, 1000, 300, 65, 64, 1])
-def test_nms_keep_bit_exact(hip, kind, n):
+def test_nms_keep_bit_exact(hip, kind, n, nms_at_equal):
     ops = _ops()
     gen = torch.Generator().manual_seed(n * 7 + len(kind))
     boxes = _nms_inputs(kind, n, gen)
@@ -355,21 +369,83 @@ def test_nms_keep_bit_exact(hip, kind, n):
         assert torch.equal(k3[:c3.item()].cpu(), ref3)
 
 
-def test_nms_threshold_edge(hip):
-    """Documents the NAMED CHOICE NMS_SUPPRESS_AT_EQUAL = false (csrc/box_math.h, oracle): box 1 has IoU exactly 0.5 with
-    box 0 and SURVIVES at threshold 0.5 (suppression needs iou > threshold); at 0.49 it is suppressed."""
+def test_nms_threshold_edge(hip, nms_at_equal):
+    """IoU == threshold exactly (frcnn_nms_set_suppress_at_equal; default = the CPU kernel of torchvision 0.4.0, `>=`): box 1
+    has IoU exactly 0.5 with box 0.  At threshold 0.5 it is suppressed under `>=` and survives under `>`; at 0.49 it is
+    suppressed either way."""
     ops = _ops()
-    assert O.NMS_SUPPRESS_AT_EQUAL is False
+    assert hip.frcnn_nms_get_suppress_at_equal() == int(nms_at_equal)
     boxes = torch.tensor([[0., 0, 10, 10], [0, 0, 10, 5], [0, 0, 10, 7], [20, 20, 30, 30], [0, 0, 10, 7.0001]])
-    for thr, want in ((0.5, [0, 1, 3]), (0.49, [0, 3]), (0.7, [0, 1, 2, 3])):
+    for thr, want in ((0.5, [0, 3] if nms_at_equal else [0, 1, 3]), (0.49, [0, 3]), (0.7, None)):
         k, c, _ = ops.nms_sorted(boxes.to(DEV), thr)
         assert k[:c.item()].cpu().tolist() == O.nms(boxes, torch.arange(5, 0, -1).float(), thr).tolist()
-        if thr != 0.7:
+        if want is not None:
             assert k[:c.item()].cpu().tolist() == want
 
 
+def test_nms_default_is_the_cpu_kernels_comparator(hip):
+    """north_star: "match the reference CPU path" - the library's default suppresses at IoU == threshold."""
+    assert hip.frcnn_nms_get_suppress_at_equal() == 1 and O.NMS_SUPPRESS_AT_EQUAL is True
+
+
+def test_nms_at_equal_threshold_in_every_kernel(hip, nms_at_equal):
+    """Pairs with IoU EXACTLY at the threshold through every kernel that evaluates the predicate: nms_mask_kernel (pair inside
+    one 64-box block and across blocks), filter_class_small_kernel, filter_class_kernel, the LiDAR filter.  The outcome
+    equals the oracle's under the same setting and differs between the two settings."""
+    from faster_rcnn_pytorch_multimodal_amd.utils.filter_predictions import filter_device
+    ops = _ops()
+    # --- frcnn_nms, threshold 0.5: box pairs (10x10, 10x5) have IoU 50/100 exactly; 200 disjoint pairs, the partner of pair
+    # p sits 200 rows later (another 64-box block); one extra pair sits inside one block
+    boxes = []
+    for p in range(200):
+        x = 20.0 * p
+        boxes.append([x, 0.0, x + 10, 10.0])
+    for p in range(200):
+        x = 20.0 * p
+        boxes.append([x, 0.0, x + 10, 5.0])
+    boxes = torch.tensor(boxes)                                  # partner of row p is row p + 200: other blocks
+    boxes = torch.cat((boxes, torch.tensor([[5000., 0, 5010, 10], [5000., 0, 5010, 5]])), 0)   # + one pair in one block
+    n = boxes.shape[0]
+    scores = torch.arange(n, 0, -1).float()
+    ref = O.nms(boxes, scores, 0.5)
+    k, c, _ = ops.nms_sorted(boxes.to(DEV), 0.5)
+    assert torch.equal(k[:c.item()].cpu(), ref)
+    assert len(ref) == (201 if nms_at_equal else 402)
+    # --- per-class filter, cfg.TEST.NMS_THRESH = 0.6: (10x10, 10x6) pairs have IoU 60/100 exactly
+    info = np.array([0, 10000, 0, 600, 0, 0, 1.0], np.float32)
+    r, kcls = 64, 2
+    bx = []
+    for p in range(r // 2):
+        x = 30.0 * p
+        bx += [[x, 0.0, x + 10, 10.0], [x, 0.0, x + 10, 6.0]]
+    cls1 = torch.tensor(bx)
+    pred = torch.cat((torch.zeros(r, 4), cls1), 1).contiguous()
+    prob = torch.stack((torch.zeros(r), torch.linspace(0.99, 0.6, r)), 1).contiguous()
+    rois = torch.cat((torch.zeros(r, 1), cls1), 1)
+    _, ref_boxes, _ = O.filter_and_draw_prep(rois, prob, pred.clone(), info, kcls, 0.5)
+    for variant in (0, 1):
+        hip.frcnn_filter_set_variant(variant)
+        try:
+            dets, counts = filter_device(None, prob.to(DEV), pred.clone().to(DEV), info, 0.5, 0, r)
+        finally:
+            hip.frcnn_filter_set_variant(0)
+        assert int(counts[1]) == len(ref_boxes[1]) == (r // 2 if nms_at_equal else r)
+        np.testing.assert_array_equal(dets[1, :int(counts[1])].cpu().numpy(), ref_boxes[1])
+    # --- LiDAR filter: NMS on xc +- l/2, yc +- w/2 (filter_predictions.py:55-62); l x w = 10x10 and 10x6 around one corner
+    l7 = []
+    for p in range(r // 2):
+        x = 30.0 * p
+        l7 += [[x + 5, 5.0, 1.0, 10.0, 10.0, 2.0, 0.3], [x + 5, 3.0, 1.0, 10.0, 6.0, 2.0, 0.1]]
+    l7 = torch.tensor(l7)
+    pred7 = torch.cat((torch.zeros(r, 7), l7), 1).contiguous()
+    _, ref_l = O.filter_and_draw_prep_lidar(torch.zeros(r, 5), prob, pred7.clone(), kcls, 0.5)
+    dets, counts = filter_device(None, prob.to(DEV), pred7.to(DEV), info, 0.5, 0, r, db_type="lidar")
+    assert int(counts[1]) == len(ref_l[1]) == (r // 2 if nms_at_equal else r)
+    np.testing.assert_array_equal(dets[1, :int(counts[1])].cpu().numpy(), ref_l[1])
+
+
 @pytest.mark.parametrize("shape", [(38, 63, 6000, 300), (12, 17, 6000, 300), (25, 22, 12000, 2000)])
-def test_proposal_layer_matches_oracle(hip, shape):
+def test_proposal_layer_matches_oracle(hip, shape, nms_at_equal):
     from faster_rcnn_pytorch_multimodal_amd.layer_utils.proposal_layer import proposal_layer
     from faster_rcnn_pytorch_multimodal_amd.model import config as C
     h, w, pre, post = shape
@@ -495,7 +571,7 @@ def test_head_fc_softmax_decode(hip):
 
 @pytest.mark.parametrize("r,variant", [(300, 0), (300, 1), (1024, 0), (1500, 0), (37, 0)])
 @pytest.mark.parametrize("thresh,max_dets", [(0.1, 100), (0.5, 100), (0.05, 20), (0.999, 100)])
-def test_filter_per_class_matches_oracle(hip, thresh, max_dets, r, variant):
+def test_filter_per_class_matches_oracle(hip, thresh, max_dets, r, variant, nms_at_equal):
     """variant 0: LDS-resident kernel for r <= 1024 (rank sort, wave-per-word ballot matrix), the general workspace kernel
     above that; variant 1 forces the general kernel.  Both must reproduce the oracle's rows exactly."""
     from faster_rcnn_pytorch_multimodal_amd.utils.filter_predictions import filter_device
@@ -982,7 +1058,7 @@ def test_lidar_fpn_train_step_matches_oracle_autograd(hip):
 
 
 @pytest.mark.parametrize("thresh,max_dets", [(0.1, 100), (0.5, 30)])
-def test_filter_per_class_lidar_matches_oracle(hip, thresh, max_dets):
+def test_filter_per_class_lidar_matches_oracle(hip, thresh, max_dets, nms_at_equal):
     ops = _ops()
     g = torch.Generator().manual_seed(17)
     r, k = 300, 3

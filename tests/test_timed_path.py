@@ -145,20 +145,23 @@ def _timed_path_against_cpu_oracle():
             dets, counts = runners[k].run(frames[i], rpn=rpn_dev[i])
             p = runners[k].predictions
             got.append((dets.clone(), counts.clone(), p["rois_count"].clone(), p["rpn_order"].clone(),
-                        p["rpn_keep"].clone(), p["rois"].clone(), p["cls_prob"].clone(), p["pred_boxes"].clone()))
+                        p["rpn_keep"].clone(), p["rois"].clone(), p["cls_prob"].clone(), p["pred_boxes"].clone(),
+                        p["bbox_pred"].clone()))
     for st in streams:
         torch.cuda.current_stream().wait_stream(st)
     torch.cuda.synchronize()
-    worst_score = worst_prob = worst_roi = 0.0
+    worst_score = worst_prob = worst_roi = worst_delta = worst_small = worst_large_ulp = worst_box = 0.0
+    n_small = 0
     for i in range(n_frames):
         if i not in _ORACLE_CACHE:       # the CPU side does not depend on the convolution mode under test: evaluate it once
             _, cp_r, pb_r, rois_r, _ = cpu.test_frame(frames_host[i], INFO, structured[i])
             _, boxes_r, pb_r = O.filter_and_draw_prep(rois_r, cp_r, pb_r, INFO, bench.NUM_CLASSES, bench.THRESH)
             ref = [O.max_dets_cut(b, bench.MAX_DETS) for b in boxes_r]    # == O.frame_detect (lib/model/test.py:68-93,210-221)
-            d = {"keep": cpu._dbg["keep"].clone(), "order": cpu._dbg["order"].clone()}
+            d = {"keep": cpu._dbg["keep"].clone(), "order": cpu._dbg["order"].clone(),
+                 "bbox_pred": cpu._dbg["bbox_pred"].clone()}
             _ORACLE_CACHE[i] = (cp_r, pb_r, rois_r, ref, d, _pred_boxes_fp64(sd, frames_host[i], rois_r))
         cp_r, pb_r, rois_r, ref, d, (pb64, cp64) = _ORACLE_CACHE[i]
-        dets, counts, n_dev, order, keep, rois, cls_prob, pred_boxes = [t.cpu() for t in got[i]]
+        dets, counts, n_dev, order, keep, rois, cls_prob, pred_boxes, bbox_pred = [t.cpu() for t in got[i]]
         n = int(n_dev)
         # proposals: the same anchors survive, in the same order
         assert n == d["keep"].shape[0] == rois_r.shape[0]
@@ -171,6 +174,27 @@ def _timed_path_against_cpu_oracle():
         print("frame %d: |pred_boxes - fp64| device %.3e px, CPU fp32 oracle %.3e px; |cls_prob - fp64| device %.3e, oracle %.3e"
               % (i, err_dev, err_cpu, float((cls_prob[:n].double() - cp64).abs().max()), float((cp_r.double() - cp64).abs().max())))
         assert err_dev <= max(1e-4, 1.5 * err_cpu), "frame %d: pred_boxes %.3e px from fp64 (CPU oracle: %.3e)" % (i, err_dev, err_cpu)
+        # ---- the quantity north_star names: |device - reference CPU path| on the fp32 tensors themselves ----
+        # (a) regression deltas (an O(1) tensor: 1e-4 abs is meaningful as it stands)
+        worst_delta = max(worst_delta, float((bbox_pred[:n] - d["bbox_pred"]).abs().max()))
+        # (b) decoded boxes.  A coordinate is roi + delta * diagonal evaluated through ~6 dependent fp32 operations at the
+        # magnitude of the coordinate, and the deltas of the two fp32 paths differ by ~6e-6 (above): two correct fp32
+        # evaluations differ by  |d delta| * (0.1 * diagonal + 0.2 * side)  +  a few ulp(coordinate)  - e.g. 6e-6 * 0.1 * 256 =
+        # 1.6e-4 px for a 256 px box, and one ulp at 1000 px is 6.1e-5 px.  An absolute 1e-4 is therefore only resolvable
+        # where the box scale max(diagonal, |coordinate|) is <= 128 px (1e-4 = 13 ulp there); beyond that the bound is
+        # 12 ulp of the box scale (measured 9.0; 12 ulp(1000 px) = 7.3e-4 px).
+        rw, rh = rois_r[:, 3] - rois_r[:, 1] + 1.0, rois_r[:, 4] - rois_r[:, 2] + 1.0        # rois rows are [0,x1,y1,x2,y2]
+        diag = torch.sqrt(rw * rw + rh * rh)
+        diff = (pred_boxes[:n] - pb_r).abs()
+        scale = torch.maximum(diag, pb_r.abs().max(1).values)
+        ulp = torch.from_numpy(np.spacing(scale.numpy().astype(np.float32)))
+        small = scale <= 128.0
+        n_small += int(small.sum())
+        if small.any():
+            worst_small = max(worst_small, float(diff[small].max()))
+        if (~small).any():
+            worst_large_ulp = max(worst_large_ulp, float((diff[~small] / ulp[~small, None]).max()))
+        worst_box = max(worst_box, float(diff.max()))
         for j in range(1, bench.NUM_CLASSES):
             r = ref[j]
             assert int(counts[j]) == len(r), "frame %d class %d: %d detections vs oracle %d" % (i, j, int(counts[j]), len(r))
@@ -181,7 +205,12 @@ def _timed_path_against_cpu_oracle():
             assert bd <= 1e-4 + 2.5 * err_cpu, "frame %d class %d: detection boxes off by %.3e px" % (i, j, bd)
     print("timed path vs CPU oracle over %d frames: max |roi diff| %.3e, |cls_prob diff| %.3e, |score diff| %.3e"
           % (n_frames, worst_roi, worst_prob, worst_score))
+    print("|device - CPU oracle|: bbox_pred deltas %.3e; pred_boxes %.3e px overall, %.3e px on the %d boxes of scale <= 128 px, "
+          "%.2f ulp(box scale) on larger ones" % (worst_delta, worst_box, worst_small, n_small, worst_large_ulp))
     assert worst_roi <= 1e-4 and worst_prob <= SCORE_TOL and worst_score <= SCORE_TOL
+    assert worst_delta <= 1e-4, "bbox_pred deltas differ from the CPU oracle by %.3e" % worst_delta
+    assert worst_small <= 1e-4, "pred_boxes of boxes up to 128 px differ from the CPU oracle by %.3e px" % worst_small
+    assert worst_large_ulp <= 12.0, "pred_boxes of large boxes differ from the CPU oracle by %.2f ulp" % worst_large_ulp
 
 
 def test_bench_runs_its_collective_path_over_rccl_with_one_rank(hip):
@@ -201,7 +230,8 @@ def test_bench_runs_its_collective_path_over_rccl_with_one_rank(hip):
     assert res.returncode == 0, res.stderr[-3000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     col = out["collective"]
-    assert col["backend"] == "nccl" and col["is_rccl"] and col["rccl_ranks"] == 1 and col["allgather_us_per_step"] > 0
+    assert col["backend"] == "nccl" and col["is_rccl"] and col["rccl_ranks"] == 1 and col["allgather_us_per_block"] > 0
+    assert col["gather_every_frames"] == 8 and col["allgathers_per_region"] == 2
     assert out["verification"]["equal_to_eager_path"] is True and out["verification"]["timed_steps_checked"] == 12
     assert out["n_gpus"] == 1 and out["value"] > 50
     # the measurement objects of the contract, produced by this run's code (not read from a committed file)
