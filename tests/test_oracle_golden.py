@@ -83,7 +83,14 @@ def test_nms_known_answers():
     # hand-computed: IoU([0,0,10,10],[0,0,10,5]) = 0.5 exactly; [0,0,10,7] vs first = 0.7
     boxes = torch.tensor([[0., 0, 10, 10], [0, 0, 10, 5], [0, 0, 10, 7], [20, 20, 30, 30], [0, 0, 10, 7.0001]])
     scores = torch.tensor([0.9, 0.8, 0.7, 0.6, 0.5])
-    assert O.nms(boxes, scores, 0.5).tolist() == [0, 1, 3]          # 0.5 is NOT > 0.5 -> box 1 stays
+    # IoU == threshold: suppressed under the default (torchvision 0.4.0's CPU kernel, `>=`), kept under its CUDA kernel's `>`
+    assert O.NMS_SUPPRESS_AT_EQUAL is True
+    assert O.nms(boxes, scores, 0.5).tolist() == [0, 3]
+    O.NMS_SUPPRESS_AT_EQUAL = False
+    try:
+        assert O.nms(boxes, scores, 0.5).tolist() == [0, 1, 3]      # 0.5 is NOT > 0.5 -> box 1 stays
+    finally:
+        O.NMS_SUPPRESS_AT_EQUAL = True
     assert O.nms(boxes, scores, 0.49).tolist() == [0, 3]
     # equal scores: ties resolved by ascending index
     assert O.nms(boxes[[1, 0]], torch.tensor([0.5, 0.5]), 0.4).tolist() == [0]
