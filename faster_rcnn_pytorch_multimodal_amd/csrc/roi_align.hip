@@ -604,7 +604,7 @@ __global__ __launch_bounds__(64 * RES_WAVES) void roi_align_fwd_resident(
       const float start = is_x ? rsw : rsh, bin = is_x ? bw : bh;
       const int grid = is_x ? gw : gh, size = is_x ? W : H, cap = is_x ? RES_FX : RES_FY;
       bool over = false;
-#pragma unroll 1
+#pragma unroll
       for (int t = 0; t < P; ++t) {
         int lo = 0, hi = 0;
         float wl = 0.f, wh = 0.f;
@@ -668,6 +668,10 @@ __global__ __launch_bounds__(64 * RES_WAVES) void roi_align_fwd_resident(
         wxr[j] = j < my_xcnt ? T->wx[pwc][j] : 0.f;
         const int x = my_xcnt > 0 ? my_xlo + min(j, my_xcnt - 1) : 0;
         off[j] = res_col(x, W) * 64 + q * 16;
+        // a four-lane group without a task (slots 7 and 15) repeats the addresses of slot 4 / 12, which the same
+        // ds_read_b128 service group reads anyway: identical addresses are one bank access
+        const int borrowed = __shfl(off[j], lane - 12);
+        off[j] = slot_live ? off[j] : borrowed;
       }
       int cnt_max = my_xcnt, rows_max = nrows;
 #pragma unroll
