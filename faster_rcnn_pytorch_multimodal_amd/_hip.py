@@ -26,6 +26,7 @@ PROTOTYPES = {
     "frcnn_conv2d_set_tile": (c_int, [c_int, c_int]),
     "frcnn_conv2d_set_staging": (c_int, [c_int]),
     "frcnn_conv2d_set_algo": (c_int, [c_int]),
+    "frcnn_conv2d_plan_algo": (c_int, [c_int] * 10),
     "frcnn_conv2d_set_autotune": (c_int, [c_int]),
     "frcnn_conv2d_profile_begin": (c_int, []),
     "frcnn_conv2d_profile_end": (c_int, [POINTER(c_float), POINTER(c_int), POINTER(c_int), c_int]),
@@ -48,6 +49,7 @@ PROTOTYPES = {
     "frcnn_bbox_transform_inv": (c_int, [_P, c_int, _P, c_int, c_int, c_float, _P, _P]),
     "frcnn_clip_boxes": (c_int, [_P, c_int, POINTER(c_float), _P, _P]),
     "frcnn_lidar_bbox_transform_inv": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_float, _P, _P]),
+    "frcnn_uncertainty_transform_inv": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_float, c_int, c_int, _P, _P]),
     "frcnn_sort_topk_desc_ws_bytes": (c_size_t, [c_int, c_int]),
     "frcnn_sort_topk_desc": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "frcnn_gather_rows": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),

@@ -1325,6 +1325,56 @@ extern "C" int frcnn_bbox_transform_inv(const float* boxes, int box_ld, const fl
   return check_launch("bbox_transform_inv_kernel");
 }
 
+namespace {
+// uncertainty_transform_inv / lidar_3d_uncertainty_transform_inv (lib/model/bbox_transform.py:107-130,132-169): a per-element
+// uncertainty of the 7-element deltas [x,y,z,l,w,h,ry] mapped to box space and squared.  lidar == 0: the 4 BEV terms
+// [x,y,l,w] -> out (n, 4K); lidar == 1: all 7 -> out (n, 7K).  Centre terms scale with the RoI's +1 sizes (z with the 3-D
+// anchor's height), size terms are exp(u) - 1, the yaw term passes through.  The image form as written upstream omits the
+// unsqueeze that makes the size factors per-box (see tests/golden/make_golden_uc_inv.py); per-box scaling is implemented.
+__global__ __launch_bounds__(256) void uc_transform_inv_kernel(const float* __restrict__ rois, int roi_ld,
+                                                              const float* __restrict__ anchors3d,
+                                                              const float* __restrict__ uc, int n, int k, float scale,
+                                                              int use_scale, int lidar, int is_var,
+                                                              float* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * k) return;
+  const int i = t / k, c = t - i * k;
+  const float* r = rois + (size_t)i * roi_ld;
+  float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
+  if (use_scale) { x1 = x1 / scale; y1 = y1 / scale; x2 = x2 / scale; y2 = y2 / scale; }
+  const float len = x2 - x1 + 1.f, wid = y2 - y1 + 1.f;
+  float u[7];
+#pragma unroll
+  for (int e = 0; e < 7; ++e) {
+    const float v = uc[((size_t)i * k + c) * 7 + e];
+    u[e] = is_var ? sqrtf(v) : v;          // a variance is turned into the standard deviation the formulas take
+  }
+  const float ux = u[0] * len, uy = u[1] * wid;
+  const float ul = exp_f32(u[3]) - 1.f, uw = exp_f32(u[4]) - 1.f;
+  if (!lidar) {
+    float* o = out + ((size_t)i * k + c) * 4;
+    o[0] = ux * ux; o[1] = uy * uy; o[2] = ul * ul; o[3] = uw * uw;
+    return;
+  }
+  const float ht = anchors3d[(size_t)i * 7 + 5];
+  const float uz = u[2] * ht, uh = exp_f32(u[5]) - 1.f, ur = u[6];
+  float* o = out + ((size_t)i * k + c) * 7;
+  o[0] = ux * ux; o[1] = uy * uy; o[2] = uz * uz; o[3] = ul * ul; o[4] = uw * uw; o[5] = uh * uh; o[6] = ur * ur;
+}
+}  // namespace
+
+extern "C" int frcnn_uncertainty_transform_inv(const float* rois, int roi_ld, const float* anchors_3d, const float* uncertainty,
+                                               int n, int num_classes, float scale, int lidar, int input_is_variance, float* out,
+                                               void* stream_) {
+  FRCNN_REQUIRE(rois && uncertainty && out && n > 0 && num_classes > 0 && roi_ld >= 4 && (!lidar || anchors_3d),
+                "uncertainty_transform_inv: bad arguments");
+  const int total = n * num_classes;
+  hipLaunchKernelGGL(uc_transform_inv_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_), rois,
+                     roi_ld, anchors_3d, uncertainty, n, num_classes, scale, scale > 0.f ? 1 : 0, lidar ? 1 : 0,
+                     input_is_variance ? 1 : 0, out);
+  return check_launch("uc_transform_inv_kernel");
+}
+
 extern "C" int frcnn_lidar_bbox_transform_inv(const float* rois, int roi_ld, const float* anchors_3d,
                                               const float* deltas, int n, int num_classes, float scale, float* out,
                                               void* stream_) {

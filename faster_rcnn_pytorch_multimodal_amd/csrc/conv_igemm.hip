@@ -740,10 +740,10 @@ struct Plan {
 bool winograd_ok(int r, int s, int stride, int pad, int c, int k, int out_stride);
 size_t winograd_ws_bytes(int n, int h, int w, int c, int k);
 // test / tuning hook: 0 = the autotuner may pick either form, 1 = implicit GEMM only, 2 = Winograd wherever it applies
-int g_algo_mode = 0;
+std::atomic<int> g_algo_mode{0};   // atomic: set from one thread while another may launch
 
 // test / tuning hook: force the block tile (0 = automatic choice)
-int g_force_tm = 0, g_force_tn = 0;
+std::atomic<int> g_force_tm{0}, g_force_tn{0};
 
 // Pick the block tile and the K split that minimise the estimated time on 256 CUs.  Units: MFMA
 // issue cycles of one SIMD (64 per v_mfma_f32_32x32x2_f32); a CU runs one workgroup's K-step in
@@ -798,12 +798,17 @@ Plan choose_plan(int M, int K, int ksteps, int forced_splits) {
 typedef std::array<int, 10> ShapeKey;
 std::map<ShapeKey, Plan> g_plan_cache;
 std::mutex g_plan_mutex;
-int g_autotune = 0;
+std::atomic<int> g_autotune{0};
 constexpr size_t kTuneWsCap = (size_t)256 << 20;   // candidates whose split-K slabs exceed this are not tried
 constexpr size_t kTuneWinoCap = (size_t)768 << 20;  // same for the Winograd workspace (16 x (tiles x (C + K)) floats)
 
-ShapeKey shape_key(int n, int h, int w, int c, int k, int r, int s, int stride, int pad, int out_stride) {
-  return ShapeKey{n, h, w, c, k, r, s, stride, pad, out_stride};
+// The last slot carries the output stride AND whether the call has a residual operand (+ kKeyResidual): a call with a
+// residual cannot run as Winograd, so the two kinds of call of one shape are tuned and cached separately (a plan tuned for
+// one used to push the other onto the untuned analytic plan for good).
+constexpr int kKeyResidual = 256;
+ShapeKey shape_key(int n, int h, int w, int c, int k, int r, int s, int stride, int pad, int out_stride,
+                   bool has_residual = false) {
+  return ShapeKey{n, h, w, c, k, r, s, stride, pad, out_stride + (has_residual ? kKeyResidual : 0)};
 }
 
 std::vector<Plan> tune_candidates(long M, int k, int ksteps, bool allow_split) {
@@ -838,11 +843,14 @@ struct ProfRec {
   int call, kind;      // frcnn_conv2d_fwd call number since profile_begin; kind 0 = main kernel, 1 = split-K second pass
 };
 std::vector<ProfRec> g_prof;
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
 int g_prof_call = -1;
 
-bool prof_events(int kind, hipEvent_t* e0, hipEvent_t* e1) {
+bool prof_events(int kind, hipEvent_t* e0, hipEvent_t* e1, hipStream_t stream) {
   if (!g_prof_on) return false;
+  // a capturing stream cannot take the timed launch form (events would become graph nodes): plain launch, no record
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;
   if (hipEventCreate(e0) != hipSuccess) return false;
   if (hipEventCreate(e1) != hipSuccess) { (void)hipEventDestroy(*e0); return false; }
   g_prof.push_back(ProfRec{*e0, *e1, g_prof_call, kind});
@@ -862,7 +870,7 @@ int launch_conv(const ConvParams& p, int splits, int groups, hipStream_t stream)
   }
   dim3 grid(p.tiles_m * p.tiles_n, groups, splits);
   hipEvent_t e0, e1;
-  if (prof_events(0, &e0, &e1))
+  if (prof_events(0, &e0, &e1, stream))
     hipExtLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, ALIGNED>), grid, dim3(64 * WM * WN), (uint32_t)lds, stream, e0, e1,
                           0, p);
   else
@@ -883,7 +891,7 @@ int launch_conv_dma(const ConvParams& p, int splits, int groups, hipStream_t str
   }
   dim3 grid(p.tiles_m * p.tiles_n, groups, splits);
   hipEvent_t e0, e1;
-  if (prof_events(0, &e0, &e1))
+  if (prof_events(0, &e0, &e1, stream))
     hipExtLaunchKernelGGL((conv_igemm_dma_f32<WM, WN>), grid, dim3(512), (uint32_t)lds, stream, e0, e1, 0, p);
   else
     hipLaunchKernelGGL((conv_igemm_dma_f32<WM, WN>), grid, dim3(512), lds, stream, p);
@@ -901,7 +909,7 @@ int launch_conv_dma2(const ConvParams& p, int splits, int groups, hipStream_t st
   }
   dim3 grid(p.tiles_m * p.tiles_n, groups, splits);
   hipEvent_t e0, e1;
-  if (prof_events(0, &e0, &e1))
+  if (prof_events(0, &e0, &e1, stream))
     hipExtLaunchKernelGGL((conv_igemm_dma2_f32<2, 2>), grid, dim3(256), (uint32_t)lds, stream, e0, e1, 0, p);
   else
     hipLaunchKernelGGL((conv_igemm_dma2_f32<2, 2>), grid, dim3(256), lds, stream, p);
@@ -909,7 +917,7 @@ int launch_conv_dma2(const ConvParams& p, int splits, int groups, hipStream_t st
 }
 
 // tuning hook: 0 = register-staged kernels only, 1 = LDS-DMA kernel for the 8-wave tiles when C % 32 == 0
-int g_use_dma = 1;
+std::atomic<int> g_use_dma{1};
 
 bool conv_args_ok(int n, int h, int w, int c, int k, int r, int s, int stride, int pad) {
   return n > 0 && h > 0 && w > 0 && c > 0 && (c % 4) == 0 && k > 0 && r > 0 && s > 0 && stride > 0 && pad >= 0 &&
@@ -951,11 +959,24 @@ extern "C" size_t frcnn_conv2d_fwd_ws_bytes(int n, int h, int w, int c, int k, i
   const bool wino = winograd_ok(r, s, stride, pad, c, k, 1) && g_algo_mode != 1;
   const size_t wino_bytes = wino ? winograd_ws_bytes(n, h, w, c, k) : 0;
   if (split_k <= 0 && g_force_tm == 0) {
-    Plan cached;
-    if (lookup_plan(shape_key(n, h, w, c, k, r, s, stride, pad, 1), &cached)) {
-      if (cached.algo == 1) return wino_bytes;
-      const size_t direct = cached.splits > 1 ? (size_t)cached.splits * M * k * sizeof(float) : 0;
-      return g_algo_mode == 2 ? std::max(direct, wino_bytes) : direct;
+    // the caller does not say whether it has a residual: room for the cached plan of either kind of call.  A shape with
+    // only one of the two cached keeps room for whatever the other may still be tuned to (below)
+    Plan c0, c1;
+    const bool h0 = lookup_plan(shape_key(n, h, w, c, k, r, s, stride, pad, 1, false), &c0);
+    const bool h1 = lookup_plan(shape_key(n, h, w, c, k, r, s, stride, pad, 1, true), &c1);
+    if (h0 || h1) {
+      size_t need = 0;
+      for (const Plan* pc : {h0 ? &c0 : nullptr, h1 ? &c1 : nullptr}) {
+        if (!pc) continue;
+        need = std::max(need, pc->algo == 1 ? wino_bytes : (pc->splits > 1 ? (size_t)pc->splits * M * k * sizeof(float) : 0));
+      }
+      if (g_algo_mode == 2) need = std::max(need, wino_bytes);
+      if (h0 && h1) return need;
+      if (!g_autotune) return need;
+      size_t more = wino_bytes <= kTuneWinoCap ? wino_bytes : 0;
+      for (const Plan& cand : tune_candidates(M, k, ksteps, true))
+        if (cand.splits > 1) more = std::max(more, (size_t)cand.splits * M * k * sizeof(float));
+      return std::max(need, more);
     }
   }
   if (split_k <= 0 && g_force_tm == 0 && g_autotune) {
@@ -967,6 +988,12 @@ extern "C" size_t frcnn_conv2d_fwd_ws_bytes(int n, int h, int w, int c, int k, i
   if (g_algo_mode == 2 && split_k <= 0 && g_force_tm == 0 && wino) return wino_bytes;
   const Plan pl = choose_plan((int)M, k, ksteps, split_k);
   return pl.splits > 1 ? (size_t)pl.splits * M * k * sizeof(float) : 0;
+}
+
+extern "C" int frcnn_conv2d_plan_algo(int n, int h, int w, int c, int k, int r, int s, int stride, int pad, int has_residual) {
+  Plan pl;
+  if (!lookup_plan(shape_key(n, h, w, c, k, r, s, stride, pad, 1, has_residual != 0), &pl)) return -1;
+  return pl.algo;
 }
 
 extern "C" int frcnn_conv2d_set_autotune(int enable) {
@@ -1009,7 +1036,7 @@ extern "C" int frcnn_conv2d_import_plans(const int* in, int entries) {
     const int* row = in + e * 13;
     const int algo = row[10] >> 4, cfg = row[10] & 15;
     FRCNN_REQUIRE(row[10] >= 0 && cfg < kNumTiles && algo <= 1 && row[11] >= 1 && row[11] <= 64 && row[12] >= 1 &&
-                      (algo == 0 || (row[11] == 1 && winograd_ok(row[5], row[6], row[7], row[8], row[3], row[4], row[9]))),
+                      (algo == 0 || (row[11] == 1 && winograd_ok(row[5], row[6], row[7], row[8], row[3], row[4], row[9]))),   // a residual key (row[9] >= 256) fails winograd_ok: no Winograd plan for it
                   "conv2d_import_plans: entry %d is not a valid plan (tile %d, splits %d)", e, row[10], row[11]);
     ShapeKey key;
     for (int i = 0; i < 10; ++i) key[i] = row[i];
@@ -1218,7 +1245,7 @@ template <typename... Args, typename... Actual>
 int launch_1d(const char* what, void (*kernel)(Args...), size_t threads, hipStream_t stream, Actual... args) {
   const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
   hipEvent_t e0, e1;
-  if (prof_events(2, &e0, &e1)) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, e0, e1, 0, args...);
+  if (prof_events(2, &e0, &e1, stream)) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, e0, e1, 0, args...);
   else hipLaunchKernelGGL(kernel, grid, block, 0, stream, args...);
   return frcnn::check_launch(what);
 }
@@ -1266,7 +1293,7 @@ int launch_plan(ConvParams p, const Plan& pl, long M, int k, const float* scale,
     const size_t mk = (size_t)M * k;
     const int blocks = (int)std::min<size_t>((mk + 255) / 256, 2048);
     hipEvent_t e0, e1;
-    if (prof_events(1, &e0, &e1))
+    if (prof_events(1, &e0, &e1, stream))
       hipExtLaunchKernelGGL(conv_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, e0, e1, 0,
                             (const float*)p.partial, pl.splits, mk, k, scale, shift, residual, y, relu);
     else
@@ -1354,7 +1381,7 @@ int run_conv(const float* x, const float* wgt, const float* scale, const float* 
   Plan pl;
   bool have = false;
   if (split_k <= 0 && g_force_tm == 0) {   // cached plans always apply; new shapes are tuned only in autotune mode
-    const ShapeKey key = shape_key(n, h, w, c, k, r, s, stride, pad, out_stride);
+    const ShapeKey key = shape_key(n, h, w, c, k, r, s, stride, pad, out_stride, residual != nullptr);
     have = lookup_plan(key, &pl);
     const bool wino = residual == nullptr && winograd_ok(r, s, stride, pad, c, k, out_stride);
     // a cached plan of the other form than this call may use (a residual operand, or a forced mode) is left in the cache

@@ -36,3 +36,17 @@ def bbox_transform(ex_rois, gt_rois):
 def lidar_3d_bbox_transform(ex_rois, ex_anchors, gt_rois):
     """Targets (N,7) of the 3-D gt rows against the BEV RoIs and their 3-D anchors.  lib/model/bbox_transform.py:16-49."""
     return ops.lidar_bbox_transform(ex_rois.contiguous(), ex_anchors.contiguous(), gt_rois.contiguous())
+
+
+def uncertainty_transform_inv(boxes, deltas, uncertainty, scales=None):
+    """lib/model/bbox_transform.py:107-130: uncertainty (N, 7K) of the deltas -> (N, 4K) squared BEV terms [x,y,l,w]; ``boxes``
+    are the (N,4) RoIs the deltas were regressed against (``deltas`` is unused upstream too).  Per-box scaling: upstream's
+    missing ``unsqueeze`` only gives that for one box per call (tests/golden/make_golden_uc_inv.py)."""
+    return ops.uncertainty_transform_inv(boxes.contiguous(), uncertainty.contiguous(), scale=scales, lidar=False)
+
+
+def lidar_3d_uncertainty_transform_inv(rois, boxes, deltas, uncertainty, scales=None):
+    """lib/model/bbox_transform.py:132-169: rois (N,4) BEV RoIs, boxes (N,7) their 3-D anchors, uncertainty (N,7K) ->
+    (N,7K) squared terms (the in-place division of the anchors by ``scales`` upstream does not change the result: only
+    their height is read)."""
+    return ops.uncertainty_transform_inv(rois.contiguous(), uncertainty.contiguous(), boxes.contiguous(), scales, lidar=True)

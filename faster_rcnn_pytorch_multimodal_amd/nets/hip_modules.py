@@ -66,20 +66,30 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, use_bn=True):
         x = ops.pad_channels(x, w.shape[-1])
     stride = conv.stride[0] if isinstance(conv.stride, (tuple, list)) else conv.stride
     pad = conv.padding[0] if isinstance(conv.padding, (tuple, list)) else conv.padding
-    return ops.conv2d_nhwc(x, w, scale, shift, residual, stride=stride, pad=pad, relu=relu,
-                           w_winograd=_winograd_filter(conv, w, stride, pad) if residual is None else None)
+    u = None
+    if residual is None:
+        n, h, wd, c = x.shape
+        u = _winograd_filter(conv, w, (n, h, wd), stride, pad)
+    return ops.conv2d_nhwc(x, w, scale, shift, residual, stride=stride, pad=pad, relu=relu, w_winograd=u)
 
 
-def _winograd_filter(conv, w_krsc, stride, pad):
-    """The Winograd-transformed filter of an eligible 3x3 layer, cached next to the KRSC filter it was made from
-    (``prepared_conv`` makes a new one per parameter version), so the inference path does not redo the transform
-    per frame.  Only read by the library when the layer's tuned plan is a Winograd plan."""
+def _winograd_filter(conv, w_krsc, nhw, stride, pad):
+    """The Winograd-transformed filter U of an eligible 3x3 layer, cached next to the KRSC filter it was made from
+    (``prepared_conv`` makes a new one per parameter version), so the inference path does not redo the transform per frame.
+    U (1.78x the filter) is only built - and only kept - for a layer whose plan reads it (``ops.winograd_filter_wanted``: a
+    cached Winograd plan, forced Winograd, or a shape the autotuner is about to time); under set_conv_algo(1) or an
+    implicit-GEMM plan nothing is transformed or held.  A cache miss inside a stream capture would launch the transform
+    into the graph and pin a graph-pool tensor on the module: it raises instead (run one eager frame first)."""
     k, r, s, c = w_krsc.shape
-    if not ops.winograd_eligible(k, r, s, c, stride, pad):
+    n, h, w = nhw
+    if not ops.winograd_filter_wanted(n, h, w, c, k, r, s, stride, pad):
+        conv.__dict__.pop('_frcnn_winograd', None)
         return None
     cache = conv.__dict__.get('_frcnn_winograd')
     if cache is not None and cache[0] is w_krsc:
         return cache[1]
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("Winograd filter of a %dx%dx3x3 layer is not prepared: run an eager frame before capturing" % (k, c))
     u = ops.winograd_filter(w_krsc)
     conv.__dict__['_frcnn_winograd'] = (w_krsc, u)
     return u

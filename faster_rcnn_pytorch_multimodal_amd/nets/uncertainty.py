@@ -33,6 +33,9 @@ from .hip_modules import pad4
 # ---- reconstruction constants (the missing network.py) ---------------------------------------------------------------
 UC_FC1_DIVISOR = 2                 # *_fc1: fc7 -> fc7 / 2; *_fc2: fc7 / 2 -> _det_net_channels (= fc7 / 4)
 CLS_VAR_IS_LOG = True              # cls_al_var_net predicts log-variances like the box head ("x = log(bbox_var)", test.py:82)
+E_BBOX_INV_INPUT_IS_STD = True     # EN_BBOX_EPISTEMIC_INV_TRANSFORM: lidar_3d_uncertainty_transform_inv receives sqrt(e_bbox_var)
+                                   # (it scales by box sizes, takes exp(u) - 1 and squares: a standard-deviation-like input);
+                                   # the call site lived in the missing network.py
 BBOX_VAR_ON_DENORMALISED = True    # both box variances describe deltas * STDS + MEANS (what bbox_transform_inv consumes):
                                    # e_bbox_var = variance over the T passes, a_bbox_var = exp(log-variance) * STDS^2
 UNCERTAINTY_ORDER = ('a_entropy', 'a_mutual_info', 'a_cls_var', 'e_entropy', 'e_mutual_info', 'e_cls_var',
@@ -56,8 +59,13 @@ def check_flags():
                                   "CLIs (tools/test_net.py:203-204): with one of them both heads read _det_net_channels = "
                                   "fc7/4 features but only one branch has the layers that produce them")
     if u.EN_BBOX_EPISTEMIC_INV_TRANSFORM:
-        raise NotImplementedError("cfg.UC.EN_BBOX_EPISTEMIC_INV_TRANSFORM: uncertainty_transform_inv "
-                                  "(lib/model/bbox_transform.py:107-130) is only called from the missing network.py")
+        if not u.EN_BBOX_EPISTEMIC:
+            raise NotImplementedError("cfg.UC.EN_BBOX_EPISTEMIC_INV_TRANSFORM transforms the epistemic box variance: it needs "
+                                      "cfg.UC.EN_BBOX_EPISTEMIC")
+        if cfg.NET_TYPE != 'lidar':
+            raise NotImplementedError("cfg.UC.EN_BBOX_EPISTEMIC_INV_TRANSFORM with the image detector: uncertainty_transform_inv "
+                                      "(lib/model/bbox_transform.py:107-130) reads 7-element rows [x,y,z,l,w,h,ry] "
+                                      "(columns 0::7, 1::7, 3::7, 4::7); the image head predicts 4 elements per class")
 
 
 def num_uncertainty_pos(num_classes, bbox_elem):
@@ -206,6 +214,11 @@ def classify_test(net, fc7, rois):
     if u.EN_BBOX_EPISTEMIC:
         var = ops.mc_bbox_var(box_s.contiguous()) if tb > 1 else torch.zeros((r, k * e), dtype=torch.float32, device=fc7.device)
         unc['e_bbox_var'] = var * stds * stds if BBOX_VAR_ON_DENORMALISED else var
+        if u.EN_BBOX_EPISTEMIC_INV_TRANSFORM:
+            # variance of the deltas -> variance-like terms in box space (lib/model/bbox_transform.py:132-169)
+            unc['e_bbox_var'] = ops.uncertainty_transform_inv(rois[:, 1:5].contiguous(), unc['e_bbox_var'].contiguous(),
+                                                              net._predictions['roi_anchors_3d'], net._frame_scale, lidar=True,
+                                                              input_is_variance=E_BBOX_INV_INPUT_IS_STD)
     deltas = (bbox_pred * stds + means).contiguous()
     if lidar:
         pred_boxes = ops.lidar_bbox_transform_inv(rois[:, 1:5].contiguous(), net._predictions['roi_anchors_3d'], deltas,

@@ -43,13 +43,38 @@ def _workspace(nbytes, device):
 def set_conv_autotune(enable):
     """Turn the convolution plan autotuner on/off (frcnn_conv2d_set_autotune): tune during eager warm-up frames,
     the cached plans are then used inside captured graphs."""
+    global _CONV_AUTOTUNE
     _hip.check(_hip.load().frcnn_conv2d_set_autotune(int(bool(enable))), "frcnn_conv2d_set_autotune")
+    _CONV_AUTOTUNE = bool(enable)
 
 
 def set_conv_algo(mode):
     """0 = the autotuner may choose Winograd F(2x2, 3x3) for the eligible 3x3 layers, 1 = implicit GEMM only,
     2 = Winograd wherever it applies (frcnn_conv2d_set_algo)."""
+    global _CONV_ALGO_MODE
     _hip.check(_hip.load().frcnn_conv2d_set_algo(int(mode)), "frcnn_conv2d_set_algo")
+    _CONV_ALGO_MODE = int(mode)
+
+
+_CONV_ALGO_MODE = 0
+_CONV_AUTOTUNE = False
+
+
+def conv_plan_algo(n, h, w, c, k, r, s, stride, pad, has_residual=False):
+    """Form of the cached plan of this forward shape: -1 none, 0 implicit GEMM, 1 Winograd (frcnn_conv2d_plan_algo)."""
+    return int(_hip.load().frcnn_conv2d_plan_algo(n, h, w, c, k, r, s, stride, pad, int(bool(has_residual))))
+
+
+def winograd_filter_wanted(n, h, w, c, k, r, s, stride, pad):
+    """Whether a residual-free call of this shape can read a pre-transformed Winograd filter NOW: its cached plan is a
+    Winograd plan, or Winograd is forced (algo mode 2), or the shape is about to be tuned (autotune on, no plan yet: the tuner
+    times the Winograd form too)."""
+    if _CONV_ALGO_MODE == 1 or not winograd_eligible(k, r, s, c, stride, pad):
+        return False
+    if _CONV_ALGO_MODE == 2:
+        return True
+    algo = conv_plan_algo(n, h, w, c, k, r, s, stride, pad, False)
+    return algo == 1 or (algo < 0 and _CONV_AUTOTUNE)
 
 
 def conv_profile_begin():
@@ -304,6 +329,25 @@ def lidar_bbox_transform_inv(rois, anchors_3d, deltas, scale=None):
     _hip.check(lib.frcnn_lidar_bbox_transform_inv(_ptr(rois), rois.shape[1], _ptr(anchors_3d), _ptr(deltas), n, k,
                                                   float(scale) if scale is not None else 0.0, _ptr(out), _stream()),
                "frcnn_lidar_bbox_transform_inv")
+    return out
+
+
+def uncertainty_transform_inv(rois, uncertainty, anchors_3d=None, scale=None, lidar=False, input_is_variance=False):
+    """uncertainty (N, 7K) of the 7-element deltas -> squared box-space terms: (N, 4K) [x,y,l,w] (lidar False) or (N, 7K)."""
+    lib = _hip.load()
+    _dev_f32(rois, "rois"); _dev_f32(uncertainty, "uncertainty")
+    n = rois.shape[0]
+    if uncertainty.shape[0] != n or uncertainty.shape[1] % 7:
+        raise _hip.HipError("uncertainty_transform_inv: uncertainty must be (N, 7K), got %s" % (tuple(uncertainty.shape),))
+    k = uncertainty.shape[1] // 7
+    out = torch.empty((n, (7 if lidar else 4) * k), dtype=torch.float32, device=rois.device)
+    if lidar:
+        _dev_f32(anchors_3d, "anchors_3d")
+    if n:
+        _hip.check(lib.frcnn_uncertainty_transform_inv(_ptr(rois), rois.shape[1], _ptr(anchors_3d) if lidar else None,
+                                                       _ptr(uncertainty), n, k, float(scale) if scale is not None else 0.0,
+                                                       1 if lidar else 0, 1 if input_is_variance else 0, _ptr(out), _stream()),
+                   "frcnn_uncertainty_transform_inv")
     return out
 
 

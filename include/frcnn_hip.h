@@ -79,6 +79,11 @@ int frcnn_conv2d_set_tile(int tm, int tn);
  * frcnn_conv2d_fwd_ws_bytes returns room for the largest candidate of a not-yet-tuned shape.  Default: off (the
  * analytic model picks).  frcnn_conv2d_bwd_weight follows the same switch with its own cache (tile 128x128 or 64x64 x
  * pixel splits).  frcnn_conv2d_clear_plans forgets both caches. */
+/* Form of the cached (tuned or imported) plan of a stride-1-output forward call of this shape: -1 none, 0 implicit GEMM,
+ * 1 Winograd F(2x2,3x3).  Calls with and without a residual operand are planned separately.  Callers that keep a
+ * pre-transformed Winograd filter (frcnn_conv2d_fwd_pre) use this to build it only for layers whose plan reads it. */
+int frcnn_conv2d_plan_algo(int n, int h, int w, int c, int k, int r, int s, int stride, int pad, int has_residual);
+
 /* Per-dispatch timing of the kernels frcnn_conv2d_fwd launches (the main implicit-GEMM kernel and, for a split-K
  * plan, the second pass): between _begin and _end every launch gets its own start / stop HIP events on the launch stream
  * (hipExtLaunchKernelGGL), i.e. the begin -> end time of that dispatch.  _end synchronises and fills, per dispatch in
@@ -177,6 +182,14 @@ int frcnn_clip_boxes(const float* boxes, int num_boxes, const float* info_host, 
  * are [x1,y1,x2,y2]; anchors_3d (n,7); deltas/out (n, 7*num_classes); scale <= 0 = None. */
 int frcnn_lidar_bbox_transform_inv(const float* rois, int roi_ld, const float* anchors_3d, const float* deltas,
                                    int n, int num_classes, float scale, float* out, void* stream);
+
+/* uncertainty_transform_inv (lidar == 0) / lidar_3d_uncertainty_transform_inv (lidar != 0), lib/model/bbox_transform.py:
+ * 107-130 / 132-169: uncertainty (n, 7K) of the deltas [x,y,z,l,w,h,ry] -> squared box-space terms, out (n, 4K) [x,y,l,w]
+ * or (n, 7K).  rois (n rows, first 4 = BEV [x1,y1,x2,y2], divided by scale when scale > 0), anchors_3d (n,7) supplies the
+ * height of the z term (may be NULL when lidar == 0).  input_is_variance != 0: the square root of every input element is
+ * taken first (Monte-Carlo variances -> standard deviations). */
+int frcnn_uncertainty_transform_inv(const float* rois, int roi_ld, const float* anchors_3d, const float* uncertainty, int n,
+                                    int num_classes, float scale, int lidar, int input_is_variance, float* out, void* stream);
 
 /* scores.sort(descending=True)[:top_n] (proposal_layer.py:39-42) with the canonical total order
  * (score desc, index asc).  order_out[top_n] int64 source indices, scores_out[top_n];

@@ -628,6 +628,30 @@ def lidar_3d_bbox_transform_inv(rois, boxes, deltas, scales=None):
     return torch.cat([p.unsqueeze(2) for p in parts], 2).view(len(boxes), -1)
 
 
+def uncertainty_transform_inv(boxes, deltas, uncertainty, scales=None):
+    """bbox_transform.py:107-130 with the per-box scaling the function means (upstream multiplies (N,K) by (N,) without
+    unsqueeze(1), which is per-box only for N == 1; pinned one box per call by tests/golden/uc_inv.npz)."""
+    if scales is not None:
+        boxes = boxes / scales
+    ln = (boxes[:, 2] - boxes[:, 0] + 1).unsqueeze(1)
+    wd = (boxes[:, 3] - boxes[:, 1] + 1).unsqueeze(1)
+    parts = [uncertainty[:, 0::7] * ln, uncertainty[:, 1::7] * wd, torch.exp(uncertainty[:, 3::7]) - 1,
+             torch.exp(uncertainty[:, 4::7]) - 1]
+    return torch.pow(torch.cat([p.unsqueeze(2) for p in parts], 2).view(len(boxes), -1), 2)
+
+
+def lidar_3d_uncertainty_transform_inv(rois, boxes, deltas, uncertainty, scales=None):
+    """bbox_transform.py:132-169."""
+    if scales is not None:
+        rois = rois / scales
+    ln = (rois[:, 2] - rois[:, 0] + 1).unsqueeze(1)
+    wd = (rois[:, 3] - rois[:, 1] + 1).unsqueeze(1)
+    ht = boxes[:, 5].unsqueeze(1)
+    u = [uncertainty[:, i::7] for i in range(7)]
+    parts = [u[0] * ln, u[1] * wd, u[2] * ht, torch.exp(u[3]) - 1, torch.exp(u[4]) - 1, torch.exp(u[5]) - 1, u[6]]
+    return torch.pow(torch.cat([p.unsqueeze(2) for p in parts], 2).view(len(boxes), -1), 2)
+
+
 def lidar_extents():
     return [LIDAR_X_RANGE[0], LIDAR_Y_RANGE[0], LIDAR_Z_RANGE[0], LIDAR_X_RANGE[1], LIDAR_Y_RANGE[1], LIDAR_Z_RANGE[1]]
 

@@ -261,3 +261,19 @@ def test_uncertainty_statistics_and_aleatoric_loss_match_reference(golden_dir):
     loss.backward()
     np.testing.assert_array_equal(p.grad.numpy(), z["sl1_al_dpred"])
     np.testing.assert_array_equal(v.grad.numpy(), z["sl1_al_dvar"])
+
+
+def test_uncertainty_inverse_transforms_pinned(golden_dir):
+    """O.uncertainty_transform_inv / O.lidar_3d_uncertainty_transform_inv equal the imported reference bit for bit
+    (lib/model/bbox_transform.py:107-169); the image form's missing unsqueeze is pinned as well: with N == K == 2 boxes the
+    reference scales class j by the size of BOX j."""
+    import os
+    z = np.load(os.path.join(golden_dir, "uc_inv.npz"))
+    r, a, d, u = [torch.from_numpy(z[k]) for k in ("rois", "anchors", "deltas", "uc")]
+    for tag, sc in (("", None), ("_scale0.5", 0.5)):
+        np.testing.assert_array_equal(O.lidar_3d_uncertainty_transform_inv(r, a, d, u, sc).numpy(), z["lidar" + tag])
+        np.testing.assert_array_equal(O.uncertainty_transform_inv(r, d, u, sc).numpy(), z["bev" + tag])
+    q = z["bev_quirk_n2"]                     # what the reference returns for two boxes at once
+    ln = z["rois"][:2, 2] - z["rois"][:2, 0] + 1
+    np.testing.assert_allclose(q[:, 0::4], (z["uc"][:2, 0::7] * ln[None, :]) ** 2, rtol=1e-6)      # box j, not box i
+    assert not np.allclose(q, z["bev"][:2])

@@ -205,8 +205,44 @@ def test_lidar_detector_uncertainty_heads_against_oracle(hip):
         for k, v in unc_r.items():
             tol = 2e-5 * max(1.0, float(np.abs(v.numpy()).max()))
             np.testing.assert_allclose(unc[k].cpu().numpy(), v.numpy(), rtol=1e-4, atol=tol, err_msg=k)
+        # cfg.UC.EN_BBOX_EPISTEMIC_INV_TRANSFORM (lib/model/config.py:42): the same frame and draws, e_bbox_var carried to
+        # box space by lidar_3d_uncertainty_transform_inv (lib/model/bbox_transform.py:132-169) on sqrt(variance)
+        C.cfg.UC.EN_BBOX_EPISTEMIC_INV_TRANSFORM = True
+        net.set_uc_seed(5)
+        net.set_e_num_sample(10)
+        _, _, _, rois2, unc2 = net.test_frame(data, info)
+        net.set_e_num_sample(1)
+        assert torch.equal(rois2, rois)
+        a3 = net._predictions["roi_anchors_3d"][:n].cpu()
+        want = O.lidar_3d_uncertainty_transform_inv(rois[:, 1:5].cpu(), a3, None, torch.sqrt(unc["e_bbox_var"].cpu()), 0.5)
+        np.testing.assert_allclose(unc2["e_bbox_var"].cpu().numpy(), want.numpy(), rtol=2e-5, atol=1e-9)
+        assert not torch.equal(unc2["e_bbox_var"], unc["e_bbox_var"])
+        for k in unc:
+            if k != "e_bbox_var":
+                assert torch.equal(unc2[k], unc[k]), k
     finally:
         C.reset_cfg()
+
+
+def test_uncertainty_inverse_transforms_match_reference_vectors(hip, golden_dir):
+    """model.bbox_transform.uncertainty_transform_inv / lidar_3d_uncertainty_transform_inv (lib/model/bbox_transform.py:
+    107-130, 132-169) against vectors produced by the imported reference (tests/golden/make_golden_uc_inv.py)."""
+    import os
+    from faster_rcnn_pytorch_multimodal_amd.model.bbox_transform import (lidar_3d_uncertainty_transform_inv,
+                                                                         uncertainty_transform_inv)
+    z = np.load(os.path.join(golden_dir, "uc_inv.npz"))
+    dev = "cuda:0"
+    r, a, d, u = [torch.from_numpy(z[k]).to(dev) for k in ("rois", "anchors", "deltas", "uc")]
+    for tag, sc in (("", None), ("_scale0.5", 0.5)):
+        got = lidar_3d_uncertainty_transform_inv(r, a, d, u, sc).cpu().numpy()
+        np.testing.assert_allclose(got, z["lidar" + tag], rtol=3e-6, atol=1e-9)
+        got = uncertainty_transform_inv(r, d, u, sc).cpu().numpy()
+        np.testing.assert_allclose(got, z["bev" + tag], rtol=3e-6, atol=1e-9)
+    # the variance-input form used by the detector: sqrt first
+    got = lidar_3d_uncertainty_transform_inv(r, a, d, u, None).cpu().numpy()
+    from faster_rcnn_pytorch_multimodal_amd import ops
+    got_v = ops.uncertainty_transform_inv(r, (u * u).contiguous(), a, None, lidar=True, input_is_variance=True).cpu().numpy()
+    np.testing.assert_allclose(got_v, got, rtol=2e-6, atol=1e-9)
 
 
 def test_flag_combinations_the_snapshot_does_not_define_are_rejected(hip):
