@@ -38,6 +38,7 @@ PROTOTYPES = {
     "frcnn_conv2d_bwd_data": (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
     "frcnn_conv2d_bwd_weight_ws_bytes": (c_size_t, [c_int] * 9),
     "frcnn_conv2d_bwd_weight": (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
+    "frcnn_conv2d_bwd_weight_acc": (c_int, [_P, _P, _P, c_int, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
     "frcnn_maxpool3x3s2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "frcnn_maxpool3x3s2_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "frcnn_pad_channels": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
@@ -106,12 +107,12 @@ PROTOTYPES = {
     "frcnn_bbox_overlaps": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, _P]),
     "frcnn_anchor_target_layer_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "frcnn_anchor_target_layer": (c_int, [_P, c_int, _P, c_int, POINTER(c_float), c_int, c_float, c_float, c_float,
-                                          c_uint32, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+                                          c_uint32, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "frcnn_proposal_target_layer": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_float, c_float, c_float,
-                                            c_float, POINTER(c_float), POINTER(c_float), c_uint32, _P, _P, _P, _P, _P,
+                                            c_float, POINTER(c_float), POINTER(c_float), c_uint32, _P, _P, _P, _P, _P, _P,
                                             _P, _P, _P, _P, _P]),
     "frcnn_proposal_target_layer_lidar": (c_int, [_P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_float, c_float,
-                                                  c_float, c_float, POINTER(c_float), POINTER(c_float), c_uint32, _P, _P,
+                                                  c_float, c_float, POINTER(c_float), POINTER(c_float), c_uint32, _P, _P, _P,
                                                   _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "frcnn_filter_per_class_ws_bytes": (c_size_t, [c_int, c_int]),
     "frcnn_filter_per_class": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int,

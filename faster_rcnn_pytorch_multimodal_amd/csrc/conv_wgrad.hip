@@ -162,6 +162,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // db[k] = sum_m dy[m][k] in two deterministic passes: BIAS_GROUPS x (K/64) workgroups sum interleaved pixel
 // subsets (4 waves each) into partial[g][k], then one pass adds the groups in g order.
 constexpr int BIAS_GROUPS = 64;
+// Slab sum + layout change + accumulation in one pass: grad (K, c_real, R, S) - a Conv2d / Linear parameter's own layout -
+// += sum_z slabs[z] (K, R, S, C) restricted to the real channels.  One thread per OUTPUT element (coalesced read-modify-write of
+// the gradient); the slab reads stride by C floats (small tensors).  z ascending: deterministic.
+__global__ __launch_bounds__(256) void wgrad_accumulate_kernel(const float* __restrict__ slabs, int splits, int K, int R, int S,
+                                                              int C, int c_real, float* __restrict__ grad) {
+  const size_t total = (size_t)K * c_real * R * S, slab = (size_t)K * R * S * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int s = (int)(i % S);
+    size_t t = i / S;
+    const int r = (int)(t % R);
+    t /= R;
+    const int c = (int)(t % c_real);
+    const int k = (int)(t / c_real);
+    const size_t src = (((size_t)k * R + r) * S + s) * C + c;
+    float v = slabs[src];
+    for (int z = 1; z < splits; ++z) v += slabs[(size_t)z * slab + src];
+    grad[i] += v;
+  }
+}
+
+__global__ __launch_bounds__(256) void bias_grad_accumulate_kernel(const float* __restrict__ partial, int K, int groups,
+                                                                  float* __restrict__ db) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  float v = 0.f;
+  for (int g = 0; g < groups; ++g) v += partial[(size_t)g * K + k];
+  db[k] += v;
+}
+
 __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __restrict__ dy, int M, int K,
                                                                float* __restrict__ partial) {
   __shared__ float part[4][64];
@@ -261,18 +290,18 @@ size_t slab_bytes_of(const WgradPlan& pl, int k, int q) {
 }
 
 // main kernel + the slab reduction of one plan
-int launch_wgrad(WgradParams p, const WgradPlan& pl, float* dw, void* ws, hipStream_t stream) {
+int launch_wgrad(WgradParams p, const WgradPlan& pl, float* dw, void* ws, hipStream_t stream, bool slabs_only = false) {
   const int bt = 64 * pl.ti;
   p.tiles_k = (p.K + bt - 1) / bt;
   p.tiles_q = (p.Q + bt - 1) / bt;
   p.steps_per_split = (p.steps + pl.splits - 1) / pl.splits;
-  p.out = pl.splits > 1 ? static_cast<float*>(ws) : dw;
+  p.out = (pl.splits > 1 || slabs_only) ? static_cast<float*>(ws) : dw;   // slabs_only: the caller reduces the slab(s) itself
   const dim3 grid(p.tiles_k * p.tiles_q, 1, pl.splits);
   if (pl.ti == 2) hipLaunchKernelGGL(conv_wgrad_f32<2>, grid, dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(conv_wgrad_f32<1>, grid, dim3(256), 0, stream, p);
   int rc = frcnn::check_launch("conv_wgrad_f32");
   if (rc != FRCNN_OK) return rc;
-  if (pl.splits > 1) {
+  if (pl.splits > 1 && !slabs_only) {
     const size_t n4 = (size_t)p.K * p.Q / 4;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0,
                        stream, static_cast<const float*>(ws), pl.splits, n4, dw);
@@ -331,7 +360,9 @@ extern "C" size_t frcnn_conv2d_bwd_weight_ws_bytes(int n, int h, int w, int c, i
     pl = WgradPlan{2, choose_splits(tiles_for(k, q, 2), steps, 2)};
     slabs = slab_bytes_of(pl, k, q);
   }
-  // slabs (when the pixel range is split) + the bias-gradient partials
+  // slabs (when the pixel range is split; at least one, which frcnn_conv2d_bwd_weight_acc reduces from) + the
+  // bias-gradient partials
+  slabs = std::max(slabs, (size_t)k * q * sizeof(float));
   return frcnn::align_up(slabs, 256) + (size_t)BIAS_GROUPS * k * sizeof(float);
 }
 
@@ -381,4 +412,45 @@ extern "C" int frcnn_conv2d_bwd_weight(const float* x, const float* dy, float* d
     rc = frcnn::check_launch("bias_grad_final_kernel");
   }
   return rc;
+}
+
+extern "C" int frcnn_conv2d_bwd_weight_acc(const float* x, const float* dy, float* grad_w, int c_real, float* grad_b, int n,
+                                           int h, int w, int c, int k, int r, int s, int stride, int pad, void* ws,
+                                           size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FRCNN_REQUIRE(x && dy && grad_w && c_real > 0 && c_real <= c, "conv2d_bwd_weight_acc: null tensor or c_real out of range");
+  FRCNN_REQUIRE(wgrad_args_ok(n, h, w, c, k, r, s, stride, pad),
+                "conv2d_bwd_weight_acc: bad shape n=%d h=%d w=%d c=%d k=%d r=%d s=%d stride=%d pad=%d (need c%%4==0, k%%4==0)",
+                n, h, w, c, k, r, s, stride, pad);
+  WgradParams p;
+  p.x = x; p.dy = dy; p.out = nullptr;
+  p.H = h; p.W = w; p.C = c; p.K = k; p.R = r; p.S = s; p.stride = stride; p.pad = pad;
+  p.Ho = (h + 2 * pad - r) / stride + 1;
+  p.Wo = (w + 2 * pad - s) / stride + 1;
+  const long M = (long)n * p.Ho * p.Wo;
+  FRCNN_REQUIRE(M * (long)k < (1L << 31) && (long)n * h * w * c < (1L << 31), "conv2d_bwd_weight_acc: tensor too large");
+  p.M = (int)M;
+  p.Q = r * s * c;
+  p.steps = (p.M + BR - 1) / BR;
+  p.steps_per_split = p.steps; p.tiles_k = p.tiles_q = 0;
+  const size_t bias_bytes = grad_b ? (size_t)BIAS_GROUPS * k * sizeof(float) : 0;
+  WgradPlan pl;
+  if (!lookup_wgrad(wgrad_key(n, h, w, c, k, r, s, stride, pad), &pl))
+    pl = WgradPlan{2, choose_splits(tiles_for(k, p.Q, 2), p.steps, 2)};      // plans are tuned by frcnn_conv2d_bwd_weight
+  const size_t slab_bytes = frcnn::align_up(std::max(slab_bytes_of(pl, k, p.Q), (size_t)k * p.Q * sizeof(float)), 256);
+  if (!ws || ws_bytes < slab_bytes + bias_bytes)
+    return frcnn::fail(FRCNN_ERR_WS, "conv2d_bwd_weight_acc: workspace %zu < %zu bytes", ws_bytes, slab_bytes + bias_bytes);
+  int rc = launch_wgrad(p, pl, nullptr, ws, stream, true);
+  if (rc != FRCNN_OK) return rc;
+  const size_t total = (size_t)k * c_real * r * s;
+  hipLaunchKernelGGL(wgrad_accumulate_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0,
+                     stream, static_cast<const float*>(ws), pl.splits, k, r, s, c, c_real, grad_w);
+  rc = frcnn::check_launch("wgrad_accumulate_kernel");
+  if (rc != FRCNN_OK || !grad_b) return rc;
+  float* partial = reinterpret_cast<float*>(static_cast<char*>(ws) + slab_bytes);
+  hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((k + 63) / 64, BIAS_GROUPS), dim3(256), 0, stream, dy, p.M, k, partial);
+  rc = frcnn::check_launch("bias_grad_partial_kernel");
+  if (rc != FRCNN_OK) return rc;
+  hipLaunchKernelGGL(bias_grad_accumulate_kernel, dim3((k + 255) / 256), dim3(256), 0, stream, partial, k, BIAS_GROUPS, grad_b);
+  return frcnn::check_launch("bias_grad_accumulate_kernel");
 }

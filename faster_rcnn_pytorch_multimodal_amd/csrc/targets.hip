@@ -57,12 +57,20 @@ struct AtlFrame {
   float x_lo, x_hi, y_lo, y_hi;  // inside test: x1 >= x_lo, y1 >= y_lo, x2 < x_hi, y2 < y_hi  (:37-42)
 };
 
+constexpr int ATL_MAX_GT_LDS = 512;
+
 __global__ __launch_bounds__(256) void atl_overlap_kernel(const float* __restrict__ anchors, int n,
                                                          const float* __restrict__ gt, int g, AtlFrame fr,
                                                          float* __restrict__ max_ov, int* __restrict__ argmax,
                                                          unsigned* __restrict__ gt_max) {
-  // every lane of a wave runs the same number of iterations so the per-gt maxima can be reduced with wave
-  // shuffles before ONE atomicMax per wave and gt box (a per-lane atomic serialises ~10^6 anchors on G addresses)
+  // Per-gt maxima: a wave reduces with shuffles only when one of its anchors overlaps the gt box at all (most waves of a
+  // 10^6-anchor pyramid level do not), wave leaders merge into an LDS table, and each workgroup issues ONE global atomicMax
+  // per gt box at its end (a per-wave global atomic was 117 K same-address atomics for 937 500 anchors x 8 boxes: 423 us).
+  // Every lane of a wave runs the same number of iterations (the ballot / shuffles need all lanes).
+  __shared__ unsigned s_gmax[ATL_MAX_GT_LDS];
+  const bool use_lds = g <= ATL_MAX_GT_LDS;
+  for (int j = threadIdx.x; j < g && use_lds; j += blockDim.x) s_gmax[j] = 0u;
+  __syncthreads();
   const int stride = gridDim.x * blockDim.x;
   const int iters = (n + stride - 1) / stride;
   for (int it = 0; it < iters; ++it) {
@@ -79,25 +87,33 @@ __global__ __launch_bounds__(256) void atl_overlap_kernel(const float* __restric
     for (int j = 0; j < g; ++j) {
       const float ov = inside ? iou_plus1(a, gt + (size_t)j * 5) : 0.f;
       if (inside && ov > best) { best = ov; arg = j; }      // first maximum, like argmax(dim=1)
+      if (__ballot(ov > 0.f) == 0ull) continue;             // wave-uniform
       float wmax = ov;
       for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
-      if ((threadIdx.x & 63) == 0 && wmax > 0.f)
-        atomicMax(gt_max + j, __float_as_uint(wmax));       // ov >= 0: the bit pattern orders like the value
+      if ((threadIdx.x & 63) == 0) {                        // ov >= 0: the bit pattern orders like the value
+        if (use_lds) atomicMax(&s_gmax[j], __float_as_uint(wmax));
+        else atomicMax(gt_max + j, __float_as_uint(wmax));
+      }
     }
     if (live) {
       max_ov[i] = inside ? best : -1.f;                     // -1 marks an anchor outside the frame
       argmax[i] = arg;
     }
   }
+  __syncthreads();
+  for (int j = threadIdx.x; j < g && use_lds; j += blockDim.x)
+    if (s_gmax[j] > 0u) atomicMax(gt_max + j, s_gmax[j]);
 }
 
 __global__ __launch_bounds__(256) void atl_label_kernel(const float* __restrict__ anchors, int n,
                                                        const float* __restrict__ gt, int g,
                                                        const float* __restrict__ max_ov,
                                                        const unsigned* __restrict__ gt_max, float neg_ov, float pos_ov,
-                                                       uint32_t seed, float* __restrict__ labels,
+                                                       uint32_t seed, const uint32_t* __restrict__ seed_dev,
+                                                       float* __restrict__ labels,
                                                        float* __restrict__ key_fg, float* __restrict__ key_bg,
                                                        int* __restrict__ counters) {
+  if (seed_dev) seed += *seed_dev;      // per-step seed from device memory (a replayed hipGraph keeps `seed` itself)
   const float eps = 1.1920929e-07f;  // torch.finfo(float32).eps (:62)
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float mo = max_ov[i];
@@ -106,8 +122,8 @@ __global__ __launch_bounds__(256) void atl_label_kernel(const float* __restrict_
       if (mo < neg_ov) lab = 0.f;                          // :66-69 (RPN_CLOBBER_POSITIVES off)
       const float4 a4 = reinterpret_cast<const float4*>(anchors)[i];
       const float a[4] = {a4.x, a4.y, a4.z, a4.w};
-      for (int j = 0; j < g; ++j) {                        // :63,73: every anchor tying a gt's best overlap
-        const float gm = fmaxf(__uint_as_float(gt_max[j]), eps);
+      for (int j = 0; j < g && mo > 0.f; ++j) {            // :63,73: every anchor tying a gt's best overlap
+        const float gm = fmaxf(__uint_as_float(gt_max[j]), eps);   // (gm >= eps > 0: an anchor without any overlap ties nothing)
         if (iou_plus1(a, gt + (size_t)j * 5) == gm) { lab = 1.f; break; }
       }
       if (mo >= pos_ov) lab = 1.f;                         // :78
@@ -204,11 +220,13 @@ __global__ __launch_bounds__(PTL_THREADS) void ptl_kernel(const float* __restric
                                                          float* __restrict__ out_anchors3d,
                                                          const float* __restrict__ gt, int g, int num_classes,
                                                          int rois_per_frame, int fg_quota, float fg_thresh, float bg_hi,
-                                                         float bg_lo, PtlNorm norm, uint32_t seed, int npad,
+                                                         float bg_lo, PtlNorm norm, uint32_t seed,
+                                                         const uint32_t* __restrict__ seed_dev, int npad,
                                                          float* __restrict__ out_labels, float* __restrict__ out_rois,
                                                          float* __restrict__ out_scores, float* __restrict__ out_targets,
                                                          float* __restrict__ out_inside, float* __restrict__ out_outside,
                                                          int* __restrict__ out_assign, int* __restrict__ out_counts) {
+  if (seed_dev) seed += *seed_dev;
   extern __shared__ __attribute__((aligned(16))) unsigned char ptl_smem[];
   uint64_t* kfg = reinterpret_cast<uint64_t*>(ptl_smem);
   uint64_t* kbg = kfg + npad;
@@ -387,9 +405,9 @@ extern "C" size_t frcnn_anchor_target_layer_ws_bytes(int num_anchors_total, int 
 
 extern "C" int frcnn_anchor_target_layer(const float* anchors, int n, const float* gt_boxes, int num_gt,
                                          const float* info_host, int rpn_batchsize, float fg_fraction,
-                                         float negative_overlap, float positive_overlap, uint32_t seed, float* labels,
-                                         float* targets, float* inside, float* outside, int* counts, void* ws,
-                                         size_t ws_bytes, void* stream_) {
+                                         float negative_overlap, float positive_overlap, uint32_t seed,
+                                         const uint32_t* seed_dev, float* labels, float* targets, float* inside,
+                                         float* outside, int* counts, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   FRCNN_REQUIRE(anchors && gt_boxes && info_host && labels && targets && inside && outside && n > 0 && num_gt > 0 &&
                     rpn_batchsize > 0,
@@ -420,7 +438,7 @@ extern "C" int frcnn_anchor_target_layer(const float* anchors, int n, const floa
   int rc = check_launch("atl_overlap_kernel");
   if (rc != FRCNN_OK) return rc;
   hipLaunchKernelGGL(atl_label_kernel, dim3(grid), dim3(256), 0, stream, anchors, n, gt_boxes, num_gt, max_ov, gt_max,
-                     negative_overlap, positive_overlap, seed, labels, key_fg, key_bg, counters);
+                     negative_overlap, positive_overlap, seed, seed_dev, labels, key_fg, key_bg, counters);
   rc = check_launch("atl_label_kernel");
   if (rc != FRCNN_OK) return rc;
   const int num_fg_cap = (int)(fg_fraction * (float)rpn_batchsize);   // :91
@@ -454,7 +472,8 @@ int launch_ptl(const float* rois, const float* roi_scores, const int* roi_count,
                const unsigned char* skip, const float* anchors3d,
                const float* true_gt, float* out_anchors3d, const float* gt_boxes, int num_gt, int num_classes,
                int rois_per_frame, float fg_fraction, float fg_thresh, float bg_thresh_hi, float bg_thresh_lo,
-               const float* means_host, const float* stds_host, uint32_t seed, float* labels, float* out_rois,
+               const float* means_host, const float* stds_host, uint32_t seed, const uint32_t* seed_dev, float* labels,
+               float* out_rois,
                float* out_scores, float* targets, float* inside, float* outside, int* gt_assignment, int* counts,
                void* stream_) {
   PtlNorm norm;
@@ -471,7 +490,7 @@ int launch_ptl(const float* rois, const float* roi_scores, const int* roi_count,
   const int fg_quota = (int)lrintf(fg_fraction * (float)rois_per_frame);   // int(round(...)) (:44-45)
   hipLaunchKernelGGL(ptl_kernel<E>, dim3(1), dim3(PTL_THREADS), lds, static_cast<hipStream_t>(stream_), rois, roi_scores,
                      roi_count, num_rois, skip, anchors3d, true_gt, out_anchors3d, gt_boxes, num_gt, num_classes,
-                     rois_per_frame, fg_quota, fg_thresh, bg_thresh_hi, bg_thresh_lo, norm, seed, npad, labels, out_rois,
+                     rois_per_frame, fg_quota, fg_thresh, bg_thresh_hi, bg_thresh_lo, norm, seed, seed_dev, npad, labels, out_rois,
                      out_scores, targets, inside, outside, gt_assignment, counts);
   return check_launch("ptl_kernel");
 }
@@ -481,7 +500,8 @@ extern "C" int frcnn_proposal_target_layer(const float* rois, const float* roi_s
                                            int num_rois, const float* gt_boxes, int num_gt, int num_classes,
                                            int rois_per_frame, float fg_fraction, float fg_thresh, float bg_thresh_hi,
                                            float bg_thresh_lo, const float* means_host, const float* stds_host,
-                                           uint32_t seed, float* labels, float* out_rois, float* out_scores,
+                                           uint32_t seed, const uint32_t* seed_dev, float* labels, float* out_rois,
+                                           float* out_scores,
                                            float* targets, float* inside, float* outside, int* gt_assignment,
                                            int* counts, const unsigned char* skip_mask, void* stream_) {
   FRCNN_REQUIRE(rois && gt_boxes && means_host && stds_host && labels && out_rois && out_scores && targets && inside &&
@@ -489,7 +509,7 @@ extern "C" int frcnn_proposal_target_layer(const float* rois, const float* roi_s
                     num_classes > 1 && rois_per_frame > 0,
                 "proposal_target_layer: bad arguments (num_rois <= 4096, at least one gt box)");
   return launch_ptl<4>(rois, roi_scores, roi_count, num_rois, skip_mask, nullptr, nullptr, nullptr, gt_boxes, num_gt, num_classes,
-                       rois_per_frame, fg_fraction, fg_thresh, bg_thresh_hi, bg_thresh_lo, means_host, stds_host, seed,
+                       rois_per_frame, fg_fraction, fg_thresh, bg_thresh_hi, bg_thresh_lo, means_host, stds_host, seed, seed_dev,
                        labels, out_rois, out_scores, targets, inside, outside, gt_assignment, counts, stream_);
 }
 
@@ -498,7 +518,8 @@ extern "C" int frcnn_proposal_target_layer_lidar(const float* rois, const float*
                                                  const float* true_gt_boxes, int num_gt, int num_classes,
                                                  int rois_per_frame, float fg_fraction, float fg_thresh,
                                                  float bg_thresh_hi, float bg_thresh_lo, const float* means_host,
-                                                 const float* stds_host, uint32_t seed, float* labels, float* out_rois,
+                                                 const float* stds_host, uint32_t seed, const uint32_t* seed_dev,
+                                                 float* labels, float* out_rois,
                                                  float* out_scores, float* out_anchors3d, float* targets, float* inside,
                                                  float* outside, int* gt_assignment, int* counts,
                                                  const unsigned char* skip_mask, void* stream_) {
@@ -508,6 +529,6 @@ extern "C" int frcnn_proposal_target_layer_lidar(const float* rois, const float*
                 "proposal_target_layer_lidar: bad arguments (num_rois <= 4096, at least one gt box)");
   return launch_ptl<7>(rois, roi_scores, roi_count, num_rois, skip_mask, anchors3d, true_gt_boxes, out_anchors3d, gt_boxes, num_gt,
                        num_classes, rois_per_frame, fg_fraction, fg_thresh, bg_thresh_hi, bg_thresh_lo, means_host,
-                       stds_host, seed, labels, out_rois, out_scores, targets, inside, outside, gt_assignment, counts,
+                       stds_host, seed, seed_dev, labels, out_rois, out_scores, targets, inside, outside, gt_assignment, counts,
                        stream_);
 }

@@ -18,7 +18,7 @@ from .anchor_target_layer import _draw_seed
 
 
 def proposal_target_layer_device(rpn_rois, rpn_scores, gt_boxes, num_classes, roi_count=None, seed=None,
-                                 anchors_3d=None, true_gt_boxes=None, gt_boxes_dc=None):
+                                 anchors_3d=None, true_gt_boxes=None, gt_boxes_dc=None, seed_dev=None):
     scores = None if rpn_scores is None else rpn_scores.contiguous().view(-1)
     if cfg.TRAIN.USE_GT:
         # proposal_target_layer.py:31-37: the gt boxes join the candidates (score 0; LiDAR: the 3-D gt box is its own
@@ -46,12 +46,13 @@ def proposal_target_layer_device(rpn_rois, rpn_scores, gt_boxes, num_classes, ro
                                          cfg.TRAIN.LIDAR.BBOX_NORMALIZE_MEANS, cfg.TRAIN.LIDAR.BBOX_NORMALIZE_STDS,
                                          _draw_seed() if seed is None else seed, roi_count=roi_count,
                                          anchors_3d=anchors_3d.contiguous(), true_gt_boxes=true_gt_boxes.contiguous(),
-                                         skip_mask=skip)
+                                         skip_mask=skip, seed_dev=seed_dev)
     return ops.proposal_target_layer(rpn_rois.contiguous(), scores, gt_boxes[:, :5].contiguous(), num_classes,
                                      cfg.TRAIN.ROI_BATCH_SIZE, cfg.TRAIN.FG_FRACTION, cfg.TRAIN.FG_THRESH,
                                      cfg.TRAIN.BG_THRESH_HI, cfg.TRAIN.BG_THRESH_LO,
                                      cfg.TRAIN.IMAGE.BBOX_NORMALIZE_MEANS, cfg.TRAIN.IMAGE.BBOX_NORMALIZE_STDS,
-                                     _draw_seed() if seed is None else seed, roi_count=roi_count, skip_mask=skip)
+                                     _draw_seed() if seed is None else seed, roi_count=roi_count, skip_mask=skip,
+                                     seed_dev=seed_dev)
 
 
 def proposal_target_layer(rpn_rois, rpn_scores, anchors_3d, gt_boxes, true_gt_boxes, gt_boxes_dc, _num_classes,

@@ -13,7 +13,7 @@ convolution output that receives no gradient.  The LiDAR backbone trains its Bat
 import torch
 
 from .. import ops
-from .hip_modules import pad4, prepared_conv
+from .hip_modules import _winograd_filter, pad4, prepared_conv, stable_store
 
 
 # Filter gradients are off the critical path of backward (only the data gradient feeds the next node), so they CAN
@@ -23,6 +23,7 @@ from .hip_modules import pad4, prepared_conv
 # the plain autograd flow.
 ASYNC_WGRAD = False
 _SIDE = {}
+_KEEP = []      # operands of side-stream launches, held until the main stream has joined the side stream
 
 
 def _side_stream(device):
@@ -37,6 +38,7 @@ def join_weight_grads(device=None):
     for key, side in _SIDE.items():
         if device is None or key == str(torch.device(device)):
             torch.cuda.current_stream(side.device).wait_stream(side)
+    _KEEP.clear()
 
 
 def _accumulate(param, grad):
@@ -58,9 +60,23 @@ def _wgrad(x, d_conv, r, s, stride, pad, targets):
     side = _side_stream(x.device)
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        dw_krsc, db = ops.conv2d_bwd_weight(x, d_conv, r, s, stride=stride, pad=pad, want_bias=want_bias)
-        for param, fn, _ in targets:
-            _accumulate(param, fn(dw_krsc, db))
+        # plain Conv2d / Linear targets ('w' [+ 'b'] of one module, gradient buffers in place): one launch chain sums the
+        # pixel-split slabs, changes the layout and adds into param.grad - no temporaries, no permute copy, no add_
+        kinds = [kind for _, _, kind in targets]
+        direct = (kinds in (['w'], ['w', 'b']) and all(p.grad is not None and p.grad.is_contiguous() for p, _, _ in targets)
+                  and targets[0][0].dim() in (2, 4) and targets[0][0].numel() == d_conv.shape[-1] * targets[0][0].shape[1] * r * s)
+        if direct:
+            ops.conv2d_bwd_weight_acc(x, d_conv, r, s, targets[0][0].grad, targets[1][0].grad if len(targets) > 1 else None,
+                                      stride=stride, pad=pad)
+        else:
+            dw_krsc, db = ops.conv2d_bwd_weight(x, d_conv, r, s, stride=stride, pad=pad, want_bias=want_bias)
+            for param, fn, _ in targets:
+                _accumulate(param, fn(dw_krsc, db))
+    # the side stream still reads x / d_conv when this function's caller drops them, and the allocator would hand their
+    # blocks to the next main-stream allocation.  Tensor.record_stream covers that in eager mode; inside a stream capture it
+    # was observed not to (run-to-run different gradients from the replayed graph), so the operands are simply kept alive
+    # until join_weight_grads() has made the main stream wait for the side stream.
+    _KEEP.append((x, d_conv))
     x.record_stream(side)
     d_conv.record_stream(side)
     return [None for _ in targets]
@@ -71,10 +87,9 @@ def _transposed_filter(conv_like, w_krsc):
     cache = conv_like.__dict__.get('_frcnn_wt')
     key = (w_krsc.data_ptr(), w_krsc._version, tuple(w_krsc.shape))
     if cache is not None and cache[0] == key:
-        return cache[1]
-    w_t = ops.conv2d_transpose_filter(w_krsc)
-    conv_like.__dict__['_frcnn_wt'] = (key, w_t)
-    return w_t
+        return cache[1][0]
+    return stable_store(conv_like, '_frcnn_wt', key, (ops.conv2d_transpose_filter(w_krsc),),
+                        refresh=lambda: _transposed_filter(conv_like, w_krsc))[0]
 
 
 def _param_grad_from_krsc(dw_krsc, param):
@@ -97,7 +112,10 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, weight, bias, pack):
         w_krsc, scale, shift, stride, pad, relu, owner = pack
-        y = ops.conv2d_nhwc(x, w_krsc, scale, shift, residual, stride=stride, pad=pad, relu=relu)
+        u = None
+        if residual is None and w_krsc.shape[1] == 3 and isinstance(owner, torch.nn.Module):
+            u = _winograd_filter(owner, w_krsc, tuple(x.shape[:3]), stride, pad)
+        y = ops.conv2d_nhwc(x, w_krsc, scale, shift, residual, stride=stride, pad=pad, relu=relu, w_winograd=u)
         ctx.pack = pack
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, y if relu else None, weight, bias)
@@ -202,11 +220,11 @@ class _PermutedLinearFn(torch.autograd.Function):
     def _prepared(lin, c, p):
         key = (lin.weight._version, lin.weight.data_ptr())
         cache = lin.__dict__.get('_frcnn_perm')
-        if cache is None or cache[0] != key:
-            w = lin.weight.detach().view(lin.out_features, c, p, p).permute(0, 2, 3, 1).reshape(lin.out_features, 1, 1, -1)
-            cache = (key, w.contiguous())
-            lin.__dict__['_frcnn_perm'] = cache
-        return cache[1]
+        if cache is not None and cache[0] == key:
+            return cache[1][0]
+        w = lin.weight.detach().view(lin.out_features, c, p, p).permute(0, 2, 3, 1).reshape(lin.out_features, 1, 1, -1)
+        return stable_store(lin, '_frcnn_perm', key, (w.contiguous(),),
+                            refresh=lambda: _PermutedLinearFn._prepared(lin, c, p))[0]
 
     @staticmethod
     def forward(ctx, x2d, weight, bias, lin, cp, relu):
@@ -227,7 +245,7 @@ class _PermutedLinearFn(torch.autograd.Function):
         d_conv = ops.act_bwd(dy4, y, None, relu=True)[0] if relu else dy4
         x4 = x2d.view(r, 1, 1, -1)
         to_w = lambda dwk, dbk: dwk.view(lin.out_features, p, p, c).permute(0, 3, 1, 2).reshape(lin.out_features, -1)
-        dw, db = _wgrad(x4, d_conv, 1, 1, 1, 0, [(lin.weight, to_w, 'w'), (lin.bias, lambda dwk, dbk: dbk, 'b')])
+        dw, db = _wgrad(x4, d_conv, 1, 1, 1, 0, [(lin.weight, to_w, 'w_perm'), (lin.bias, lambda dwk, dbk: dbk, 'b')])
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_bwd_data(d_conv, _transposed_filter(lin, w_krsc), tuple(x4.shape)).view(r, -1)
@@ -255,9 +273,9 @@ class _FusedHeadFn(torch.autograd.Function):
         k1, k2 = w1.shape[0], w2.shape[0]
         b1, b2 = ctx.biases
         dw1, db1, dw2, db2 = _wgrad(x, dy, w_krsc.shape[1], w_krsc.shape[2], 1, 0, [
-            (w1, lambda dwk, dbk: _param_grad_from_krsc(dwk[:k1], w1), 'w'),
+            (w1, lambda dwk, dbk: _param_grad_from_krsc(dwk[:k1], w1), 'w_part'),
             (b1, lambda dwk, dbk: dbk[:k1].contiguous(), 'b'),
-            (w2, lambda dwk, dbk: _param_grad_from_krsc(dwk[k1:k1 + k2], w2), 'w'),
+            (w2, lambda dwk, dbk: _param_grad_from_krsc(dwk[k1:k1 + k2], w2), 'w_part'),
             (b2, lambda dwk, dbk: dbk[k1:k1 + k2].contiguous(), 'b')])
         dx = None
         if ctx.needs_input_grad[0]:
@@ -271,7 +289,7 @@ def fused_head_weights(owner, m1, m2, cache_name):
     key = tuple((t._version, t.data_ptr()) for t in tensors)
     cache = owner.__dict__.get(cache_name)
     if cache is not None and cache[0] == key:
-        return cache[1], cache[2]
+        return cache[1]
     with torch.no_grad():
         w1 = m1.weight.detach().reshape(m1.weight.shape[0], -1)
         w2 = m2.weight.detach().reshape(m2.weight.shape[0], -1)
@@ -284,8 +302,7 @@ def fused_head_weights(owner, m1, m2, cache_name):
         b[:w1.shape[0]] = m1.bias.detach()
         b[w1.shape[0]:k] = m2.bias.detach()
         w = w.view(kp, 1, 1, -1).contiguous()
-    owner.__dict__[cache_name] = (key, w, b)
-    return w, b
+    return stable_store(owner, cache_name, key, (w, b), refresh=lambda: fused_head_weights(owner, m1, m2, cache_name))
 
 
 def fused_head_train(x, owner, m1, m2, cache_name):
@@ -323,7 +340,10 @@ class _BottleneckFn(torch.autograd.Function):
         else:
             pd, sd, identity = None, 1, x
         o1 = ops.conv2d_nhwc(x, p1[0], p1[1], p1[2], None, stride=s1, pad=0, relu=True)
-        o2 = ops.conv2d_nhwc(o1, p2[0], p2[1], p2[2], None, stride=s2, pad=1, relu=True)
+        # the 3x3 layer with its cached Winograd-transformed filter when its tuned plan reads one (re-derived only when the
+        # weights change, i.e. once per optimizer step instead of inside every call)
+        u2 = _winograd_filter(block.conv2, p2[0], tuple(o1.shape[:3]), s2, 1)
+        o2 = ops.conv2d_nhwc(o1, p2[0], p2[1], p2[2], None, stride=s2, pad=1, relu=True, w_winograd=u2)
         out = ops.conv2d_nhwc(o2, p3[0], p3[1], p3[2], identity, stride=1, pad=0, relu=True)
         ctx.block = block
         ctx.meta = (p1, p2, p3, pd, s1, s2, sd)

@@ -20,6 +20,51 @@ def pad4(c):
     return (c + 3) // 4 * 4
 
 
+def stable_store(holder, name, key, fresh, refresh=None):
+    """Cache ``fresh`` (a tuple of tensors / None) under ``holder.__dict__[name]`` keyed by ``key`` - INTO THE STORAGE OF THE
+    PREVIOUS ENTRY when there is one of the same shapes.  Weight-derived tensors (KRSC filters, folded BatchNorm terms,
+    transposed and Winograd filters, fused head filters) therefore keep their device addresses across optimizer steps, which
+    is what a captured training graph (model/train_graph.py) reads.  ``refresh``: zero-argument callable that re-derives
+    this entry from the live parameters (``refresh_derived_weights`` calls it after an optimizer step, since a replayed
+    graph runs no Python that would notice the parameters' new version)."""
+    d = holder.__dict__
+    old = d.get(name)
+    value = fresh
+    if old is not None and len(old[1]) == len(fresh) and all(
+            (o is None) == (f is None) and (o is None or (o.shape == f.shape and o.device == f.device))
+            for o, f in zip(old[1], fresh)):
+        with torch.no_grad():
+            for o, f in zip(old[1], fresh):
+                if o is not None and o.data_ptr() != f.data_ptr():
+                    o.copy_(f)
+        value = old[1]
+    d[name] = (key, value)
+    if refresh is not None:
+        d[name + '_refresh'] = refresh
+    return value
+
+
+# derived entries that read other derived entries (the KRSC filter) come second
+_REFRESH_ORDER = ('_frcnn_prepared', '_frcnn_perm', '_fused_cache', '_heads_cache', '_frcnn_wt', '_frcnn_winograd')
+
+
+def refresh_derived_weights(net):
+    """Re-derive every cached weight-dependent tensor of ``net`` in place (see ``stable_store``).  Returns the number of
+    entries visited."""
+    holders = [net] + [m for m in net.modules() if m is not net]
+    for h in list(holders):
+        holders += [v for k, v in h.__dict__.items() if k.endswith('_holder')]
+    todo = []
+    for h in holders:
+        for k, fn in list(h.__dict__.items()):
+            if k.endswith('_refresh') and callable(fn):
+                rank = next((i for i, tag in enumerate(_REFRESH_ORDER) if tag in k), len(_REFRESH_ORDER))
+                todo.append((rank, fn))
+    for _, fn in sorted(todo, key=lambda t: t[0]):
+        fn()
+    return len(todo)
+
+
 def _versions(*tensors):
     return tuple((t._version, t.data_ptr()) if t is not None else None for t in tensors)
 
@@ -52,9 +97,8 @@ def prepared_conv(conv, bn=None, use_bn=True):
                 shift = (shift + conv.bias.detach() * scale).contiguous()
         elif conv.bias is not None:
             shift = conv.bias.detach().contiguous()
-    prepared = (w_krsc.contiguous(), scale, shift)
-    conv.__dict__['_frcnn_prepared'] = (key, prepared)
-    return prepared
+    return stable_store(conv, '_frcnn_prepared', key, (w_krsc.contiguous(), scale, shift),
+                        refresh=lambda: prepared_conv(conv, bn, use_bn))
 
 
 def conv_bn_act(x, conv, bn=None, relu=False, residual=None, use_bn=True):
@@ -84,15 +128,16 @@ def _winograd_filter(conv, w_krsc, nhw, stride, pad):
     n, h, w = nhw
     if not ops.winograd_filter_wanted(n, h, w, c, k, r, s, stride, pad):
         conv.__dict__.pop('_frcnn_winograd', None)
+        conv.__dict__.pop('_frcnn_winograd_refresh', None)
         return None
     cache = conv.__dict__.get('_frcnn_winograd')
-    if cache is not None and cache[0] is w_krsc:
-        return cache[1]
+    key = (w_krsc.data_ptr(), w_krsc._version)
+    if cache is not None and cache[0] == key:
+        return cache[1][0]
     if torch.cuda.is_current_stream_capturing():
         raise RuntimeError("Winograd filter of a %dx%dx3x3 layer is not prepared: run an eager frame before capturing" % (k, c))
-    u = ops.winograd_filter(w_krsc)
-    conv.__dict__['_frcnn_winograd'] = (w_krsc, u)
-    return u
+    return stable_store(conv, '_frcnn_winograd', key, (ops.winograd_filter(w_krsc),),
+                        refresh=lambda: _winograd_filter(conv, w_krsc, nhw, stride, pad))[0]
 
 
 def to_nhwc(t):

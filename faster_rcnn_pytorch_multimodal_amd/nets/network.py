@@ -384,11 +384,15 @@ class Network(nn.Module):
         """RPN anchor targets + second-stage RoI sampling.  ``self._target_override`` (tests) injects precomputed
         targets: dict(anchor=(labels, targets, inside, outside), proposal=dict(rois, labels, targets, inside, outside))."""
         ov = getattr(self, '_target_override', None) or {}
+        # per-step sampling seeds: drawn on the host, or (model/train_graph.py) read on the device from self._seed_dev
+        sd = getattr(self, '_seed_dev', None)
+        seed_a = dict(seed=0, seed_dev=sd[0:1]) if sd is not None else {}
+        seed_p = dict(seed=0, seed_dev=sd[1:2]) if sd is not None else {}
         with torch.no_grad():
             if 'anchor' in ov:
                 self._anchor_targets = dict(zip(('labels', 'targets', 'inside', 'outside'), ov['anchor']))
             else:
-                lab, tgt, inw, outw, counts = anchor_target_layer_device(self._gt_boxes, self._info, self._anchors)
+                lab, tgt, inw, outw, counts = anchor_target_layer_device(self._gt_boxes, self._info, self._anchors, **seed_a)
                 self._anchor_targets = {'labels': lab, 'targets': tgt, 'inside': inw, 'outside': outw, 'counts': counts}
             if 'proposal' in ov:
                 self._proposal_targets = dict(ov['proposal'])
@@ -397,11 +401,12 @@ class Network(nn.Module):
                 if cfg.NET_TYPE == 'lidar':
                     self._proposal_targets = proposal_target_layer_device(
                         p['rois'], p['roi_scores'], self._gt_boxes, self._num_classes, roi_count=p['rois_count'],
-                        anchors_3d=p['roi_anchors_3d'], true_gt_boxes=self._true_gt_boxes, gt_boxes_dc=self._gt_boxes_dc)
+                        anchors_3d=p['roi_anchors_3d'], true_gt_boxes=self._true_gt_boxes, gt_boxes_dc=self._gt_boxes_dc,
+                        **seed_p)
                 else:
                     self._proposal_targets = proposal_target_layer_device(p['rois'], p['roi_scores'], self._gt_boxes,
                                                                           self._num_classes, roi_count=p['rois_count'],
-                                                                          gt_boxes_dc=self._gt_boxes_dc)
+                                                                          gt_boxes_dc=self._gt_boxes_dc, **seed_p)
         if 'anchors_3d' in self._proposal_targets:
             self._predictions['roi_anchors_3d'] = self._proposal_targets['anchors_3d']   # follows the sampled rows
         self._predictions['rois_sampled'] = self._proposal_targets['rois']
@@ -496,13 +501,43 @@ class Network(nn.Module):
         loss.backward()
         autograd_ops.join_weight_grads(self._device)
 
+    def enable_train_graphs(self, enabled=True, max_graphs=8):
+        """Run ``train_step`` as a replayed hipGraph per problem shape (model/train_graph.py): same arithmetic and the same
+        random sub-sampling streams as the eager step, without the ~1000 host launches per frame."""
+        self._train_graphs = {} if enabled else None
+        self._train_graph_max = int(max_graphs)
+
+    def _train_runner(self, blobs):
+        graphs = getattr(self, '_train_graphs', None)
+        if graphs is None:
+            return None
+        from ..model import train_graph
+        if train_graph.graphable(self, blobs) is not None:
+            return None
+        data, info = blobs['data'], np.asarray(blobs['info'], dtype=np.float32)
+        key = (int(data.shape[1]), int(data.shape[2]), int(data.shape[3]), int(len(blobs['gt_boxes'])),
+               tuple(float(v) for v in info))
+        runner = graphs.get(key)
+        if runner is None:
+            if len(graphs) >= self._train_graph_max:
+                return None                  # many distinct shapes: the remaining ones run eagerly
+            runner = train_graph.TrainStepRunner(self, key[0], key[1], key[2], key[3], info)
+            graphs[key] = runner
+        return runner
+
     def train_step(self, blobs, optimizer, update_weights=False):
         """One forward/backward on a frame (lib/model/train_val.py:458).  Gradients accumulate over calls and the
         optimizer steps only when ``update_weights`` (pseudo-batching, train_val.py:379-382).  Returns the loss."""
-        self.forward(blobs['data'], blobs['info'], blobs['gt_boxes'], blobs.get('gt_boxes_dc'), mode='TRAIN')
-        counts = self._proposal_targets.get('counts') if isinstance(self._proposal_targets, dict) else None
-        loss = self._losses['total_loss']
-        self.backward(loss)
+        graph_mode = getattr(self, '_train_graphs', None) is not None
+        runner = self._train_runner(blobs) if graph_mode else None
+        if runner is not None:
+            loss, counts = runner.run(blobs)
+            self._losses = runner.losses
+        else:
+            self.forward(blobs['data'], blobs['info'], blobs['gt_boxes'], blobs.get('gt_boxes_dc'), mode='TRAIN')
+            counts = self._proposal_targets.get('counts') if isinstance(self._proposal_targets, dict) else None
+            loss = self._losses['total_loss']
+            self.backward(loss)
         # candidate counts are read AFTER the backward pass has been queued: the host wait overlaps the device work instead
         # of stalling between forward and backward
         if counts is not None:
@@ -519,7 +554,14 @@ class Network(nn.Module):
                 optimizer.reduce()        # data parallel: average over the ranks first, clip the batch gradient after
             self._clip_gradients()
             optimizer.step()
-            optimizer.zero_grad()
+            if graph_mode:
+                # captured graphs accumulate into the gradient buffers and read the derived filters by ADDRESS: zero in
+                # place, re-derive in place
+                optimizer.zero_grad(set_to_none=False)
+                from ..model.train_graph import after_optimizer_step
+                after_optimizer_step(self)
+            else:
+                optimizer.zero_grad()
         value = float(loss.item())
         self._predictions = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in self._predictions.items()}
         return value

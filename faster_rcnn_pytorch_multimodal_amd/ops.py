@@ -228,6 +228,26 @@ def conv2d_bwd_weight(x, dy, r, s, stride=1, pad=0, want_bias=False):
     return dw, db
 
 
+def conv2d_bwd_weight_acc(x, dy, r, s, grad_w, grad_b=None, stride=1, pad=0):
+    """grad_w (K, C_real, R, S) [or (K, C_real) with r = s = 1] += filter gradient, grad_b (K,) += bias gradient: the
+    parameter's own gradient buffers, accumulated in place (frcnn_conv2d_bwd_weight_acc)."""
+    lib = _hip.load()
+    _dev_f32(x, "x"); _dev_f32(dy, "dy"); _dev_f32(grad_w, "grad_w")
+    n, h, w, c = x.shape
+    k = dy.shape[-1]
+    if tuple(dy.shape[:3]) != (n,) + conv_out_hw(h, w, r, s, stride, pad):
+        raise _hip.HipError("conv2d_bwd_weight_acc: dy shape %s does not match the forward output" % (tuple(dy.shape),))
+    c_real = grad_w.shape[1]
+    if grad_w.shape[0] != k or c_real > c or grad_w.numel() != k * c_real * r * s:
+        raise _hip.HipError("conv2d_bwd_weight_acc: grad_w %s does not fit k=%d c<=%d r=%d s=%d" % (tuple(grad_w.shape), k, c, r, s))
+    if grad_b is not None:
+        _dev_f32(grad_b, "grad_b")
+    ws_bytes = lib.frcnn_conv2d_bwd_weight_ws_bytes(n, h, w, c, k, r, s, stride, pad)
+    ws = _workspace(ws_bytes, x.device)
+    _hip.check(lib.frcnn_conv2d_bwd_weight_acc(_ptr(x), _ptr(dy), _ptr(grad_w), c_real, _ptr(grad_b), n, h, w, c, k, r, s,
+                                               stride, pad, _ptr(ws), ws_bytes, _stream()), "frcnn_conv2d_bwd_weight_acc")
+
+
 def maxpool3x3s2_nhwc(x):
     lib = _hip.load()
     _dev_f32(x, "x")
@@ -860,7 +880,7 @@ def lidar_bbox_transform(ex_rois, ex_anchors_3d, gt_rois):
     return out
 
 
-def anchor_target_layer(anchors, gt_boxes, info, rpn_batchsize, fg_fraction, neg_ov, pos_ov, seed):
+def anchor_target_layer(anchors, gt_boxes, info, rpn_batchsize, fg_fraction, neg_ov, pos_ov, seed, seed_dev=None):
     """Returns labels (N,), targets/inside/outside (N,4) in anchor order and counts (2,) int32 [fg, bg candidates]."""
     lib = _hip.load()
     _dev_f32(anchors, "anchors"); _dev_f32(gt_boxes, "gt_boxes")
@@ -875,13 +895,13 @@ def anchor_target_layer(anchors, gt_boxes, info, rpn_batchsize, fg_fraction, neg
     ws = _workspace(ws_bytes, dev)
     _hip.check(lib.frcnn_anchor_target_layer(
         _ptr(anchors), n, _ptr(gt_boxes), g, _hip.float_array([float(v) for v in list(info)[:4]]), int(rpn_batchsize),
-        float(fg_fraction), float(neg_ov), float(pos_ov), int(seed) & 0xFFFFFFFF, _ptr(labels), _ptr(targets),
+        float(fg_fraction), float(neg_ov), float(pos_ov), int(seed) & 0xFFFFFFFF, _ptr(seed_dev), _ptr(labels), _ptr(targets),
         _ptr(inside), _ptr(outside), _ptr(counts), _ptr(ws), ws_bytes, _stream()), "frcnn_anchor_target_layer")
     return labels, targets, inside, outside, counts
 
 
 def proposal_target_layer(rois, roi_scores, gt_boxes, num_classes, rois_per_frame, fg_fraction, fg_thresh, bg_hi, bg_lo,
-                          means, stds, seed, roi_count=None, anchors_3d=None, true_gt_boxes=None, skip_mask=None):
+                          means, stds, seed, roi_count=None, anchors_3d=None, true_gt_boxes=None, skip_mask=None, seed_dev=None):
     """Returns dict(labels (R,), rois (R,5), scores (R,), targets/inside/outside (R,4K), assign int32 (R,), counts int32 (4,)).
     With ``anchors_3d`` (num_rois,7) and ``true_gt_boxes`` (G,8) the LiDAR form: 7K-wide targets and ``anchors_3d`` (R,7)."""
     lib = _hip.load()
@@ -911,7 +931,7 @@ def proposal_target_layer(rois, roi_scores, gt_boxes, num_classes, rois_per_fram
         _hip.check(lib.frcnn_proposal_target_layer_lidar(
             _ptr(rois), _ptr(roi_scores), _ptr(roi_count), rois.shape[0], _ptr(anchors_3d), _ptr(gt_boxes),
             _ptr(true_gt_boxes), gt_boxes.shape[0], int(num_classes), r, float(fg_fraction), float(fg_thresh), float(bg_hi),
-            float(bg_lo), _hip.float_array(means), _hip.float_array(stds), int(seed) & 0xFFFFFFFF, _ptr(out["labels"]),
+            float(bg_lo), _hip.float_array(means), _hip.float_array(stds), int(seed) & 0xFFFFFFFF, _ptr(seed_dev), _ptr(out["labels"]),
             _ptr(out["rois"]), _ptr(out["scores"]), _ptr(out["anchors_3d"]), _ptr(out["targets"]), _ptr(out["inside"]),
             _ptr(out["outside"]), _ptr(out["assign"]), _ptr(out["counts"]), _ptr(skip_mask), _stream()),
             "frcnn_proposal_target_layer_lidar")
@@ -927,7 +947,7 @@ def proposal_target_layer(rois, roi_scores, gt_boxes, num_classes, rois_per_fram
     _hip.check(lib.frcnn_proposal_target_layer(
         _ptr(rois), _ptr(roi_scores), _ptr(roi_count), rois.shape[0], _ptr(gt_boxes), gt_boxes.shape[0], int(num_classes),
         r, float(fg_fraction), float(fg_thresh), float(bg_hi), float(bg_lo), _hip.float_array(means),
-        _hip.float_array(stds), int(seed) & 0xFFFFFFFF, _ptr(out["labels"]), _ptr(out["rois"]), _ptr(out["scores"]),
+        _hip.float_array(stds), int(seed) & 0xFFFFFFFF, _ptr(seed_dev), _ptr(out["labels"]), _ptr(out["rois"]), _ptr(out["scores"]),
         _ptr(out["targets"]), _ptr(out["inside"]), _ptr(out["outside"]), _ptr(out["assign"]), _ptr(out["counts"]),
         _ptr(skip_mask), _stream()), "frcnn_proposal_target_layer")
     return out

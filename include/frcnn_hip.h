@@ -69,6 +69,14 @@ size_t frcnn_conv2d_bwd_weight_ws_bytes(int n, int h, int w, int c, int k, int r
 int frcnn_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, int n, int h, int w, int c, int k,
                             int r, int s, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
 
+/* The same filter gradient ACCUMULATED into a parameter's own gradient buffer: grad_w (K, c_real, R, S) += dw (the layout of
+ * nn.Conv2d.weight; nn.Linear.weight with R = S = 1), c_real <= c real input channels (c is the padded count of x),
+ * grad_b (K) += db (may be NULL).  One pass sums the pixel-split slabs, drops the channel padding, changes the layout and
+ * adds - instead of a reduction launch, a permute copy and an add per parameter.  Uses the plan frcnn_conv2d_bwd_weight tuned
+ * for the shape; workspace of frcnn_conv2d_bwd_weight_ws_bytes. */
+int frcnn_conv2d_bwd_weight_acc(const float* x, const float* dy, float* grad_w, int c_real, float* grad_b, int n, int h, int w,
+                                int c, int k, int r, int s, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+
 /* Tuning / test hook: force the workgroup tile to (64*tm) x (64*tn) output pixels x channels for all
  * following frcnn_conv2d_fwd calls of this process; (tm,tn) in {(4,2),(2,4)} (8 waves, one workgroup per
  * CU), {(2,2),(2,1),(1,2),(1,1)} (4 waves); (0,0) restores the automatic choice. */
@@ -393,12 +401,15 @@ int frcnn_lidar_bbox_transform(const float* ex_rois, int roi_ld, const float* ex
  * uniform example weights): anchors (n,4) in (H,W,A) order, gt_boxes (num_gt,5) [x1,y1,x2,y2,cls], info HOST
  * [x_min,x_max,y_min,y_max].  Outputs in anchor order: labels (n) in {-1,0,1}, targets/inside/outside (n,4);
  * counts (2 ints, may be NULL) = fg / bg candidates before sub-sampling.  Sub-sampling to
- * fg_fraction*rpn_batchsize foreground and rpn_batchsize total draws hash keys from `seed`. */
+ * fg_fraction*rpn_batchsize foreground and rpn_batchsize total draws hash keys from `seed` + *seed_dev (seed_dev: device
+ * uint32, may be NULL - a launch replayed from a hipGraph keeps its `seed` argument, so per-step seeds come through
+ * device memory the caller rewrites before each replay; same for the proposal target layers below). */
 size_t frcnn_anchor_target_layer_ws_bytes(int num_anchors_total, int num_gt, int rpn_batchsize);
 int frcnn_anchor_target_layer(const float* anchors, int n, const float* gt_boxes, int num_gt,
                               const float* info_host, int rpn_batchsize, float fg_fraction, float negative_overlap,
-                              float positive_overlap, uint32_t seed, float* labels, float* targets, float* inside,
-                              float* outside, int* counts, void* ws, size_t ws_bytes, void* stream);
+                              float positive_overlap, uint32_t seed, const uint32_t* seed_dev, float* labels,
+                              float* targets, float* inside, float* outside, int* counts, void* ws, size_t ws_bytes,
+                              void* stream);
 
 /* proposal_target_layer (lib/layer_utils/proposal_target_layer.py:22-262, image detector, USE_GT / IGNORE_DC off):
  * rois (num_rois,5), roi_scores (num_rois) or NULL, roi_count device int or NULL, gt_boxes (num_gt,5).
@@ -410,9 +421,10 @@ int frcnn_anchor_target_layer(const float* anchors, int n, const float* gt_boxes
 int frcnn_proposal_target_layer(const float* rois, const float* roi_scores, const int* roi_count, int num_rois,
                                 const float* gt_boxes, int num_gt, int num_classes, int rois_per_frame,
                                 float fg_fraction, float fg_thresh, float bg_thresh_hi, float bg_thresh_lo,
-                                const float* means_host, const float* stds_host, uint32_t seed, float* labels,
-                                float* out_rois, float* out_scores, float* targets, float* inside, float* outside,
-                                int* gt_assignment, int* counts, const unsigned char* skip_mask, void* stream);
+                                const float* means_host, const float* stds_host, uint32_t seed, const uint32_t* seed_dev,
+                                float* labels, float* out_rois, float* out_scores, float* targets, float* inside,
+                                float* outside, int* gt_assignment, int* counts, const unsigned char* skip_mask,
+                                void* stream);
 
 /* LiDAR form (proposal_target_layer.py:142-154, NET_TYPE 'lidar'): overlaps and labels on the BEV rectangles gt_boxes
  * (num_gt,5); targets = lidar_3d_bbox_transform(roi, the RoI's 3-D anchor, true_gt_boxes (num_gt,8)
@@ -422,8 +434,8 @@ int frcnn_proposal_target_layer_lidar(const float* rois, const float* roi_scores
                                       const float* anchors3d, const float* gt_boxes, const float* true_gt_boxes,
                                       int num_gt, int num_classes, int rois_per_frame, float fg_fraction, float fg_thresh,
                                       float bg_thresh_hi, float bg_thresh_lo, const float* means_host,
-                                      const float* stds_host, uint32_t seed, float* labels, float* out_rois,
-                                      float* out_scores, float* out_anchors3d, float* targets, float* inside,
+                                      const float* stds_host, uint32_t seed, const uint32_t* seed_dev, float* labels,
+                                      float* out_rois, float* out_scores, float* out_anchors3d, float* targets, float* inside,
                                       float* outside, int* gt_assignment, int* counts, const unsigned char* skip_mask,
                                       void* stream);
 

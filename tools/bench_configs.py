@@ -75,7 +75,7 @@ def _timed_train_windows(net, blobs, opt, steps, windows=3):
     return losses, sorted(times)[len(times) // 2]
 
 
-def fpn_train(steps, autotune=True):
+def fpn_train(steps, autotune=True, graph=False):
     from faster_rcnn_pytorch_multimodal_amd import ops
     from faster_rcnn_pytorch_multimodal_amd.model import config as C
     from faster_rcnn_pytorch_multimodal_amd.nets.imagenet import imagenet
@@ -115,12 +115,15 @@ def fpn_train(steps, autotune=True):
     torch.cuda.synchronize()
     fwd_flops = sum(s["flops"] for s in ops.PROFILE)
     ops.PROFILE = None
+    if graph:
+        net.enable_train_graphs(True)        # model/train_graph.py: the step replayed as one hipGraph
     losses, dt = _timed_train_windows(net, blobs, opt, steps)
     C.reset_cfg()
     return {"metric": "train steps/sec res101+FPN Faster-RCNN 1000x600 forward+backward", "value": steps / dt,
             "unit": "steps/s", "ms_per_step": 1e3 * dt / steps, "n_gpus": 1, "steps": steps, "dtype": "f32",
             "config": {"workload": "BASELINE.json configs[3]: 8 random gt boxes, 12000/2000 proposals, 256 sampled RoIs, "
-                                   "FIXED_BLOCKS=1, SGD update every 16 steps", "launch": "eager (autograd)",
+                                   "FIXED_BLOCKS=1, SGD update every 16 steps",
+                       "launch": "hipGraph replay of the whole step, filter gradients on a side stream" if graph else "eager (autograd)",
                        "forward_conv_gflop": fwd_flops / 1e9, "loss_first": losses[0], "loss_last": losses[-1]}}
 
 
@@ -181,12 +184,13 @@ def main():
     ap.add_argument("--lidar-train", action="store_true")
     ap.add_argument("--steps", type=int, default=0)
     ap.add_argument("--no-autotune", action="store_true", help="heuristic conv plans in the training step")
+    ap.add_argument("--graph", action="store_true", help="--train: replay the step as a hipGraph (Network.enable_train_graphs)")
     args = ap.parse_args()
     both = not (args.lidar or args.train or args.lidar_train)
     if args.lidar or both:
         print(json.dumps(lidar_forward(args.steps or 80)))
     if args.train or both:
-        print(json.dumps(fpn_train(args.steps or 16, not args.no_autotune)))
+        print(json.dumps(fpn_train(args.steps or 16, not args.no_autotune, args.graph)))
     if args.lidar_train or both:
         print(json.dumps(lidar_train(args.steps or 16)))
 
