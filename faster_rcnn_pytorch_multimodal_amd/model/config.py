@@ -60,7 +60,9 @@ def _defaults():
         RPN_CLOBBER_POSITIVES=False, RPN_FG_FRACTION=0.5, RPN_BATCHSIZE=256, RPN_NMS_THRESH=0.7,
         RPN_PRE_NMS_TOP_N=12000, RPN_POST_NMS_TOP_N=2000, RPN_BBOX_INSIDE_WEIGHTS=(1.0, 1.0, 1.0, 1.0),
         RPN_POSITIVE_WEIGHT=-1.0, IGNORE_DC=False, ITER=1, DISPLAY=512, SNAPSHOT_KEPT=30, SUMMARY_INTERVAL=15,
-        SNAPSHOT_ITERS=5000, SNAPSHOT_PREFIX='res101_faster_rcnn', TOD_FILTER_LIST=['Day', 'Night', 'Dawn/Dusk'],
+        SNAPSHOT_ITERS=5000, SNAPSHOT_PREFIX='res101_faster_rcnn',
+        TOD_FILTER_LIST=['Day', 'Night', 'Dawn/Dusk'],
+        FRAMES_IN_FLIGHT=1,      # not in the reference: > 1 pipelines that many frames of a pseudo batch (model/train_graph.py)
         LIDAR=dict(BBOX_NORMALIZE_MEANS=(0.0,) * 7, BBOX_NORMALIZE_STDS=(0.1, 0.1, 0.1, 0.2, 0.2, 0.2, 1.0)),
         IMAGE=dict(BBOX_NORMALIZE_MEANS=(0.0, 0.0, 0.0, 0.0), BBOX_NORMALIZE_STDS=(0.1, 0.1, 0.2, 0.2)))
     c.TEST = dict(SCALES=(1.0,), NMS_THRESH=0.6, BBOX_REG=True, HAS_RPN=True, RPN_NMS_THRESH=0.7,

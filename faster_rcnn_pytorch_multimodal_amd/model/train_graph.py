@@ -49,7 +49,10 @@ class TrainStepRunner:
     """``run(blobs)`` -> (loss (device scalar tensor), candidate counts (device int32)) with the gradients of this frame
     added to every ``param.grad``."""
 
-    def __init__(self, net, height, width, channels, num_gt, info, warmup=2, autotune=True):
+    def __init__(self, net, height, width, channels, num_gt, info, warmup=2, autotune=True, grads=None):
+        """``grads``: gradient buffers (one per trainable parameter, in net.parameters() order) the captured backward
+        accumulates into; default: the parameters' own ``.grad`` (created as zeros when missing).  A pipeline slot passes
+        its private buffers (``TrainPipeline``)."""
         self.net = net
         self.info = np.asarray(info, dtype=np.float32).copy()
         dev = torch.device(net._device)
@@ -59,9 +62,14 @@ class TrainStepRunner:
         self.key = (height, width, channels, num_gt, tuple(float(v) for v in self.info))
         from .. import ops
         # every gradient buffer exists before the capture: the captured backward then ACCUMULATES in place
-        for p in net.parameters():
-            if p.requires_grad and p.grad is None:
+        params = [p for p in net.parameters() if p.requires_grad]
+        for p in params:
+            if p.grad is None:
                 p.grad = torch.zeros_like(p)
+        own = [p.grad for p in params]
+        if grads is not None:                       # warm-up and capture see the slot's buffers as the gradients
+            for p, g in zip(params, grads):
+                p.grad = g
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         saved = [p.grad.clone() for p in net.parameters() if p.requires_grad]
@@ -90,8 +98,10 @@ class TrainStepRunner:
             autograd_ops.ASYNC_WGRAD = prev
         # the warm-up and capture passes ran on zero inputs: drop what they added to the gradients
         with torch.no_grad():
-            for p, g in zip([p for p in net.parameters() if p.requires_grad], saved):
+            for p, g in zip(params, saved):
                 p.grad.copy_(g)
+        for p, g in zip(params, own):
+            p.grad = g
 
     def _step(self):
         net = self.net
@@ -122,3 +132,101 @@ class TrainStepRunner:
 def after_optimizer_step(net):
     """The parameters changed in place: re-derive the cached filters the captured graphs read."""
     return refresh_derived_weights(net)
+
+
+class TrainPipeline:
+    """Several frames of ONE pseudo batch in flight.
+
+    Between two optimizer steps the weights do not change (lib/model/train_val.py:379-382: the optimizer steps every
+    cfg.TRAIN.BATCH_SIZE frames), so the frames of a pseudo batch are independent.  Slot s owns a HIP stream, its own
+    captured graph(s) and its own set of gradient buffers (190 MB each; 288 GB of HBM make that free); ``submit`` replays a
+    frame on the next slot without waiting (the host never blocks on a loss it does not need yet), ``collect`` returns
+    losses in submission order, ``flush`` adds the slots' gradients into ``param.grad`` (one multi-tensor add per slot)
+    before the optimizer step.  Same arithmetic as the sequential loop except for the order in which the frames'
+    gradients are summed.
+    MEASURED (profiles/r03_train_step.md): on the res101+FPN 1000x600 step 2 / 4 frames in flight run at 16.7 / 17.1 ms per
+    frame against 17.0 ms for one - no gain.  Unlike the inference frame, the captured training step already runs two
+    chains side by side (data-gradient chain || filter gradients: 24.6 -> 17.0 ms) and that fills the chip; what is left is
+    the efficiency of the individual small-GEMM kernels, not idle CUs.  The class stays as the host-side pipelining of the
+    solver loop (cfg.TRAIN.FRAMES_IN_FLIGHT, default 1)."""
+
+    def __init__(self, net, slots=4, max_graphs=8):
+        self.net = net
+        self.dev = torch.device(net._device)
+        self.slots = max(1, int(slots))
+        self.max_graphs = int(max_graphs)
+        self.params = [p for p in net.parameters() if p.requires_grad]
+        for p in self.params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        self.grads = [[torch.zeros_like(p) for p in self.params] for _ in range(self.slots)]
+        self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.slots)]
+        self.runners = [dict() for _ in range(self.slots)]
+        self.pending = [None] * self.slots         # per slot: [runner, event, loss value or None, counts or None]
+        self.order = []                            # slots in submission order, not collected yet
+        self.next_slot = 0
+
+    def _finish(self, s):
+        ent = self.pending[s]
+        if ent is not None and ent[2] is None:
+            ent[1].synchronize()
+            ent[2] = float(ent[0].loss.item())
+            ent[3] = [int(v) for v in ent[0].counts[:2].cpu()] if ent[0].counts is not None else None
+        return ent
+
+    def submit(self, blobs):
+        """Queue one frame (forward + backward, gradients into the slot's buffers).  Returns the slot index."""
+        why = graphable(self.net, blobs)
+        if why is not None:
+            raise RuntimeError("this frame cannot run as a captured training step: " + why)
+        s = self.next_slot
+        self.next_slot = (s + 1) % self.slots
+        if self.pending[s] is not None and self.pending[s][2] is None:
+            raise RuntimeError("TrainPipeline: slot %d still holds an uncollected frame (collect() before submitting more than "
+                               "%d frames)" % (s, self.slots))
+        data, info = blobs['data'], np.asarray(blobs['info'], dtype=np.float32)
+        key = (int(data.shape[1]), int(data.shape[2]), int(data.shape[3]), int(len(blobs['gt_boxes'])),
+               tuple(float(v) for v in info))
+        runner = self.runners[s].get(key)
+        if runner is None:
+            if len(self.runners[s]) >= self.max_graphs:
+                raise RuntimeError("TrainPipeline: more than %d distinct frame shapes" % self.max_graphs)
+            torch.cuda.synchronize(self.dev)       # captures happen with the device idle
+            runner = TrainStepRunner(self.net, key[0], key[1], key[2], key[3], info, grads=self.grads[s],
+                                     autotune=not any(self.runners))
+            self.runners[s][key] = runner
+        st = self.streams[s]
+        st.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(st):
+            runner.run(blobs)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        self.pending[s] = [runner, ev, None, None]
+        self.order.append(s)
+        return s
+
+    def in_flight(self):
+        return len(self.order)
+
+    def collect(self):
+        """(loss, [fg, bg] candidate counts) of the OLDEST uncollected frame (blocks until that frame is done)."""
+        s = self.order.pop(0)
+        ent = self._finish(s)
+        self.net._losses = ent[0].losses
+        return ent[2], ent[3]
+
+    def flush(self):
+        """All submitted frames are done and their gradients are added to ``param.grad``; the slot buffers are zeroed.  Call
+        with every frame collected, before clipping / the optimizer step."""
+        if self.order:
+            raise RuntimeError("TrainPipeline.flush: %d frames not collected" % len(self.order))
+        cur = torch.cuda.current_stream(self.dev)
+        for st in self.streams:
+            cur.wait_stream(st)
+        own = [p.grad for p in self.params]
+        with torch.no_grad():
+            for g in self.grads:
+                torch._foreach_add_(own, g)
+                torch._foreach_zero_(g)
+        for st in self.streams:
+            st.wait_stream(cur)

@@ -317,32 +317,58 @@ class SolverWrapper:
         next_stepsize = stepsizes.pop()
         self.net.train()
         self.optimizer.zero_grad()
-        losses, loss_cumsum = [], 0.0
+        losses = []
+        pipe, pending = None, []
+        if int(cfg.TRAIN.get('FRAMES_IN_FLIGHT', 1)) > 1:
+            from . import train_graph
+            self.optimizer.zero_grad(set_to_none=False)
+            self.net.enable_train_graphs(True)      # frames the pipeline cannot take run through train_step's own graph / eager path
+            pipe = train_graph.TrainPipeline(self.net, slots=int(cfg.TRAIN.FRAMES_IN_FLIGHT))
         while it < max_iters + 1:
             update_weights = (it % self.batch_size == 0 and it != 0)
             if it == next_stepsize + 1:
+                self._drain(pipe, pending, losses)
                 self.snapshot(it)
                 lr *= cfg.TRAIN.GAMMA
                 scale_lr(self.optimizer, cfg.TRAIN.GAMMA)
                 next_stepsize = stepsizes.pop()
             blobs = self.data_gen.next()
             if self.val_sum_size and self.data_gen_val is not None and it % self.val_sum_size == 0:
+                self._drain(pipe, pending, losses)
                 for i in range(self.val_batch_size):
                     out = self.net.run_eval(self.data_gen_val.next(), self.val_batch_size,
                                             i == self.val_batch_size - 1)
                     self.val_summaries += [(it, k, v) for k, v in out[0]]
-            if self.sum_size and it % self.sum_size == 0:
-                total_loss, summary = self.net.train_step_with_summary(blobs, self.optimizer, self.sum_size,
-                                                                       update_weights)
-                self.summaries += [(it, k, v) for k, v in summary]
+            want_summary = bool(self.sum_size and it % self.sum_size == 0)
+            if pipe is not None and train_graph.graphable(self.net, blobs) is None:
+                # cfg.TRAIN.FRAMES_IN_FLIGHT > 1: the frame is queued on the next pipeline slot; its loss is collected when
+                # the slot comes round again, or right away where this iteration needs it (summary, weight update)
+                if pipe.in_flight() >= pipe.slots:
+                    self._collect_one(pipe, pending, losses)
+                pipe.submit(blobs)
+                pending.append((it, want_summary))
+                if update_weights or want_summary:
+                    self._drain(pipe, pending, losses)
+                if update_weights:
+                    pipe.flush()
+                    self.net.apply_update(self.optimizer, in_place=True)
+                total_loss = None
             else:
-                total_loss = self.net.train_step(blobs, self.optimizer, update_weights)
-            losses.append(total_loss)
-            loss_cumsum += total_loss
+                self._drain(pipe, pending, losses)
+                if pipe is not None:
+                    pipe.flush()                # an eager frame adds to param.grad directly: merge the slots first
+                if want_summary:
+                    total_loss, summary = self.net.train_step_with_summary(blobs, self.optimizer, self.sum_size,
+                                                                           update_weights)
+                    self.summaries += [(it, k, v) for k, v in summary]
+                else:
+                    total_loss = self.net.train_step(blobs, self.optimizer, update_weights)
+                losses.append(total_loss)
             if self.epoch_size and it % self.epoch_size == 0:
-                self.log('epoch average loss: %f' % (loss_cumsum / self.epoch_size))
-                loss_cumsum = 0.0
+                self._drain(pipe, pending, losses)
+                self.log('epoch average loss: %f' % (sum(losses[-self.epoch_size:]) / self.epoch_size))
             if it % cfg.TRAIN.SNAPSHOT_ITERS == 0:
+                self._drain(pipe, pending, losses)
                 last_snapshot_iter = it
                 ss_path, np_path = self.snapshot(it)
                 np_paths.append(np_path)
@@ -350,9 +376,25 @@ class SolverWrapper:
                 if len(np_paths) > cfg.TRAIN.SNAPSHOT_KEPT:
                     self.remove_snapshot(np_paths, ss_paths)
             it += 1
+        self._drain(pipe, pending, losses)
         if last_snapshot_iter != it - 1:
             self.snapshot(it - 1)
         return losses
+
+    def _collect_one(self, pipe, pending, losses):
+        it, want_summary = pending.pop(0)
+        loss, counts = pipe.collect()
+        if counts is not None and counts[0] + counts[1] == 0:
+            from ..nets.network import NO_CANDIDATES
+            if not (hasattr(self.optimizer, 'mark_fault') and self.optimizer.mark_fault()):
+                raise RuntimeError(NO_CANDIDATES)
+        losses.append(loss)
+        if want_summary:
+            self.summaries += [(it, k, float(v.item())) for k, v in self.net._losses.items()]
+
+    def _drain(self, pipe, pending, losses):
+        while pipe is not None and pending:
+            self._collect_one(pipe, pending, losses)
 
 
 class _PointerFrames:

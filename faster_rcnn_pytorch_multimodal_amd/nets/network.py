@@ -525,6 +525,22 @@ class Network(nn.Module):
             graphs[key] = runner
         return runner
 
+    def apply_update(self, optimizer, in_place=False):
+        """The weight update that ends a pseudo batch (lib/model/train_val.py:379-382 inside the missing network.py's
+        train_step): data-parallel average, per-element gradient clip, optimizer step, gradients cleared.  ``in_place``:
+        captured training graphs accumulate into the gradient buffers and read the derived filters by ADDRESS, so the
+        gradients are zeroed in place and the filters re-derived in place."""
+        if hasattr(optimizer, 'reduce'):
+            optimizer.reduce()        # data parallel: average over the ranks first, clip the batch gradient after
+        self._clip_gradients()
+        optimizer.step()
+        if in_place:
+            optimizer.zero_grad(set_to_none=False)
+            from ..model.train_graph import after_optimizer_step
+            after_optimizer_step(self)
+        else:
+            optimizer.zero_grad()
+
     def train_step(self, blobs, optimizer, update_weights=False):
         """One forward/backward on a frame (lib/model/train_val.py:458).  Gradients accumulate over calls and the
         optimizer steps only when ``update_weights`` (pseudo-batching, train_val.py:379-382).  Returns the loss."""
@@ -550,18 +566,7 @@ class Network(nn.Module):
                 if not (hasattr(optimizer, 'mark_fault') and optimizer.mark_fault()):
                     raise RuntimeError(NO_CANDIDATES)
         if update_weights:
-            if hasattr(optimizer, 'reduce'):
-                optimizer.reduce()        # data parallel: average over the ranks first, clip the batch gradient after
-            self._clip_gradients()
-            optimizer.step()
-            if graph_mode:
-                # captured graphs accumulate into the gradient buffers and read the derived filters by ADDRESS: zero in
-                # place, re-derive in place
-                optimizer.zero_grad(set_to_none=False)
-                from ..model.train_graph import after_optimizer_step
-                after_optimizer_step(self)
-            else:
-                optimizer.zero_grad()
+            self.apply_update(optimizer, in_place=graph_mode)
         value = float(loss.item())
         self._predictions = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in self._predictions.items()}
         return value

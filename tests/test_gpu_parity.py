@@ -1740,6 +1740,70 @@ def test_train_step_as_hipgraph_equals_eager_step(hip):
     C.reset_cfg()
 
 
+def test_train_pipeline_frames_in_flight_equals_sequential_accumulation(hip):
+    """model/train_graph.TrainPipeline: 3 slots, 5 frames of one pseudo batch in flight on their own streams / graphs /
+    gradient buffers.  Per-frame losses equal the sequential eager steps' (same RNG draws in submission order) and, after
+    flush(), param.grad equals the sequentially accumulated gradient (summation order aside); the weight update through
+    Network.apply_update matches, and the solver loop with cfg.TRAIN.FRAMES_IN_FLIGHT > 1 returns its losses in frame order."""
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.model import train_val
+    from faster_rcnn_pytorch_multimodal_amd.model.train_graph import TrainPipeline
+    net_e, _ = _build_fpn_pair(seed=23)
+    net_p, _ = _build_fpn_pair(seed=23)
+    data, info, gt, _, _ = _fpn_case()
+    rng = np.random.default_rng(9)
+    frames = [data, (rng.standard_normal(data.shape) * 50).astype(np.float32), data * 0.5, data * 1.5, data[:, ::-1].copy()]
+    for n in (net_e, net_p):
+        n.train()
+    opt_e, opt_p = [torch.optim.SGD([p for p in n.parameters() if p.requires_grad], lr=1e-3, momentum=C.cfg.TRAIN.MOMENTUM)
+                    for n in (net_e, net_p)]
+    opt_p.zero_grad(set_to_none=False)
+    pipe = TrainPipeline(net_p, slots=3)
+    mk = lambda f: {"data": f, "info": info, "gt_boxes": gt, "gt_boxes_dc": np.zeros((0, 4), np.float32)}
+    torch.manual_seed(77)
+    got = []
+    for f in frames:
+        if pipe.in_flight() >= pipe.slots:
+            got.append(pipe.collect()[0])
+        pipe.submit(mk(f))
+    while pipe.in_flight():
+        got.append(pipe.collect()[0])
+    pipe.flush()
+    torch.manual_seed(77)                                     # the same seed stream, frame by frame
+    want = [net_e.train_step(mk(f), opt_e, update_weights=False) for f in frames]
+    assert len(got) == 5 and np.allclose(got, want, rtol=2e-5, atol=0), (got, want)
+    floor = 0.01 * max(float(p.grad.abs().max()) for p in net_e.parameters() if p.requires_grad and p.grad is not None)
+    for (name, pe), (_, pp) in zip(net_e.named_parameters(), net_p.named_parameters()):
+        if pe.requires_grad and pe.grad is not None:
+            scale = max(float(pe.grad.abs().max()), floor)
+            assert float((pe.grad - pp.grad).abs().max()) <= 1e-4 * scale, name
+    for g in pipe.grads:
+        assert all(float(t.abs().max()) == 0.0 for t in g)    # slot buffers cleared by flush()
+    net_e.apply_update(opt_e)
+    net_p.apply_update(opt_p, in_place=True)
+    for pe, pp in zip(net_e.parameters(), net_p.parameters()):
+        assert torch.allclose(pe, pp, rtol=0, atol=1e-6 * max(1.0, float(pe.abs().max())))
+    # solver loop with frames in flight: 6 iterations, update every 3, losses come back in frame order
+    C.cfg.TRAIN.FRAMES_IN_FLIGHT = 2
+    C.cfg.TRAIN.SNAPSHOT_ITERS = 1000
+
+    class Frames:
+        def __init__(self):
+            self.i = 0
+
+        def next(self):
+            self.i += 1
+            return mk(frames[(self.i - 1) % 5])
+
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        solver = train_val.SolverWrapper(net_p, 2, Frames(), output_dir=tmp, batch_size=3, sum_size=4, log=lambda *_: None)
+        losses = solver.train_model(6)
+    assert len(losses) == 6 and all(np.isfinite(v) and v > 0 for v in losses)
+    assert [it for it, name, _ in solver.summaries if name == "total_loss"] == [4]
+    C.reset_cfg()
+
+
 @pytest.mark.parametrize("rows,c,relu,res", [(8800, 128, True, False), (2200, 1024, True, True), (1, 8, False, False),
                                             (12544, 2048, False, False), (777, 36, True, True)])
 def test_batchnorm_batch_statistics_fwd_bwd(hip, rows, c, relu, res):

@@ -75,7 +75,42 @@ def _timed_train_windows(net, blobs, opt, steps, windows=3):
     return losses, sorted(times)[len(times) // 2]
 
 
-def fpn_train(steps, autotune=True, graph=False):
+def _timed_pipeline_windows(net, blobs, opt, steps, inflight, windows=3):
+    """The same windows with `inflight` frames of a pseudo batch in flight (model/train_graph.TrainPipeline): a frame's loss
+    is collected when its slot comes round again; every 16th frame the slots' gradients are merged and the optimizer
+    steps."""
+    from faster_rcnn_pytorch_multimodal_amd.model.train_graph import TrainPipeline
+    opt.zero_grad(set_to_none=False)
+    pipe = TrainPipeline(net, slots=inflight)
+
+    def run(n):
+        losses = []
+        for i in range(n):
+            if pipe.in_flight() >= pipe.slots:
+                losses.append(pipe.collect()[0])
+            pipe.submit(blobs)
+            if i % 16 == 15:
+                while pipe.in_flight():
+                    losses.append(pipe.collect()[0])
+                pipe.flush()
+                net.apply_update(opt, in_place=True)
+        while pipe.in_flight():
+            losses.append(pipe.collect()[0])
+        return losses
+
+    run(8)
+    times, losses = [], []
+    for _ in range(windows):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        losses = run(steps)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    pipe.flush()
+    return losses, sorted(times)[len(times) // 2]
+
+
+def fpn_train(steps, autotune=True, graph=False, inflight=1):
     from faster_rcnn_pytorch_multimodal_amd import ops
     from faster_rcnn_pytorch_multimodal_amd.model import config as C
     from faster_rcnn_pytorch_multimodal_amd.nets.imagenet import imagenet
@@ -117,13 +152,17 @@ def fpn_train(steps, autotune=True, graph=False):
     ops.PROFILE = None
     if graph:
         net.enable_train_graphs(True)        # model/train_graph.py: the step replayed as one hipGraph
-    losses, dt = _timed_train_windows(net, blobs, opt, steps)
+    if inflight > 1:
+        losses, dt = _timed_pipeline_windows(net, blobs, opt, steps, inflight)
+    else:
+        losses, dt = _timed_train_windows(net, blobs, opt, steps)
     C.reset_cfg()
     return {"metric": "train steps/sec res101+FPN Faster-RCNN 1000x600 forward+backward", "value": steps / dt,
             "unit": "steps/s", "ms_per_step": 1e3 * dt / steps, "n_gpus": 1, "steps": steps, "dtype": "f32",
             "config": {"workload": "BASELINE.json configs[3]: 8 random gt boxes, 12000/2000 proposals, 256 sampled RoIs, "
                                    "FIXED_BLOCKS=1, SGD update every 16 steps",
-                       "launch": "hipGraph replay of the whole step, filter gradients on a side stream" if graph else "eager (autograd)",
+                       "launch": ("hipGraph replay, %d frames of a pseudo batch in flight" % inflight) if inflight > 1 else
+                                 "hipGraph replay of the whole step, filter gradients on a side stream" if graph else "eager (autograd)",
                        "forward_conv_gflop": fwd_flops / 1e9, "loss_first": losses[0], "loss_last": losses[-1]}}
 
 
@@ -185,12 +224,13 @@ def main():
     ap.add_argument("--steps", type=int, default=0)
     ap.add_argument("--no-autotune", action="store_true", help="heuristic conv plans in the training step")
     ap.add_argument("--graph", action="store_true", help="--train: replay the step as a hipGraph (Network.enable_train_graphs)")
+    ap.add_argument("--inflight", type=int, default=1, help="--train: frames of a pseudo batch in flight (TrainPipeline)")
     args = ap.parse_args()
     both = not (args.lidar or args.train or args.lidar_train)
     if args.lidar or both:
         print(json.dumps(lidar_forward(args.steps or 80)))
     if args.train or both:
-        print(json.dumps(fpn_train(args.steps or 16, not args.no_autotune, args.graph)))
+        print(json.dumps(fpn_train(args.steps or 16, not args.no_autotune, args.graph, args.inflight)))
     if args.lidar_train or both:
         print(json.dumps(lidar_train(args.steps or 16)))
 
