@@ -33,7 +33,7 @@ WEIGHT_SEED, BN_MODE = 3, "tame"     # cfg.RNG_SEED; see DESIGN.md "workload" fo
 MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix peak
 HBM_PEAK_GBS = 8000.0
 MIN_TIMED_S = 1.0                    # repeat the --steps region until about this much timed work exists
-PMC_FILES = ("r02b_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # committed rocprofv3 PMC passes, newest first
+PMC_FILES = ("r03_pmc_traffic.json", "r02b_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # committed rocprofv3 PMC passes, newest first
 
 
 def synthetic_frame(seed):

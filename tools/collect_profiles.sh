@@ -19,10 +19,16 @@ for C in FETCH_SIZE WRITE_SIZE MfmaUtil; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/${TAG}_pmc_$C -o pmc -- python3 $R/bench.py --plans $O/${TAG}_plans.json --steps 3 --warmup 1 --no-graph --streams 1 --no-cpu-baseline > $O/${TAG}_$C.log 2>&1
   echo "$C done"
 done
+# secondary configs: LiDAR-BEV forward (configs[2]), FPN train step (configs[3]) eager and as a replayed hipGraph, LiDAR train step
+python3 $R/tools/bench_configs.py --lidar > $O/${TAG}_configs.jsonl 2> $O/${TAG}_configs.err
+python3 $R/tools/bench_configs.py --train --steps 32 >> $O/${TAG}_configs.jsonl 2>> $O/${TAG}_configs.err
+python3 $R/tools/bench_configs.py --train --graph --steps 32 >> $O/${TAG}_configs.jsonl 2>> $O/${TAG}_configs.err
+python3 $R/tools/bench_configs.py --lidar-train >> $O/${TAG}_configs.jsonl 2>> $O/${TAG}_configs.err
+echo "secondary configs done"; cut -c1-160 $O/${TAG}_configs.jsonl
 # training step (BASELINE.json configs[3] names a "rocprof MFMA capture"): MfmaUtil per kernel over the last steps
 rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -d $O/${TAG}_train_pmc -o pmc -- python3 $R/tools/bench_configs.py --train --steps 12 > $O/${TAG}_train_pmc.log 2>&1
 echo "train MfmaUtil done"
-rocprofv3 --kernel-trace --stats -d $O/${TAG}_train_prof -o t -- python3 $R/tools/bench_configs.py --train --steps 12 > $O/${TAG}_train_prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/${TAG}_train_prof -o t -- python3 $R/tools/bench_configs.py --train --graph --steps 12 > $O/${TAG}_train_prof.log 2>&1
 echo "train trace done"
 # summaries (small, these are what gets committed under profiles/); the raw traces stay on the box
 S=$O/${TAG}_summary
@@ -32,7 +38,9 @@ CMD="python3 bench.py --plans <plans of the timed run> --steps 30 --warmup 5 --n
 python3 tools/rocpd_summary.py $O/${TAG}_prof/${TAG}_results.db "$CMD" --conv-cross-check > $S/kernel_stats.md
 python3 tools/pmc_traffic.py $O/${TAG}_pmc_FETCH_SIZE $O/${TAG}_pmc_WRITE_SIZE --mfma=$O/${TAG}_pmc_MfmaUtil "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE|MfmaUtil> --output-format csv -- python3 bench.py --plans <plans of the timed run> --steps 3 --warmup 1 --no-graph --streams 1 --no-cpu-baseline" > $S/pmc_traffic.json
 python3 tools/pmc_mfma.py $O/${TAG}_train_pmc "rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -- python3 tools/bench_configs.py --train --steps 12" --last-frac=0.4 > $S/train_pmc.json
-python3 tools/rocpd_summary.py $O/${TAG}_train_prof/t_results.db "python3 tools/bench_configs.py --train --steps 12 (res101+FPN 1000x600 forward+backward; includes the plan autotuning launches of the warm-up)" > $S/train_kernel_stats.md
+python3 tools/rocpd_summary.py $O/${TAG}_train_prof/t_results.db "python3 tools/bench_configs.py --train --graph --steps 12 (res101+FPN 1000x600 forward+backward replayed as a hipGraph; includes the plan autotuning launches of the warm-up)" > $S/train_kernel_stats.md
+python3 tools/train_busy.py $O/${TAG}_train_prof/t_results.db atl_overlap_kernel 8 > $S/train_busy.txt
+cp $O/${TAG}_configs.jsonl $S/
 cp $O/${TAG}_bench.json $O/${TAG}_plans.json $S/
 rm -rf $O/${TAG}_prof $O/${TAG}_pmc_FETCH_SIZE $O/${TAG}_pmc_WRITE_SIZE $O/${TAG}_pmc_MfmaUtil $O/${TAG}_train_pmc $O/${TAG}_train_prof
 echo "summaries in $S"; ls -la $S
