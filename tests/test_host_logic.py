@@ -229,3 +229,74 @@ def test_c_abi_from_plain_c(tmp_path):
                     os.path.join(root, "tests", "c_abi", "abi_check.c"), "-o", exe, "-ldl"], check=True)
     out = subprocess.run([exe, LIB_PATH] + sorted(_hip.PROTOTYPES), check=True, capture_output=True, text=True)
     assert "abi ok" in out.stdout and ("%d symbols" % len(_hip.PROTOTYPES)) in out.stdout
+
+
+def test_storage_stable_weight_caches_keep_addresses_and_refresh():
+    """nets.hip_modules.stable_store / refresh_derived_weights (what a captured training graph relies on): a derived tensor
+    is re-derived INTO the storage of the previous entry, dependents are refreshed after what they read, and a missing or
+    reshaped entry falls back to new storage."""
+    import torch
+    from faster_rcnn_pytorch_multimodal_amd.nets import hip_modules as HM
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.weight = torch.nn.Parameter(torch.arange(6, dtype=torch.float32).view(2, 3))
+
+    net = torch.nn.Sequential(Holder(), Holder())
+    calls = []
+
+    def doubled(m):                               # "KRSC filter": derived from the parameter
+        key = (m.weight._version, m.weight.data_ptr())
+        c = m.__dict__.get('_frcnn_prepared')
+        if c is not None and c[0] == key:
+            return c[1][0]
+        calls.append('prepared')
+        return HM.stable_store(m, '_frcnn_prepared', key, (m.weight.detach() * 2,), refresh=lambda: doubled(m))[0]
+
+    def transposed(m):                            # "transposed filter": derived from the derived tensor
+        src = doubled(m)
+        key = (src.data_ptr(), src._version)
+        c = m.__dict__.get('_frcnn_wt')
+        if c is not None and c[0] == key:
+            return c[1][0]
+        calls.append('wt')
+        return HM.stable_store(m, '_frcnn_wt', key, (src.t().contiguous(),), refresh=lambda: transposed(m))[0]
+
+    first = [(doubled(m), transposed(m)) for m in net]
+    ptrs = [(a.data_ptr(), b.data_ptr()) for a, b in first]
+    with torch.no_grad():
+        for m in net:
+            m.weight.add_(1.0)                    # the optimizer step: in place, version bump
+    calls.clear()
+    assert HM.refresh_derived_weights(net) == 4
+    assert calls == ['prepared', 'prepared', 'wt', 'wt']            # sources before their dependents
+    for m, (a, b), (pa, pb) in zip(net, first, ptrs):
+        assert (a.data_ptr(), b.data_ptr()) == (pa, pb)             # same storage ...
+        assert torch.equal(a, m.weight.detach() * 2) and torch.equal(b, (m.weight.detach() * 2).t())   # ... new values
+    assert HM.refresh_derived_weights(net) == 4 and calls == ['prepared', 'prepared', 'wt', 'wt']      # nothing changed: hits
+    # a reshaped entry cannot reuse the storage
+    h = Holder()
+    old = HM.stable_store(h, 'x', 1, (torch.zeros(3),))[0]
+    new = HM.stable_store(h, 'x', 2, (torch.ones(4),))[0]
+    assert new.data_ptr() != old.data_ptr() and new.shape == (4,)
+
+
+def test_train_graph_refuses_what_it_cannot_capture():
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.model import train_graph
+    C.reset_cfg()
+    C.cfg.NET_TYPE = "image"
+    blobs = {"gt_boxes": np.zeros((2, 5), np.float32), "gt_boxes_dc": np.zeros((0, 5), np.float32)}
+    assert train_graph.graphable(None, blobs) is None
+    assert "ground-truth" in train_graph.graphable(None, {"gt_boxes": np.zeros((0, 5), np.float32)})
+    C.cfg.RESNET.FIXED_BLOCKS = -1
+    assert "BatchNorm" in train_graph.graphable(None, blobs)
+    C.reset_cfg()
+    C.cfg.NET_TYPE = "lidar"
+    assert "LiDAR" in train_graph.graphable(None, blobs)
+    C.reset_cfg()
+    C.cfg.NET_TYPE = "image"
+    C.cfg.UC.EN_BBOX_ALEATORIC = True
+    assert "uncertainty" in train_graph.graphable(None, blobs)
+    C.reset_cfg()
