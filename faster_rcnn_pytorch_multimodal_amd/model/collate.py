@@ -12,6 +12,8 @@ rebuilds the reference's ``all_boxes[cls][frame]`` lists from the gathered matri
 import numpy as np
 import torch
 
+EVAL_GATHER_EVERY = 8      # frames per collate block of the eval loop (model/test.test_net, bench.py --gather-every)
+
 
 def record_numel(num_classes, max_out, elem=5):
     """elem = 5 image rows [x1,y1,x2,y2,score], 8 LiDAR rows [xc,yc,zc,l,w,h,ry,score]."""

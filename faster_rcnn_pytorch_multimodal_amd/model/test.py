@@ -150,8 +150,9 @@ def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=F
     frame source with ``num_classes``, ``num_frames(mode)``, ``blobs_at(i, mode)`` -> {'data': (1,H,W,C) blob or None,
     'info': 7-vector}, optional ``name_at(i, mode)``, optional ``evaluate_detections(all_boxes, out_dir, mode)``.
     ``out_dir`` None / '' -> ``get_output_dir(db, mode='test')`` like the reference (:166), which ignores the argument.  Per frame everything stays on the device up to the
-    per-class, max_dets-limited record (``detect_frame_device``); ranks exchange the fixed-size records with ONE
-    all-gather per step (``collate.gather_records``), so every rank ends with the complete ``all_boxes``.
+    per-class, max_dets-limited record (``detect_frame_device``); records are collated in blocks of
+    ``collate.EVAL_GATHER_EVERY`` frames (one all-gather over the ranks + one device-to-host copy per block, on a stream of
+    their own: ``collate.RecordRing``), so every rank ends with the complete ``all_boxes`` and no frame waits for the host.
     LiDAR detections are converted from the voxel grid to metres (:223-224).  Writes ``detections.pkl`` like the
     reference (:246-248) plus the per-class text files of lib/datasets/db.py:305-367 (rank 0 only) and returns
     ``all_boxes[cls][frame]`` (rows [box..., score])."""
@@ -183,30 +184,43 @@ def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=F
     # score (lib/model/test.py:213-221), so a record of max_dets rows could truncate; one row per RoI cannot
     max_out = max(max_dets, int(cfg.TEST.RPN_POST_NMS_TOP_N)) if max_dets > 0 else int(cfg.TEST.RPN_POST_NMS_TOP_N)
     infos = {}
-    for s in range(steps):
-        dets = torch.zeros((k, max_out, elem), dtype=torch.float32, device=dev)
-        counts = torch.zeros((k,), dtype=torch.int32, device=dev)
-        blobs = db.blobs_at(mine[s], mode) if s < len(mine) else None
-        if blobs is not None and blobs.get('data') is not None:
-            infos[mine[s]] = blobs['info']
-            dets, counts = detect_frame_device(net, blobs['data'], blobs['info'], thresh, max_dets, max_out)
-        if distributed:
-            rows = collate.unpack_records(collate.gather_records(collate.pack_record(dets, counts)), k, max_out, elem)
-            frames_of_step = [(r, s * world + r) for r in range(world) if s * world + r < num_images]
-        else:
-            d, c = dets.cpu().numpy(), counts.cpu().numpy()
-            rows = [[d[j, :c[j]].copy() if j > 0 else np.empty((0, elem), np.float32) for j in range(k)]]
-            frames_of_step = [(0, mine[s])] if s < len(mine) else []
-        for r, i in frames_of_step:
-            info = None
-            if lidar:
-                # the voxel-grid geometry depends on cfg and the frame scale only: another rank's frame needs no reload
-                info = infos[i] if i in infos else minibatch.lidar_frame_geometry(cfg.TEST.SCALES[0])[2]
-            for j in range(1, k):
-                cls_boxes = rows[r][j]
-                if lidar and cls_boxes.size:
-                    cls_boxes = bbox_voxel_grid_to_pc(cls_boxes, lidar_extents(), info)
-                all_boxes[j][i] = cls_boxes if cls_boxes.size else np.empty(0)
+    numel = collate.record_numel(k, max_out, elem)
+    gather_dev = dev if (not distributed or dist.get_backend() == 'nccl') else torch.device('cpu')
+    # Frames are queued without a host round trip each: a frame's record is packed into a device ring and a block of
+    # EVAL_GATHER_EVERY frames is collated (one all-gather over the ranks) and copied to the host on the ring's own stream
+    # (collate.RecordRing); the host unpacks a chunk of blocks at a time.
+    chunk = collate.EVAL_GATHER_EVERY * 8
+    for c0 in range(0, steps, chunk):
+        n = min(chunk, steps - c0)
+        ring = collate.RecordRing(numel, n, every=collate.EVAL_GATHER_EVERY, device=dev, distributed=distributed,
+                                  gather_device=gather_dev)
+        for s in range(c0, c0 + n):
+            slot = ring.slot(s - c0)
+            blobs = db.blobs_at(mine[s], mode) if s < len(mine) else None
+            if blobs is not None and blobs.get('data') is not None:
+                infos[mine[s]] = blobs['info']
+                dets, counts = detect_frame_device(net, blobs['data'], blobs['info'], thresh, max_dets, max_out)
+                collate.pack_record(dets, counts, slot)
+            else:
+                slot.zero_()              # a frame without data (the reference skips it, :198-203) or a padding step
+            ring.commit(s - c0)
+        host = ring.drain()
+        for s in range(c0, c0 + n):
+            rows = collate.unpack_records(host[s - c0], k, max_out, elem)
+            if distributed:
+                frames_of_step = [(r, s * world + r) for r in range(world) if s * world + r < num_images]
+            else:
+                frames_of_step = [(0, mine[s])] if s < len(mine) else []
+            for r, i in frames_of_step:
+                info = None
+                if lidar:
+                    # the voxel-grid geometry depends on cfg and the frame scale only: another rank's frame needs no reload
+                    info = infos[i] if i in infos else minibatch.lidar_frame_geometry(cfg.TEST.SCALES[0])[2]
+                for j in range(1, k):
+                    cls_boxes = rows[r][j]
+                    if lidar and cls_boxes.size:
+                        cls_boxes = bbox_voxel_grid_to_pc(cls_boxes, lidar_extents(), info)
+                    all_boxes[j][i] = cls_boxes if cls_boxes.size else np.empty(0)
     if rank == 0:
         os.makedirs(out_dir, exist_ok=True)
         with open(os.path.join(out_dir, 'detections.pkl'), 'wb') as f:
