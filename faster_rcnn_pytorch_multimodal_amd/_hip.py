@@ -63,6 +63,8 @@ PROTOTYPES = {
     "frcnn_roi_align_fwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "frcnn_roi_align_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_float, c_int, _P, c_int, _P,
                                     _P, c_size_t, _P]),
+    "frcnn_roi_align_fwd_affine": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_float, c_int, _P,
+                                           c_int, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "frcnn_fpn_level_map": (c_int, [_P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P]),
     "frcnn_head_fc_softmax_decode": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, POINTER(c_float),
                                              POINTER(c_float), c_float, _P, _P, _P, _P, _P, _P]),

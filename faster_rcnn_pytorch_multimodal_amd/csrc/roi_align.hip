@@ -15,6 +15,29 @@
 
 namespace {
 
+// Optional per-channel affine + ReLU applied to a pooled value before it is stored: out = act(pooled * scale[c] + shift[c]).
+// Lets a bias-free 1x1 convolution that FOLLOWS the pooling in the reference (layer4[0].conv1 / downsample[0] on pool5,
+// lib/nets/resnet.py:98-127) run BEFORE it on the feature map - pooling and a 1x1 convolution are both linear and act on
+// different axes, so they commute - with its folded BatchNorm and activation still applied after the pooling.
+struct RoiEpilogue {
+  const float* scale;   // [C] or nullptr (1)
+  const float* shift;   // [C] or nullptr (0)
+  int relu;
+  __device__ __forceinline__ bool any() const { return scale || shift || relu; }
+  __device__ __forceinline__ float4 apply(float4 v, int c4) const {
+    if (scale) {
+      const float4 s = reinterpret_cast<const float4*>(scale)[c4];
+      v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+    }
+    if (shift) {
+      const float4 b = reinterpret_cast<const float4*>(shift)[c4];
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    return v;
+  }
+};
+
 // XCD_SPLIT: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one), so workgroup b works on
 // channel slice b % 8 only: each XCD's private 4 MB L2 then holds 1/8 of the feature map (1.2 MB of the 9.8 MB
 // res101 map) instead of thrashing on all of it — the PMC passes showed 127 MB fetched from beyond L2 per launch
@@ -26,7 +49,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const float* __restric
                                                          const int* __restrict__ roi_count, int num_rois, int P,
                                                          float spatial_scale, int sampling_ratio,
                                                          const int* __restrict__ level_of_roi, int level,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, RoiEpilogue epi) {
   const int live = roi_count ? min(*roi_count, num_rois) : num_rois;
   const size_t total = (size_t)num_rois * P * P * C4;
   const int cs = XCD_SPLIT ? C4 >> 3 : C4;                 // float4 groups per channel slice
@@ -86,7 +109,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const float* __restric
       }
       acc.x /= count; acc.y /= count; acc.z /= count; acc.w /= count;
     }
-    reinterpret_cast<float4*>(out)[item] = acc;
+    reinterpret_cast<float4*>(out)[item] = epi.apply(acc, c4);
   }
 }
 
@@ -299,12 +322,12 @@ __global__ __launch_bounds__(64 * 2 * PLAN_P) void roi_plan_kernel(int H, int W,
   }
 }
 
-template <int G>
+template <int G, bool EPI>
 __global__ __launch_bounds__(256) void roi_align_fwd_planned(const float* __restrict__ feat, int H, int W, int C4,
                                                              int nslices, const RoiPlanHead* __restrict__ head,
                                                              const RoiItem* __restrict__ items,
                                                              const float* __restrict__ wxt, const float* __restrict__ wyt,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, RoiEpilogue epi) {
   constexpr int P = PLAN_P;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -317,6 +340,19 @@ __global__ __launch_bounds__(256) void roi_align_fwd_planned(const float* __rest
   const bool active = c4 < C4;
   const int cl = min(c4, C4 - 1);                      // inactive lanes read the last channel group and never store
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // epilogue terms of this lane's four channels (the slice of a workgroup never changes)
+  float4 esc = make_float4(1.f, 1.f, 1.f, 1.f), esh = zero4;
+  if (EPI) {
+    if (epi.scale) esc = reinterpret_cast<const float4*>(epi.scale)[cl];
+    if (epi.shift) esh = reinterpret_cast<const float4*>(epi.shift)[cl];
+  }
+  auto finish = [&](float4 v) {
+    if (EPI) {
+      v.x = v.x * esc.x + esh.x; v.y = v.y * esc.y + esh.y; v.z = v.z * esc.z + esh.z; v.w = v.w * esc.w + esh.w;
+      if (epi.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    }
+    return v;
+  };
 
   struct Desc { int r, sp, flag, y0, y1, bimg, xlo, xhi, pw; float inv_count; };
   struct Tab { float wx; float wy[P]; };
@@ -363,7 +399,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_planned(const float* __rest
       if (d.flag == ROI_DEAD) {
         if (active)
 #pragma unroll
-          for (int ph = 0; ph < P; ++ph) ob[(size_t)ph * P * C4] = zero4;
+          for (int ph = 0; ph < P; ++ph) ob[(size_t)ph * P * C4] = finish(zero4);
       } else {
         f32x2 acc[P][2];
 #pragma unroll
@@ -441,10 +477,11 @@ __global__ __launch_bounds__(256) void roi_align_fwd_planned(const float* __rest
         if (active)
 #pragma unroll
           for (int ph = 0; ph < P; ++ph)
-            if (ph < nph)
-              ob[(size_t)(ph_begin + ph) * P * C4] =
-                  make_float4(acc[ph][0][0] * d.inv_count, acc[ph][0][1] * d.inv_count, acc[ph][1][0] * d.inv_count,
-                              acc[ph][1][1] * d.inv_count);
+            if (ph < nph) {
+              const float4 v = make_float4(acc[ph][0][0] * d.inv_count, acc[ph][0][1] * d.inv_count,
+                                           acc[ph][1][0] * d.inv_count, acc[ph][1][1] * d.inv_count);
+              ob[(size_t)(ph_begin + ph) * P * C4] = finish(v);
+            }
       }
     }
     d_cur = d_nxt;
@@ -790,19 +827,23 @@ extern "C" size_t frcnn_roi_align_fwd_ws_bytes(int h, int w, int c, int num_rois
   return plan_bytes(h, w, c, num_rois);
 }
 
-extern "C" int frcnn_roi_align_fwd(const float* feat, int n, int h, int w, int c, const float* rois, const int* roi_count,
-                                   int num_rois, int rois_per_image, int pooled, float spatial_scale, int sampling_ratio,
-                                   const int* level_of_roi, int level, float* out, void* ws, size_t ws_bytes,
-                                   void* stream_) {
+extern "C" int frcnn_roi_align_fwd_affine(const float* feat, int n, int h, int w, int c, const float* rois,
+                                          const int* roi_count, int num_rois, int rois_per_image, int pooled,
+                                          float spatial_scale, int sampling_ratio, const int* level_of_roi, int level,
+                                          float* out, const float* scale, const float* shift, int relu, void* ws,
+                                          size_t ws_bytes, void* stream_) {
+  const RoiEpilogue epi{scale, shift, relu};
+  const bool has_epi = scale || shift || relu;
   FRCNN_REQUIRE(feat && rois && out && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && num_rois > 0 && pooled > 0,
                 "roi_align_fwd: bad arguments (c%%4==0)");
   FRCNN_REQUIRE(rois_per_image == 0 || (rois_per_image > 0 && (long)rois_per_image * n >= num_rois),
                 "roi_align_fwd: rois_per_image %d x %d images < %d rois", rois_per_image, n, num_rois);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FRCNN_REQUIRE(!(has_epi && g_roi_variant == 5), "roi_align_fwd_affine: the map-resident kernel has no epilogue");
   if (g_roi_variant == 5 && !resident_ok(h, w, c, pooled))
     return frcnn::fail(FRCNN_ERR_ARG, "roi_align_fwd: the map-resident kernel needs pooled 7, c %% 16 == 0, h <= 64 and "
                        "h*w*64 B of LDS (got %dx%dx%d)", h, w, c);
-  if ((g_roi_variant == 5 || (g_roi_variant == 0 && RES_AUTO)) && resident_ok(h, w, c, pooled)) {
+  if ((g_roi_variant == 5 || (g_roi_variant == 0 && RES_AUTO && !has_epi)) && resident_ok(h, w, c, pooled)) {
     const size_t lds = res_lds_bytes(h, w);
     static std::atomic<size_t> configured{0};
     if (lds > configured.load()) {
@@ -840,26 +881,40 @@ extern "C" int frcnn_roi_align_fwd(const float* feat, int n, int h, int w, int c
     // never more waves than wave-items in the worst case
     const long max_wave_items = (long)num_rois * nslices * PLAN_P * PLAN_P;
     const bool g8 = g_roi_variant == 3;                  // variant 3: 8 loads in flight (104 VGPRs, 4 workgroups per CU)
-    long nwg = 256 * (g8 ? 4 : 5);
+    long nwg = 256 * ((g8 || has_epi) ? 4 : 5);      // the epilogue form holds 108 VGPRs: 4 waves per SIMD
     nwg = std::min(nwg, (max_wave_items + 3) / 4);
     nwg = std::max<long>(nslices, nwg / nslices * nslices);
-    if (!g8)
-      hipLaunchKernelGGL(roi_align_fwd_planned<4>, dim3((unsigned)nwg), dim3(256), 0, stream, feat, h, w, c4, nslices, head,
-                         items, wxt, wyt, out);
+    if (!g8 && !has_epi)
+      hipLaunchKernelGGL((roi_align_fwd_planned<4, false>), dim3((unsigned)nwg), dim3(256), 0, stream, feat, h, w, c4, nslices,
+                         head, items, wxt, wyt, out, epi);
+    else if (!g8)
+      hipLaunchKernelGGL((roi_align_fwd_planned<4, true>), dim3((unsigned)nwg), dim3(256), 0, stream, feat, h, w, c4, nslices,
+                         head, items, wxt, wyt, out, epi);
+    else if (!has_epi)
+      hipLaunchKernelGGL((roi_align_fwd_planned<8, false>), dim3((unsigned)nwg), dim3(256), 0, stream, feat, h, w, c4, nslices,
+                         head, items, wxt, wyt, out, epi);
     else
-      hipLaunchKernelGGL(roi_align_fwd_planned<8>, dim3((unsigned)nwg), dim3(256), 0, stream, feat, h, w, c4, nslices, head,
-                         items, wxt, wyt, out);
+      hipLaunchKernelGGL((roi_align_fwd_planned<8, true>), dim3((unsigned)nwg), dim3(256), 0, stream, feat, h, w, c4, nslices,
+                         head, items, wxt, wyt, out, epi);
     return frcnn::check_launch("roi_align_fwd_planned");
   }
   const size_t total = (size_t)num_rois * pooled * pooled * (c / 4);
   if (g_roi_variant != 1 && c % 32 == 0) {   // 8 channel slices of c/8 channels, one per XCD; grid = multiple of 8
     const size_t per_slice_blocks = std::min<size_t>((total / 8 + 255) / 256, (size_t)1 << 17);
     hipLaunchKernelGGL(roi_align_fwd_nhwc<true>, dim3((unsigned)(per_slice_blocks * 8)), dim3(256), 0, stream, feat, h, w,
-                       c / 4, rois, roi_count, num_rois, pooled, spatial_scale, sampling_ratio, level_of_roi, level, out);
+                       c / 4, rois, roi_count, num_rois, pooled, spatial_scale, sampling_ratio, level_of_roi, level, out, epi);
     return frcnn::check_launch("roi_align_fwd_nhwc<xcd>");
   }
   const size_t blocks = std::min<size_t>((total + 255) / 256, (size_t)1 << 20);
   hipLaunchKernelGGL(roi_align_fwd_nhwc<false>, dim3((unsigned)blocks), dim3(256), 0, stream, feat, h, w, c / 4, rois,
-                     roi_count, num_rois, pooled, spatial_scale, sampling_ratio, level_of_roi, level, out);
+                     roi_count, num_rois, pooled, spatial_scale, sampling_ratio, level_of_roi, level, out, epi);
   return frcnn::check_launch("roi_align_fwd_nhwc");
+}
+
+extern "C" int frcnn_roi_align_fwd(const float* feat, int n, int h, int w, int c, const float* rois, const int* roi_count,
+                                   int num_rois, int rois_per_image, int pooled, float spatial_scale, int sampling_ratio,
+                                   const int* level_of_roi, int level, float* out, void* ws, size_t ws_bytes,
+                                   void* stream_) {
+  return frcnn_roi_align_fwd_affine(feat, n, h, w, c, rois, roi_count, num_rois, rois_per_image, pooled, spatial_scale,
+                                    sampling_ratio, level_of_roi, level, out, nullptr, nullptr, 0, ws, ws_bytes, stream_);
 }

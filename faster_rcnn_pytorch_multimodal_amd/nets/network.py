@@ -37,9 +37,12 @@ from . import autograd_ops
 from . import uncertainty
 from .autograd_ops import (conv_bn_act_train, det_loss_train, fused_head_train, fused_head_weights, linear_train,
                            roi_align_train, rpn_loss_train, spatial_mean_train)
-from .hip_modules import conv_bn_act, pad4, to_nchw_view, to_nhwc
+from .hip_modules import conv_bn_act, pad4, prepared_conv, to_nchw_view, to_nhwc
 
 ROI_ALIGN_SAMPLING_RATIO = 0
+# inference runs layer4[0]'s input-side 1x1 convolutions on the feature map, before the RoIAlign (Network._layer4_projected);
+# False: the reference's order of operations (pool, then convolve 300 x 7 x 7 pixels)
+PROJECT_BEFORE_POOLING = True
 UC_SEED_RANK_STRIDE = 7919        # decorrelates the uncertainty heads' random draws across data-parallel ranks
 # FPN choices the missing network.py leaves open (DESIGN.md "reconstructed contract"):
 FPN_RPN_LEVEL = 0                 # the RPN runs on p2 only (_feat_stride = 4, lib/nets/imagenet.py:34)
@@ -330,9 +333,11 @@ class Network(nn.Module):
             return linear_train(h, self.t_fc3, relu=True)
         if torch.is_grad_enabled() and self._mode == 'TRAIN':
             return spatial_mean_train(self._layer4(to_nhwc(pool5)))      # Bottleneck nodes + mean, all differentiable
+        return self._fc7_from_layer4(self._layer4(to_nhwc(pool5)))
+
+    def _fc7_from_layer4(self, y):
         # layer4 output (R,7,7,2048) -> fc7 in a chip-wide streaming pass (HBM-bound, 120 MB at 300 RoIs), then the
         # heads on fc7 alone: one workgroup per RoI doing both needed 72 us (profiles/r01h_kernel_stats.md)
-        y = self._layer4(to_nhwc(pool5))
         fc7 = ops.spatial_mean(y)
         if uncertainty.enabled():
             return fc7                                  # the heads run in _region_classification (nets/uncertainty.py)
@@ -341,6 +346,55 @@ class Network(nn.Module):
         out['fc7'] = fc7
         self._predictions['_tail'] = out
         return fc7
+
+    # ---- inference: layer4[0]'s two 1x1 convolutions BEFORE the pooling --------------------------------------------------
+    def _projected_head_ok(self):
+        """True when ``_predict`` may run layer4[0].conv1 and layer4[0].downsample[0] on the feature map instead of on
+        pool5 (see ``_layer4_projected``): inference without autograd, single-level 'align' pooling, layer4 as the tail, both
+        convolutions 1x1 / stride 1 / no bias and every BatchNorm of the block in eval mode."""
+        if not PROJECT_BEFORE_POOLING or self._mode != 'TEST' or torch.is_grad_enabled() or cfg.ENABLE_CUSTOM_TAIL:
+            return False
+        if self._pyramid is not None and cfg.POOLING_MODE == 'multiscale':
+            return False
+        blk = self.resnet.layer4[0]
+        if blk.downsample is None:
+            return False
+        for conv in (blk.conv1, blk.downsample[0]):
+            if (tuple(conv.kernel_size) != (1, 1) or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (0, 0)
+                    or conv.bias is not None or conv.groups != 1):
+                return False
+        return not any(m.training for m in (blk.bn1, blk.bn2, blk.bn3, blk.downsample[1]))
+
+    def _layer4_projected(self, net_conv, rois):
+        """layer4 on the pooled RoIs (lib/nets/resnet.py:98-127 applied by ``_head_to_tail`` to pool5) with the block's two
+        input-side 1x1 convolutions moved in front of the RoIAlign.
+
+        RoIAlign is linear in the feature map and acts on the pixel axes; a bias-free 1x1 convolution is linear and acts on
+        the channel axis: ``conv(roi_align(F)) == roi_align(conv(F))``.  The reference evaluates the left side on
+        300 x 7 x 7 = 14 700 pooled pixels; the right side needs the convolution on the 38 x 63 = 2 394 pixels of the map
+        once (6.1x fewer multiply-adds for conv1 and the downsample branch: 75.6 -> 12.3 GFLOP per 1000x600 frame).  The
+        folded BatchNorm (an affine map with a shift - it does NOT commute with a pooling that drops out-of-map samples)
+        and the ReLU stay behind the pooling, in the RoIAlign kernel's store epilogue, exactly where the reference applies
+        them.  Same function, another rounding order (differences ~1e-6 relative, tests/test_gpu_parity.py)."""
+        blk = self.resnet.layer4[0]
+        bn = blk.batchnorm_en
+        x = to_nhwc(net_conv)
+        w1, s1, b1 = prepared_conv(blk.conv1, blk.bn1, bn)
+        wd, sd, bd = prepared_conv(blk.downsample[0], blk.downsample[1])
+        if x.shape[-1] != w1.shape[-1]:
+            x = ops.pad_channels(x, w1.shape[-1])
+        rois = rois.contiguous()
+        count = self._predictions.get('rois_count')
+        scale = 1.0 / self._feat_stride
+        a1 = ops.roi_align_nhwc(ops.conv2d_nhwc(x, w1), rois, cfg.POOLING_SIZE, scale, ROI_ALIGN_SAMPLING_RATIO,
+                                roi_count=count, scale=s1, shift=b1, relu=True)
+        identity = ops.roi_align_nhwc(ops.conv2d_nhwc(x, wd), rois, cfg.POOLING_SIZE, scale, ROI_ALIGN_SAMPLING_RATIO,
+                                      roi_count=count, scale=sd, shift=bd, relu=False)
+        out = conv_bn_act(a1, blk.conv2, blk.bn2, relu=True, use_bn=bn)
+        y = conv_bn_act(out, blk.conv3, blk.bn3, relu=True, residual=identity, use_bn=bn)
+        for later in list(self.resnet.layer4)[1:]:
+            y = later(y)
+        return y
 
     def _region_classification(self, fc7):
         """cls_score_net + softmax, bbox_pred_net.  Returns (cls_prob, bbox_pred) like the ancestor."""
@@ -371,8 +425,11 @@ class Network(nn.Module):
         rois = self._region_proposal(net_conv)
         if self._mode == 'TRAIN':
             rois = self._training_targets(rois)
-        pool5 = self._crop_pool_layer(net_conv, rois)
-        fc7 = self._head_to_tail(pool5)
+        if self._projected_head_ok():
+            fc7 = self._fc7_from_layer4(self._layer4_projected(net_conv, rois))
+        else:
+            pool5 = self._crop_pool_layer(net_conv, rois)
+            fc7 = self._head_to_tail(pool5)
         cls_prob, bbox_pred = self._region_classification(fc7)
         return rois, cls_prob, bbox_pred
 

@@ -446,17 +446,30 @@ def make_rois(sorted_boxes, sorted_scores, keep_idx, keep_count):
 
 
 def roi_align_nhwc(feat, rois, pooled, spatial_scale, sampling_ratio=0, roi_count=None, level_of_roi=None, level=-1,
-                   out=None, rois_per_image=0):
+                   out=None, rois_per_image=0, scale=None, shift=None, relu=False):
     """feat (N,H,W,C), rois (R,5) -> (R, P, P, C).  ``rois_per_image`` > 0: rows [i*rpi, (i+1)*rpi) belong to image i and
-    ``roi_count`` holds N live counts (frames batched into one call); 0: the image is the RoI's batch column."""
+    ``roi_count`` holds N live counts (frames batched into one call); 0: the image is the RoI's batch column.
+    ``scale`` / ``shift`` (C,) / ``relu``: per-channel epilogue on the pooled values, out = act(pooled * scale + shift)
+    (frcnn_roi_align_fwd_affine)."""
     lib = _hip.load()
     _dev_f32(feat, "feat"); _dev_f32(rois, "rois")
     n, h, w, c = feat.shape
     r = rois.shape[0]
+    for nm, t in (("scale", scale), ("shift", shift)):
+        if t is not None:
+            _dev_f32(t, nm)
+            if t.numel() != c:
+                raise _hip.HipError("roi_align_nhwc: %s has %d elements, expected %d" % (nm, t.numel(), c))
     if out is None:
         out = torch.empty((r, pooled, pooled, c), dtype=torch.float32, device=feat.device)
     ws_bytes = lib.frcnn_roi_align_fwd_ws_bytes(h, w, c, r, pooled)
     ws = _workspace(ws_bytes, feat.device) if ws_bytes else None
+    if scale is not None or shift is not None or relu:
+        _hip.check(lib.frcnn_roi_align_fwd_affine(_ptr(feat), n, h, w, c, _ptr(rois), _ptr(roi_count), r, int(rois_per_image),
+                                                  pooled, float(spatial_scale), int(sampling_ratio), _ptr(level_of_roi), level,
+                                                  _ptr(out), _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(ws), ws_bytes,
+                                                  _stream()), "frcnn_roi_align_fwd_affine")
+        return out
     _hip.check(lib.frcnn_roi_align_fwd(_ptr(feat), n, h, w, c, _ptr(rois), _ptr(roi_count), r, int(rois_per_image), pooled,
                                        float(spatial_scale), int(sampling_ratio), _ptr(level_of_roi), level, _ptr(out),
                                        _ptr(ws), ws_bytes, _stream()), "frcnn_roi_align_fwd")

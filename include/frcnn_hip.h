@@ -255,6 +255,16 @@ size_t frcnn_roi_align_fwd_ws_bytes(int h, int w, int c, int num_rois, int poole
 int frcnn_roi_align_fwd(const float* feat, int n, int h, int w, int c, const float* rois, const int* roi_count,
                         int num_rois, int rois_per_image, int pooled, float spatial_scale, int sampling_ratio,
                         const int* level_of_roi, int level, float* out, void* ws, size_t ws_bytes, void* stream);
+/* frcnn_roi_align_fwd with a per-channel epilogue on the pooled value: out = act(pooled * scale[c] + shift[c]) (scale / shift
+ * device float[c] or NULL, relu 0/1).  Pooling and a bias-free 1x1 convolution commute (both linear, different axes), so
+ * layer4[0].conv1 and layer4[0].downsample[0] - which the reference applies to pool5, lib/nets/resnet.py:98-127 via
+ * _head_to_tail - can run on the H x W feature map BEFORE the pooling (6x fewer pixels than 300 x 7 x 7) with their folded
+ * BatchNorm + ReLU applied here, after the pooling, where the reference applies them.  Not available with the map-resident
+ * kernel (variant 5). */
+int frcnn_roi_align_fwd_affine(const float* feat, int n, int h, int w, int c, const float* rois, const int* roi_count,
+                               int num_rois, int rois_per_image, int pooled, float spatial_scale, int sampling_ratio,
+                               const int* level_of_roi, int level, float* out, const float* scale, const float* shift,
+                               int relu, void* ws, size_t ws_bytes, void* stream);
 
 /* LevelMapper (lib/utils/torchpoolers.py:20-51) of MultiScaleRoIAlign: levels[i] = clamp(floor(canonical_level +
  * log2(sqrt(area_i) / canonical_scale) + eps), k_min, k_max) - k_min for rois (n,5); area without +1. */

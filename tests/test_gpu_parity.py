@@ -521,6 +521,47 @@ def test_roi_align_every_kernel_variant(hip, variant):
     assert (got[3] == 0).all()
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_roi_align_affine_epilogue(hip, variant):
+    """frcnn_roi_align_fwd_affine: out = act(pooled * scale[c] + shift[c]) - the same pooled values as frcnn_roi_align_fwd
+    (bit-equal) with the per-channel terms applied at the store, in every kernel that has the epilogue; RoIs beyond the
+    device-side count hold act(shift) (what a folded BatchNorm makes of a zero row); the map-resident kernel refuses."""
+    from faster_rcnn_pytorch_multimodal_amd import _hip
+    ops = _ops()
+    lib = _hip.load()
+    g = torch.Generator().manual_seed(70 + variant)
+    h, w, c = 38, 63, 320
+    feat = torch.randn(1, h, w, c, generator=g).to(DEV)
+    rois = torch.cat((torch.zeros(50, 1), _rand_boxes(50, g)), 1)
+    rois[0, 1:] = torch.tensor([0., 0, 999, 599])
+    rois[1, 1:] = torch.tensor([990., 590, 1200, 800])
+    rois = rois.to(DEV)
+    scale = (torch.rand(c, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(c, generator=g).to(DEV)
+    cnt = torch.tensor([41], dtype=torch.int32, device=DEV)
+    lib.frcnn_roi_align_set_variant(variant)
+    try:
+        plain = ops.roi_align_nhwc(feat, rois, 7, 1 / 16.0, 0, roi_count=cnt)
+        both = ops.roi_align_nhwc(feat, rois, 7, 1 / 16.0, 0, roi_count=cnt, scale=scale, shift=shift, relu=True)
+        only_shift = ops.roi_align_nhwc(feat, rois, 7, 1 / 16.0, 0, roi_count=cnt, shift=shift)
+        only_relu = ops.roi_align_nhwc(feat, rois, 7, 1 / 16.0, 0, roi_count=cnt, relu=True)
+    finally:
+        lib.frcnn_roi_align_set_variant(0)
+    assert torch.equal(both, torch.clamp_min(plain * scale + shift, 0.0))
+    assert torch.equal(only_shift, plain + shift)
+    assert torch.equal(only_relu, torch.clamp_min(plain, 0.0))
+    assert torch.equal(both[41:], torch.clamp_min(shift, 0.0).expand(9, 7, 7, c))
+    with pytest.raises(_hip.HipError):
+        ops.roi_align_nhwc(feat, rois, 7, 1 / 16.0, 0, scale=scale[:8])
+    if variant == 0:
+        lib.frcnn_roi_align_set_variant(5)
+        try:
+            with pytest.raises(_hip.HipError):
+                ops.roi_align_nhwc(feat, rois, 7, 1 / 16.0, 0, shift=shift)
+        finally:
+            lib.frcnn_roi_align_set_variant(0)
+
+
 def test_roi_align_tall_window_fallback(hip):
     """Windows taller than one row chunk of the planned kernel (64 feature rows, one weight per lane) accumulate over
     several chunks."""
@@ -701,6 +742,30 @@ def _build_pair(seed=5, bn_mode="tame", fixed_blocks=None):
     return net, oracle
 
 
+def _projected_head_against(net, d, rois_r, tail, cp_r):
+    """The inference path's head (Network._layer4_projected: layer4[0].conv1 / downsample[0] on the feature map BEFORE the
+    RoIAlign, their BatchNorm + ReLU in the RoIAlign epilogue) on the oracle's net_conv / rois: against the oracle (same bars
+    as the reference order of operations) and against the reference order on the device (rounding order only)."""
+    from faster_rcnn_pytorch_multimodal_amd.nets import network as N
+    rois_dev = rois_r.contiguous().to(DEV)
+    with torch.no_grad():
+        net._mode = "TEST"
+        assert N.PROJECT_BEFORE_POOLING and net._projected_head_ok()
+        net._predictions["rois_count"] = None
+        y = net._layer4_projected(d["net_conv"].to(DEV), rois_dev)
+        got = net._tail_kernel(y, rois_dev)
+        N.PROJECT_BEFORE_POOLING = False
+        try:
+            assert not net._projected_head_ok()
+        finally:
+            N.PROJECT_BEFORE_POOLING = True
+    _close_feat(got["fc7"].cpu().numpy(), d["fc7"].numpy(), "fc7 (1x1 convolutions before the pooling)", 5e-5)
+    np.testing.assert_allclose(got["cls_prob"].cpu().numpy(), cp_r.numpy(), rtol=0, atol=1e-4)
+    _close_feat(got["fc7"].cpu().numpy(), tail["fc7"].cpu().numpy(), "fc7, projected vs reference order on the device", 2e-5)
+    np.testing.assert_allclose(got["cls_prob"].cpu().numpy(), tail["cls_prob"].cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(got["bbox_pred"].cpu().numpy(), tail["bbox_pred"].cpu().numpy(), rtol=0, atol=2e-5)
+
+
 def test_detector_stagewise_against_oracle(hip):
     """Whole image detector on a 192x320 frame.  Stage outputs are compared where the two paths still
     see the same inputs; the proposal / detection stages are re-run on the ORACLE's intermediate tensors
@@ -741,10 +806,37 @@ def test_detector_stagewise_against_oracle(hip):
         tail = net._tail_kernel(y, rois_r.contiguous().to(DEV))
     _close_feat(tail["fc7"].cpu().numpy(), d["fc7"].numpy(), "fc7", 5e-5)
     np.testing.assert_allclose(tail["cls_prob"].cpu().numpy(), cp_r.numpy(), rtol=0, atol=1e-4)
+    _projected_head_against(net, d, rois_r, tail, cp_r)
     # end to end (conv rounding noise included): same number of proposals is NOT guaranteed, report only
     print("e2e: proposals hip=%d oracle=%d; max |cls_prob diff| on common rows = %.3e" % (
         rois.shape[0], rois_r.shape[0],
         float((cp[:min(len(cp), len(cp_r))].cpu() - cp_r[:min(len(cp), len(cp_r))]).abs().max())))
+
+
+def test_projected_head_end_to_end_equals_reference_order(hip):
+    """test_frame with layer4[0]'s 1x1 convolutions before the pooling (the default) and in the reference's order of
+    operations (nets.network.PROJECT_BEFORE_POOLING = False): identical proposals, class probabilities and deltas equal up
+    to rounding order, identical detection records here."""
+    from faster_rcnn_pytorch_multimodal_amd.model.test import detect_frame_device
+    from faster_rcnn_pytorch_multimodal_amd.nets import network as N
+    net, _ = _build_pair()
+    data = (np.random.default_rng(7).standard_normal((1, 192, 320, 3)) * 50).astype(np.float32)
+    info = np.array([0, 320, 0, 192, 0, 0, 1.0], np.float32)
+    cs, cp, pb, rois, _ = [t.clone() if isinstance(t, torch.Tensor) else t for t in net.test_frame(data, info)]
+    dets, counts = detect_frame_device(net, torch.from_numpy(data).to(DEV), info, 0.3, 100, 100)
+    dets, counts = dets.clone(), counts.clone()
+    N.PROJECT_BEFORE_POOLING = False
+    try:
+        cs2, cp2, pb2, rois2, _ = net.test_frame(data, info)
+        dets2, counts2 = detect_frame_device(net, torch.from_numpy(data).to(DEV), info, 0.3, 100, 100)
+    finally:
+        N.PROJECT_BEFORE_POOLING = True
+    assert torch.equal(rois, rois2)
+    assert float((cp - cp2).abs().max()) <= 2e-5 and float((cs - cs2).abs().max()) <= 5e-5
+    scale = pb2.abs().max().clamp_min(1.0)
+    assert float((pb - pb2).abs().max() / scale) <= 2e-6
+    assert torch.equal(counts, counts2)
+    np.testing.assert_allclose(dets.cpu().numpy(), dets2.cpu().numpy(), rtol=0, atol=2e-3)
 
 
 @pytest.mark.parametrize("num_layers", [50, 152])
@@ -933,6 +1025,7 @@ def test_lidar_detector_stagewise_against_oracle(hip, bev_h, bev_w):
                                         tail["bbox_pred"].cpu() * torch.tensor(O.LIDAR_BBOX_NORMALIZE_STDS).repeat(2), 0.5)
     np.testing.assert_allclose(tail["pred_boxes"].cpu().numpy(), own.numpy(), rtol=3e-7, atol=1e-4)
     np.testing.assert_allclose(tail["pred_boxes"].cpu().numpy(), pb_r.numpy(), rtol=1e-4, atol=2e-3)
+    _projected_head_against(net, d, rois_r, tail, cp_r)
     # per-class filter on the oracle's probabilities / boxes: identical detections (7 box values + score)
     _, ref_boxes = O.filter_and_draw_prep_lidar(rois_r, cp_r, pb_r, 2, thresh=0.3)
     _, got_boxes, _ = filter_and_draw_prep(rois_r.to(DEV), cp_r.contiguous().to(DEV), pb_r.contiguous().to(DEV), {},
