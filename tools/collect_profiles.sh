@@ -35,7 +35,8 @@ S=$O/${TAG}_summary
 mkdir -p $S
 cd $R
 CMD="python3 bench.py --plans <plans of the timed run> --steps 30 --warmup 5 --no-cpu-baseline (4 frames in flight, hipGraph replay)"
-python3 tools/rocpd_summary.py $O/${TAG}_prof/${TAG}_results.db "$CMD" --conv-cross-check > $S/kernel_stats.md
+FLOPS=$(python3 -c "import json,sys; print(json.load(open(sys.argv[1]))['roofline']['flops_per_frame'])" $O/${TAG}_bench.json)
+python3 tools/rocpd_summary.py $O/${TAG}_prof/${TAG}_results.db "$CMD" --conv-cross-check --flops-per-frame=$FLOPS > $S/kernel_stats.md
 python3 tools/pmc_traffic.py $O/${TAG}_pmc_FETCH_SIZE $O/${TAG}_pmc_WRITE_SIZE --mfma=$O/${TAG}_pmc_MfmaUtil "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE|MfmaUtil> --output-format csv -- python3 bench.py --plans <plans of the timed run> --steps 3 --warmup 1 --no-graph --streams 1 --no-cpu-baseline" > $S/pmc_traffic.json
 python3 tools/pmc_mfma.py $O/${TAG}_train_pmc "rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -- python3 tools/bench_configs.py --train --steps 12" --last-frac=0.4 > $S/train_pmc.json
 python3 tools/rocpd_summary.py $O/${TAG}_train_prof/t_results.db "python3 tools/bench_configs.py --train --graph --steps 12 (res101+FPN 1000x600 forward+backward replayed as a hipGraph; includes the plan autotuning launches of the warm-up)" > $S/train_kernel_stats.md

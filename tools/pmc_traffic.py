@@ -19,11 +19,14 @@ import sys
 
 # family -> substring of the kernel name (all template instances of the conv kernel count as one family, like
 # bench.py's per-frcnn_conv2d_fwd-launch timing)
-FAMILIES = {"conv_igemm": "conv_igemm", "roi_align_fwd": "roi_align_fwd", "conv_wgrad_f32": "conv_wgrad_f32"}
+# The RoIAlign launches with the store epilogue (", true>": the two projected maps of a frame, Network._layer4_projected) are a
+# family of their own: "roi_align_fwd" stays the reference's operation on the 1024-channel map (bench.py roi_align_timing).
+FAMILIES = {"conv_igemm": "conv_igemm", "roi_align_fwd_affine": "roi_align_fwd_planned<4, true>",
+            "roi_align_fwd": "roi_align_fwd", "conv_wgrad_f32": "conv_wgrad_f32"}
 # kernels whose bytes are ADDED to a family without counting as launches of it: one RoIAlign operation = the plan kernel
 # + the pooling kernel, reported per operation
 # (same for the other launches of one frcnn_conv2d_fwd call: the split-K second pass and the Winograd transforms)
-COMPANIONS = {"roi_plan_kernel": "roi_align_fwd", "conv_splitk_epilogue": "conv_igemm", "wino_": "conv_igemm"}
+COMPANIONS = {"conv_splitk_epilogue": "conv_igemm", "wino_": "conv_igemm"}
 
 
 # bench.py tunes its conv plans during the first frames (extra candidate launches); its roofline is timed over the
@@ -36,9 +39,13 @@ def per_kernel(directory, counter):
     if not paths:
         raise SystemExit("no *counter_collection.csv under %s" % directory)
     vals, extra = {}, {}
+    plans = []
     with open(paths[0], newline="") as f:
         for row in csv.DictReader(f):
             if row["Counter_Name"] != counter:
+                continue
+            if "roi_plan_kernel" in row["Kernel_Name"]:       # belongs to the pooling launch that follows it
+                plans.append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
                 continue
             for sub, fam in COMPANIONS.items():
                 if sub in row["Kernel_Name"]:
@@ -47,6 +54,11 @@ def per_kernel(directory, counter):
                 if sub in row["Kernel_Name"]:
                     vals.setdefault(fam, []).append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
                     break
+    pools = sorted((d, fam) for fam in ("roi_align_fwd", "roi_align_fwd_affine") for d, _ in vals.get(fam, []))
+    for d, v in plans:
+        nxt = [fam for pd, fam in pools if pd > d]
+        if nxt:
+            extra.setdefault(nxt[0], []).append((d, v))
     acc = {}
     for fam, rows in vals.items():
         rows.sort()

@@ -25,7 +25,7 @@ def main(path, title=""):
         print("| `%s` | %d | %.1f | %.2f | %.2f |" % (short, calls, tot, avg, pct))
 
 
-def conv_cross_check(path, frames=5, launches_per_frame=106):
+def conv_cross_check(path, frames=5, launches_per_frame=106, flops_per_frame=563.85e9):
     """bench.py measures its `roofline` over its LAST `frames` eager frames (after the timed region): sum the
     conv_igemm* dispatches of exactly those frames (plus the split-K second passes that follow them) from the
     per-dispatch table, for comparison with bench.py's kernel_ms_per_frame / avg_launch_us."""
@@ -47,12 +47,13 @@ def conv_cross_check(path, frames=5, launches_per_frame=106):
     print("| + Winograd transform kernels per frame | %.1f us |" % (wino / frames))
     print("| average per frcnn_conv2d_fwd call (all its launches) | %.2f us |"
           % ((igemm + epi + wino) / (frames * launches_per_frame)))
-    print("| => conv rate at 628.4 algorithmic GFLOP/frame | %.1f TFLOP/s |"
-          % (628.4e9 / ((igemm + epi + wino) / frames * 1e-6) / 1e12))
+    print("| => conv rate at %.1f GFLOP/frame (the convolutions as launched, bench.py roofline.flops_per_frame) | %.1f TFLOP/s |"
+          % (flops_per_frame / 1e9, flops_per_frame / ((igemm + epi + wino) / frames * 1e-6) / 1e12))
 
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     main(args[0], " ".join(args[1:]))
     if "--conv-cross-check" in sys.argv:
-        conv_cross_check(args[0])
+        flops = [float(a.split("=", 1)[1]) for a in sys.argv[1:] if a.startswith("--flops-per-frame=")]
+        conv_cross_check(args[0], **({"flops_per_frame": flops[0]} if flops else {}))
