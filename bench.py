@@ -594,8 +594,17 @@ def main(argv=None):
             out["value"] = None
         else:
             conv = conv_roofline(net, frames[0], info, steps=min(args.steps, 5))
-            achieved = conv["flops_per_frame"] / (conv["ms_per_frame"] * 1e-3) / 1e12
-            timed_tflops = conv["flops_per_frame"] / (1e-3 * 1e3 * elapsed / args.steps) / 1e12
+            # ALGORITHMIC FLOPs of a frame's convolutions = SURVEY.md section 8(d) / BASELINE.md section 3: 628.4 GFLOP, the
+            # reference's formulation (direct-form 3x3 convolutions, layer4[0].conv1 / downsample[0] on the pooled RoIs).  The
+            # launches of this build do less arithmetic for the same function (Winograd; those two convolutions moved in front of
+            # the pooling): *_launched counts the direct-form FLOPs of the convolutions as launched, frac_executed what the matrix
+            # pipe really multiplied.
+            from faster_rcnn_pytorch_multimodal_amd.nets import network as _N
+            algorithmic = REFERENCE_ORDER_FLOPS if _N.PROJECT_BEFORE_POOLING else conv["flops_per_frame"]
+            achieved = algorithmic / (conv["ms_per_frame"] * 1e-3) / 1e12
+            achieved_launched = conv["flops_per_frame"] / (conv["ms_per_frame"] * 1e-3) / 1e12
+            timed_tflops = algorithmic / (1e-3 * 1e3 * elapsed / args.steps) / 1e12
+            timed_launched = conv["flops_per_frame"] / (1e-3 * 1e3 * elapsed / args.steps) / 1e12
             out["roofline"] = {
                 "bound": "mfma", "kernel": "frcnn_conv2d_fwd: conv_igemm_* (all instantiations) + split-K second passes + Winograd "
                 "transforms, %d calls/frame" % round(conv["launches_per_frame"]), "achieved": achieved,
@@ -605,7 +614,10 @@ def main(argv=None):
                         "events (hipExtLaunchKernelGGL) = rocprofv3's per-dispatch duration; avg_launch_us is per "
                         "frcnn_conv2d_fwd call (every launch it makes); the timed run overlaps %d frames, see "
                         "frac_timed" % n_streams,
+                "achieved_launched": achieved_launched, "frac_launched": achieved_launched / MFMA_F32_PEAK_TFLOPS,
+                "algorithmic_flops_per_frame": algorithmic,
                 "achieved_timed": timed_tflops, "frac_timed": timed_tflops / MFMA_F32_PEAK_TFLOPS,
+                "frac_timed_launched": timed_launched / MFMA_F32_PEAK_TFLOPS,
                 "frac_timed_what": "all conv FLOPs of a frame / ms_per_step of the TIMED run (hipGraph x %d streams) / "
                                    "peak: a lower bound on the conv kernels' rate in the timed mode, since the step also "
                                    "holds every non-conv kernel" % n_streams,
@@ -615,7 +627,9 @@ def main(argv=None):
                 "main_kernel_avg_us": conv["main_kernel_avg_us"],
                 "second_pass_launches_per_frame": conv["second_pass_launches_per_frame"],
                 "second_pass_avg_us": conv["second_pass_avg_us"],
-                "flops_what": "achieved / frac count the ALGORITHMIC FLOPs of the convolutions (direct form, BASELINE.md section 3); "
+                "flops_what": "achieved / frac / frac_timed count the ALGORITHMIC FLOPs of the frame's convolutions (628.4 GFLOP: direct "
+                              "form, the reference's order of operations - SURVEY.md section 8(d), BASELINE.md section 3); "
+                              "*_launched count flops_per_frame, the direct-form FLOPs of the convolutions as launched; "
                               "%d of the %d calls per frame ran as Winograd F(2x2,3x3) (autotuned; same fp32 arithmetic, "
                               "2.25x fewer multiplications), so the MFMA pipe executed executed_flops_per_frame: "
                               "frac_executed is its utilisation" % (round(conv["winograd_calls_per_frame"]),
@@ -625,7 +639,7 @@ def main(argv=None):
                               "the RoIAlign instead of on 300x7x7 pooled pixels after it (pooling and a 1x1 convolution "
                               "commute; BatchNorm + ReLU stay behind the pooling, in the RoIAlign epilogue): flops_per_frame "
                               "counts the convolutions as LAUNCHED, i.e. %.1f GFLOP less than the reference's order of "
-                              "operations (reference_order_flops_per_frame)"
+                              "operations (reference_order_flops_per_frame = algorithmic_flops_per_frame)"
                               % ((REFERENCE_ORDER_FLOPS - conv["flops_per_frame"]) / 1e9),
                 "executed_flops_per_frame": conv["executed_flops_per_frame"],
                 "frac_executed": conv["executed_flops_per_frame"] / (1e-3 * conv["ms_per_frame"]) / 1e12 / MFMA_F32_PEAK_TFLOPS,

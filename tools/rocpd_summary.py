@@ -49,6 +49,8 @@ def conv_cross_check(path, frames=5, launches_per_frame=106, flops_per_frame=563
           % ((igemm + epi + wino) / (frames * launches_per_frame)))
     print("| => conv rate at %.1f GFLOP/frame (the convolutions as launched, bench.py roofline.flops_per_frame) | %.1f TFLOP/s |"
           % (flops_per_frame / 1e9, flops_per_frame / ((igemm + epi + wino) / frames * 1e-6) / 1e12))
+    print("| => conv rate at 628.4 algorithmic GFLOP/frame (the reference's order of operations, SURVEY.md section 8(d)) | %.1f TFLOP/s |"
+          % (628.4e9 / ((igemm + epi + wino) / frames * 1e-6) / 1e12))
 
 
 if __name__ == "__main__":
