@@ -532,3 +532,117 @@ extern "C" int frcnn_proposal_target_layer_lidar(const float* rois, const float*
                        stds_host, seed, seed_dev, labels, out_rois, out_scores, targets, inside, outside, gt_assignment, counts,
                        stream_);
 }
+
+// ------------------------------------------------------------------------------------------------
+// The RPN losses read the anchors the anchor target layer labelled - at most cfg.TRAIN.RPN_BATCHSIZE of them
+// (lib/layer_utils/anchor_target_layer.py:91-107) - so the gradient of the RPN head is non-zero on at most that many
+// PIXELS of the feature map.  These three kernels let the training step run the RPN's differentiable pass on those pixels
+// only (nets/network.py: _rpn_losses_on_labelled_pixels): the list of pixels that carry a labelled anchor, the R x S input
+// patches around them, and the scatter of the patch gradients back into the map.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int AP_THREADS = 1024;
+
+// pixels (ascending) with at least one label != -1; idx[i] = -1 for i >= count[0].  count[0] = min(total, cap), count[1] = total
+__global__ __launch_bounds__(AP_THREADS) void labelled_pixels_kernel(const float* __restrict__ labels, int hw, int A, int cap,
+                                                                     int64_t* __restrict__ idx, int* __restrict__ count) {
+  __shared__ int s_wave[AP_THREADS / 64];
+  __shared__ int s_base;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) s_base = 0;
+  for (int i = t; i < cap; i += AP_THREADS) idx[i] = -1;
+  __syncthreads();
+  for (int p0 = 0; p0 < hw; p0 += AP_THREADS) {
+    const int px = p0 + t;
+    bool on = false;
+    if (px < hw)
+      for (int a = 0; a < A; ++a) on = on || labels[(size_t)px * A + a] != -1.0f;
+    const unsigned long long m = __ballot(on);
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int before = s_base;
+    for (int w = 0; w < wave; ++w) before += s_wave[w];
+    const int pos = before + __popcll(m & ((1ull << lane) - 1ull));
+    if (on && pos < cap) idx[pos] = px;
+    __syncthreads();
+    if (t == 0) {
+      int tot = s_base;
+      for (int w = 0; w < AP_THREADS / 64; ++w) tot += s_wave[w];
+      s_base = tot;
+    }
+    __syncthreads();
+  }
+  if (t == 0) { count[0] = min(s_base, cap); count[1] = s_base; }
+}
+
+// out[i][r][s][:] = x[py + r - pad][px + s - pad][:] (zero outside the map and for i >= count); C4 = C / 4
+__global__ __launch_bounds__(256) void gather_patches_kernel(const float* __restrict__ x, int H, int W, int C4,
+                                                            const int64_t* __restrict__ idx, const int* __restrict__ count,
+                                                            int cap, int R, int S, int pad, float* __restrict__ out) {
+  const size_t total = (size_t)cap * R * S * C4;
+  const int live = min(*count, cap);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    size_t q = i / C4;
+    const int s = (int)(q % S); q /= S;
+    const int r = (int)(q % R);
+    const int row = (int)(q / R);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < live) {
+      const int p = (int)idx[row];
+      const int y = p / W + r - pad, xx = p % W + s - pad;
+      if (p >= 0 && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W)
+        v = reinterpret_cast<const float4*>(x)[((size_t)y * W + xx) * C4 + c4];
+    }
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+
+// dx[py + r - pad][px + s - pad][:] += d[i][r][s][:]; patches of neighbouring pixels overlap -> float atomics
+__global__ __launch_bounds__(256) void scatter_add_patches_kernel(const float* __restrict__ d, int H, int W, int C,
+                                                                 const int64_t* __restrict__ idx,
+                                                                 const int* __restrict__ count, int cap, int R, int S, int pad,
+                                                                 float* __restrict__ dx) {
+  const int live = min(*count, cap);
+  const size_t total = (size_t)live * R * S * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t q = i / C;
+    const int s = (int)(q % S); q /= S;
+    const int r = (int)(q % R);
+    const int row = (int)(q / R);
+    const int p = (int)idx[row];
+    const int y = p / W + r - pad, xx = p % W + s - pad;
+    if (p >= 0 && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W)
+      atomicAdd(dx + ((size_t)y * W + xx) * C + c, d[i]);
+  }
+}
+}  // namespace
+
+extern "C" int frcnn_labelled_pixels(const float* labels, int hw, int num_anchors, int cap, int64_t* idx, int* count,
+                                     void* stream_) {
+  FRCNN_REQUIRE(labels && idx && count && hw > 0 && num_anchors > 0 && cap > 0, "labelled_pixels: bad arguments");
+  hipLaunchKernelGGL(labelled_pixels_kernel, dim3(1), dim3(AP_THREADS), 0, static_cast<hipStream_t>(stream_), labels, hw,
+                     num_anchors, cap, idx, count);
+  return check_launch("labelled_pixels_kernel");
+}
+
+extern "C" int frcnn_gather_patches(const float* x, int h, int w, int c, const int64_t* idx, const int* count, int cap, int r,
+                                    int s, int pad, float* out, void* stream_) {
+  FRCNN_REQUIRE(x && idx && count && out && h > 0 && w > 0 && c > 0 && c % 4 == 0 && cap > 0 && r > 0 && s > 0 && pad >= 0,
+                "gather_patches: bad arguments (c%%4==0)");
+  const size_t total = (size_t)cap * r * s * (c / 4);
+  hipLaunchKernelGGL(gather_patches_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), x, h, w, c / 4, idx, count, cap, r, s, pad, out);
+  return check_launch("gather_patches_kernel");
+}
+
+extern "C" int frcnn_scatter_add_patches(const float* d, int h, int w, int c, const int64_t* idx, const int* count, int cap,
+                                         int r, int s, int pad, float* dx, void* stream_) {
+  FRCNN_REQUIRE(d && idx && count && dx && h > 0 && w > 0 && c > 0 && cap > 0 && r > 0 && s > 0 && pad >= 0,
+                "scatter_add_patches: bad arguments");
+  const size_t total = (size_t)cap * r * s * c;
+  hipLaunchKernelGGL(scatter_add_patches_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), d, h, w, c, idx, count, cap, r, s, pad, dx);
+  return check_launch("scatter_add_patches_kernel");
+}

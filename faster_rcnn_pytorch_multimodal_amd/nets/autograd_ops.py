@@ -495,6 +495,37 @@ def spatial_mean_train(x):
     return _SpatialMeanFn.apply(x)
 
 
+class _GatherPatchesFn(torch.autograd.Function):
+    """The r x s windows of a (1,H,W,C) map around a device-side list of pixels (ops.gather_patches); backward scatters the
+    window gradients back into a zero map (float atomics, like the RoIAlign backward)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, count, r, s, pad):
+        ctx.meta = (x.shape[1], x.shape[2], pad)
+        ctx.save_for_backward(idx, count)
+        return ops.gather_patches(x, idx, count, r, s, pad)
+
+    @staticmethod
+    def backward(ctx, d):
+        idx, count = ctx.saved_tensors
+        h, w, pad = ctx.meta
+        return ops.scatter_add_patches(d.contiguous(), idx, count, h, w, pad), None, None, None, None, None
+
+
+def conv_on_patches_train(x, idx, count, conv, holder, relu=True):
+    """act(conv(x)) at the listed pixels ONLY, differentiable: a stride-1 padded convolution evaluated at pixel p is the VALID
+    convolution of the r x s window around p, so the result (cap, 1, 1, K) equals rows ``idx`` of the dense output and its
+    backward costs cap output pixels instead of H x W.  ``holder`` owns the caches of this form (the dense form of the same
+    module keeps its own on the module)."""
+    r, s = conv.kernel_size
+    stride, pad = _stride_pad(conv)
+    if stride != 1:
+        raise NotImplementedError("conv_on_patches_train: stride-1 convolutions only")
+    patches = _GatherPatchesFn.apply(x, idx, count, r, s, pad)
+    w_krsc, _, shift = prepared_conv(conv, None, False)
+    return _ConvFn.apply(patches, None, conv.weight, conv.bias, (w_krsc, None, shift, 1, 0, relu, holder))
+
+
 class _RpnLossFn(torch.autograd.Function):
     """cross_entropy over labelled anchors + smooth_l1_loss('RPN', ...) on the fused RPN head output."""
 

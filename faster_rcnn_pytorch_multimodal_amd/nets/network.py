@@ -35,7 +35,7 @@ from ..utils.bbox import bbaa_graphics_gems
 from . import resnet as custom_resnet
 from . import autograd_ops
 from . import uncertainty
-from .autograd_ops import (conv_bn_act_train, det_loss_train, fused_head_train, fused_head_weights, linear_train,
+from .autograd_ops import (_Holder, conv_bn_act_train, conv_on_patches_train, det_loss_train, fused_head_train, fused_head_weights, linear_train,
                            roi_align_train, rpn_loss_train, spatial_mean_train)
 from .hip_modules import conv_bn_act, pad4, prepared_conv, to_nchw_view, to_nhwc
 
@@ -43,6 +43,9 @@ ROI_ALIGN_SAMPLING_RATIO = 0
 # inference runs layer4[0]'s input-side 1x1 convolutions on the feature map, before the RoIAlign (Network._layer4_projected);
 # False: the reference's order of operations (pool, then convolve 300 x 7 x 7 pixels)
 PROJECT_BEFORE_POOLING = True
+# training runs the RPN's differentiable pass on the pixels that carry a labelled anchor only (Network._rpn_losses_on_labelled_pixels);
+# False: dense backward through the whole RPN head
+RPN_BACKWARD_ON_LABELLED_PIXELS = True
 UC_SEED_RANK_STRIDE = 7919        # decorrelates the uncertainty heads' random draws across data-parallel ranks
 # FPN choices the missing network.py leaves open (DESIGN.md "reconstructed contract"):
 FPN_RPN_LEVEL = 0                 # the RPN runs on p2 only (_feat_stride = 4, lib/nets/imagenet.py:34)
@@ -189,14 +192,61 @@ class Network(nn.Module):
 
     def _rpn_head(self, net_conv_nhwc):
         """relu(rpn_net) then the fused cls+bbox 1x1.  Returns (1, H, W, ld >= 6A) NHWC logits|deltas."""
-        if torch.is_grad_enabled():
+        self._rpn_grad_src = None
+        if torch.is_grad_enabled() and not self._rpn_backward_on_labelled_pixels():
             rpn = conv_bn_act_train(net_conv_nhwc, self.rpn_net, None, relu=True)
             self._act_summaries['rpn'] = rpn
             return fused_head_train(rpn, self, self.rpn_cls_score_net, self.rpn_bbox_pred_net, '_rpn_fused_cache')
+        if torch.is_grad_enabled():
+            # training: the dense head only feeds the proposal layer (which detaches it anyway, proposal_layer.py:18-57); the
+            # differentiable pass runs later on the labelled pixels alone (_rpn_losses_on_labelled_pixels)
+            with torch.no_grad():
+                out = self._rpn_head(net_conv_nhwc.detach())
+            self._rpn_grad_src = net_conv_nhwc
+            return out
         rpn = conv_bn_act(net_conv_nhwc, self.rpn_net, None, relu=True)
         self._act_summaries['rpn'] = rpn
         w, b = self._fused_rpn_head()
         return ops.conv2d_nhwc(rpn, w, None, b, None, stride=1, pad=0, relu=False)
+
+    def _rpn_backward_on_labelled_pixels(self):
+        """Training: may the RPN's differentiable pass be restricted to the pixels that carry a labelled anchor?  Yes for the
+        plain losses (cross-entropy over labels != -1, smooth-L1 with zero inside-weights elsewhere: no other anchor
+        contributes to loss or gradient); not with the RPN uncertainty heads, whose terms read every anchor."""
+        if not RPN_BACKWARD_ON_LABELLED_PIXELS or self._mode != 'TRAIN':
+            return False
+        if any(cfg.UC.get(k, False) for k in ('EN_RPN_BBOX_ALEATORIC', 'EN_RPN_CLS_ALEATORIC', 'EN_RPN_BBOX_EPISTEMIC',
+                                               'EN_RPN_CLS_EPISTEMIC')):
+            return False
+        conv = self.rpn_net
+        return tuple(conv.stride) == (1, 1) and conv.groups == 1 and tuple(conv.dilation) == (1, 1)
+
+    def _rpn_losses_on_labelled_pixels(self, at):
+        """(cross-entropy, box loss) of the RPN and their gradients, evaluated on the labelled pixels only.
+
+        The anchor target layer labels at most cfg.TRAIN.RPN_BATCHSIZE anchors (anchor_target_layer.py:91-107); every other
+        anchor has label -1 and zero inside-weights, i.e. contributes neither to the losses nor to any gradient.  So the
+        head is re-evaluated - differentiably - at the <= 256 pixels that carry a labelled anchor: rpn_net as a VALID
+        convolution of the 3x3 windows around them, the fused cls | bbox 1x1 on the 256 results, the same loss kernel on
+        the gathered target rows.  Same loss, same gradients (zeros are simply not summed); the backward of the two RPN
+        convolutions shrinks from H x W to 256 output pixels (on the FPN's p2: 37 500 -> 256, 177 GFLOP per step)."""
+        x, self._rpn_grad_src = self._rpn_grad_src, None
+        hw, a = x.shape[1] * x.shape[2], self._num_anchors
+        labels = at['labels'].contiguous().view(-1)
+        cap = int(cfg.TRAIN.RPN_BATCHSIZE)
+        if getattr(self, '_target_override', None):
+            # injected targets (tests) need not respect the sampler's cap: size the list for them (host sync, tests only)
+            cap = max(cap, int((labels.view(hw, a) != -1).any(1).sum().item()))
+        idx, count = ops.labelled_pixels(labels, hw, a, cap)
+        hidden = conv_on_patches_train(x, idx, count, self.rpn_net, _Holder.of(self, '_rpn_patch'), relu=True)
+        out = fused_head_train(hidden, self, self.rpn_cls_score_net, self.rpn_bbox_pred_net, '_rpn_fused_cache').view(cap, -1)
+        live = count[0:1]
+        # rows past the count: label -1 (ignored), zero targets and weights
+        lab = ops.gather_rows((labels + 1.0).view(hw, a), idx, live) - 1.0
+        tgt, inw, outw = (ops.gather_rows(at[k].contiguous().view(hw, 4 * a), idx, live).view(cap * a, 4)
+                          for k in ('targets', 'inside', 'outside'))
+        self._predictions['rpn_labelled_pixels'] = (idx, count)
+        return rpn_loss_train(out, lab.view(-1), tgt, inw, outw, a)
 
     def _region_proposal(self, net_conv):
         """RPN head -> proposal_layer.  Returns rois (post_nms_topN, 5) [0,x1,y1,x2,y2]; rows past
@@ -474,8 +524,11 @@ class Network(nn.Module):
         p, at, pt = self._predictions, self._anchor_targets, self._proposal_targets
         rpn_out = p['rpn_out']
         hw, ld = rpn_out.shape[1] * rpn_out.shape[2], rpn_out.shape[3]
-        rpn_l = rpn_loss_train(rpn_out.view(hw, ld), at['labels'], at['targets'], at['inside'], at['outside'],
-                               self._num_anchors)
+        if getattr(self, '_rpn_grad_src', None) is not None:
+            rpn_l = self._rpn_losses_on_labelled_pixels(at)
+        else:
+            rpn_l = rpn_loss_train(rpn_out.view(hw, ld), at['labels'], at['targets'], at['inside'], at['outside'],
+                                   self._num_anchors)
         lidar = (tuple(cfg.LIDAR.REG_LOSS_WEIGHT), bool(cfg.LIDAR.EN_RY_SIN)) if cfg.NET_TYPE == 'lidar' else None
         if cfg.UC.EN_BBOX_ALEATORIC or cfg.UC.EN_CLS_ALEATORIC:
             det_l = uncertainty.det_loss_uc(self, pt['labels'], pt['targets'], pt['inside'], pt['outside'], lidar)

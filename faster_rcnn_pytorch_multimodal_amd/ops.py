@@ -693,6 +693,46 @@ def roi_align_bwd(dout, feat_shape, rois, spatial_scale, sampling_ratio=0, roi_c
     return dfeat
 
 
+def labelled_pixels(labels, hw, num_anchors, cap):
+    """labels (hw * A,) in (H,W,A) order -> (idx int64 (cap,), count int32 (2,) = [min(total, cap), total]): the pixels that
+    carry at least one anchor with a label != -1, ascending; -1 beyond the count (frcnn_labelled_pixels)."""
+    lib = _hip.load()
+    _dev_f32(labels, "labels")
+    if labels.numel() != hw * num_anchors:
+        raise _hip.HipError("labelled_pixels: labels has %d elements, expected %d x %d" % (labels.numel(), hw, num_anchors))
+    idx = torch.empty((cap,), dtype=torch.int64, device=labels.device)
+    count = torch.empty((2,), dtype=torch.int32, device=labels.device)
+    _hip.check(lib.frcnn_labelled_pixels(_ptr(labels), hw, num_anchors, cap, _ptr(idx), _ptr(count), _stream()),
+               "frcnn_labelled_pixels")
+    return idx, count
+
+
+def gather_patches(x, idx, count, r, s, pad):
+    """x (1,H,W,C), idx (cap,) pixels -> (cap, r, s, C): the r x s windows around the listed pixels (frcnn_gather_patches)."""
+    lib = _hip.load()
+    _dev_f32(x, "x")
+    n, h, w, c = x.shape
+    if n != 1:
+        raise _hip.HipError("gather_patches: one image per call")
+    cap = idx.numel()
+    out = torch.empty((cap, r, s, c), dtype=torch.float32, device=x.device)
+    _hip.check(lib.frcnn_gather_patches(_ptr(x), h, w, c, _ptr(idx), _ptr(count), cap, r, s, pad, _ptr(out), _stream()),
+               "frcnn_gather_patches")
+    return out
+
+
+def scatter_add_patches(d, idx, count, h, w, pad, out=None):
+    """Adjoint of gather_patches: d (cap, r, s, C) -> dx (1,h,w,C) (zero-filled here unless ``out`` is given; float atomics)."""
+    lib = _hip.load()
+    _dev_f32(d, "d")
+    cap, r, s, c = d.shape
+    if out is None:
+        out = torch.zeros((1, h, w, c), dtype=torch.float32, device=d.device)
+    _hip.check(lib.frcnn_scatter_add_patches(_ptr(d), h, w, c, _ptr(idx), _ptr(count), cap, r, s, pad, _ptr(out), _stream()),
+               "frcnn_scatter_add_patches")
+    return out
+
+
 def rpn_loss(rpn, num_anchors, labels, targets, inside, outside, grad_ce=1.0, grad_box=1.0, want_grad=True):
     """rpn (HW, ld) fused head output.  Returns (losses (3,) [ce, box, count], drpn or None)."""
     lib = _hip.load()

@@ -373,6 +373,19 @@ int frcnn_roi_align_bwd(const float* dout, int h, int w, int c, const float* roi
                         int num_rois, int pooled, float spatial_scale, int sampling_ratio, const int* level_of_roi,
                         int level, float* dfeat, void* stream);
 
+/* The RPN losses read only the anchors the anchor target layer labelled (<= cfg.TRAIN.RPN_BATCHSIZE,
+ * lib/layer_utils/anchor_target_layer.py:91-107), so the gradient of the RPN head is non-zero on at most that many pixels.
+ * frcnn_labelled_pixels: labels (hw * A) in (H,W,A) order -> idx[cap] = the pixels with a label != -1, ascending, -1 beyond
+ * count[0]; count[0] = min(total, cap), count[1] = total (a caller checks count[1] <= cap where the labels are not its own).
+ * frcnn_gather_patches: out (cap, r, s, c) = the r x s window of x (h, w, c) around each listed pixel (zero outside the map and
+ * for rows >= count[0]) - the input of a VALID r x s convolution that reproduces the padded convolution at those pixels
+ * (lib/nets/network.py rpn_net on net_conv).  frcnn_scatter_add_patches: its adjoint, dx += scatter(d) with float atomics. */
+int frcnn_labelled_pixels(const float* labels, int hw, int num_anchors, int cap, int64_t* idx, int* count, void* stream);
+int frcnn_gather_patches(const float* x, int h, int w, int c, const int64_t* idx, const int* count, int cap, int r, int s,
+                         int pad, float* out, void* stream);
+int frcnn_scatter_add_patches(const float* d, int h, int w, int c, const int64_t* idx, const int* count, int cap, int r, int s,
+                              int pad, float* dx, void* stream);
+
 /* RPN losses on the fused head output rpn (hw, ld) = [A bg | A fg | 4A deltas | pad]:
  *   losses[0] = F.cross_entropy over anchors with labels != -1 (mean), losses[1] = smooth_l1_loss('RPN', ...,
  *   dim=[1,2,3]) (lib/utils/loss_utils.py:39-101), losses[2] = number of labelled anchors.

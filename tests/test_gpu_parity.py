@@ -1764,6 +1764,77 @@ def _assert_derived_weights_fresh(net, what):
     return checked
 
 
+def test_labelled_pixels_gather_and_scatter_patches(hip):
+    """frcnn_labelled_pixels / frcnn_gather_patches / frcnn_scatter_add_patches: the ascending list of pixels with a label
+    != -1 (capacity-limited, total reported), the 3x3 windows around them with zeros outside the map and past the count, and
+    the adjoint <gather(x), d> == <x, scatter(d)>."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(91)
+    h, w, a, c = 13, 17, 5, 24
+    labels = -torch.ones(h * w, a)
+    picks = torch.randperm(h * w, generator=g)[:40]
+    picks = torch.cat((picks, torch.tensor([0, w - 1, (h - 1) * w, h * w - 1])))         # the four corners too
+    for p in picks.tolist():
+        labels[p, int(torch.randint(0, a, (1,), generator=g))] = float(torch.randint(0, 2, (1,), generator=g))
+    want = np.unique(picks.numpy())
+    idx, count = ops.labelled_pixels(labels.view(-1).to(DEV), h * w, a, 64)
+    assert count.cpu().tolist() == [len(want), len(want)]
+    np.testing.assert_array_equal(idx.cpu().numpy()[:len(want)], want)
+    assert (idx.cpu().numpy()[len(want):] == -1).all()
+    idx_small, count_small = ops.labelled_pixels(labels.view(-1).to(DEV), h * w, a, 10)   # capacity below the total
+    assert count_small.cpu().tolist() == [10, len(want)]
+    np.testing.assert_array_equal(idx_small.cpu().numpy(), want[:10])
+    x = torch.randn(1, h, w, c, generator=g)
+    got = ops.gather_patches(x.to(DEV), idx, count, 3, 3, 1).cpu()
+    xp = F.pad(x[0].permute(2, 0, 1), (1, 1, 1, 1)).permute(1, 2, 0)                     # (h+2, w+2, c)
+    for i, p in enumerate(want.tolist()):
+        y, xx = divmod(p, w)
+        assert torch.equal(got[i], xp[y:y + 3, xx:xx + 3]), p
+    assert (got[len(want):] == 0).all()
+    d = torch.randn(64, 3, 3, c, generator=g)
+    dx = ops.scatter_add_patches(d.to(DEV), idx, count, h, w, 1).cpu()
+    lhs = float((got.double() * d.double()).sum())
+    rhs = float((x.double() * dx.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (lhs, rhs)
+
+
+def test_rpn_backward_on_labelled_pixels_equals_dense_backward(hip):
+    """The training step with the RPN's differentiable pass restricted to the pixels that carry a labelled anchor
+    (nets.network.RPN_BACKWARD_ON_LABELLED_PIXELS, the default) against the dense backward through the whole head: same four
+    losses, same gradient for every parameter (res101+FPN, 256x320, sampling seeds shared)."""
+    from faster_rcnn_pytorch_multimodal_amd.nets import network as N
+    net, _ = _build_fpn_pair(seed=23)
+    data, info, gt, _, _ = _fpn_case()
+    net.train()
+    blobs = {"data": data, "info": info, "gt_boxes": gt, "gt_boxes_dc": np.zeros((0, 4), np.float32)}
+    results = []
+    for sparse in (True, False):
+        N.RPN_BACKWARD_ON_LABELLED_PIXELS = sparse
+        try:
+            for p in net.parameters():
+                p.grad = None
+            torch.manual_seed(77)
+            net.forward(blobs["data"], blobs["info"], blobs["gt_boxes"], None, mode="TRAIN")
+            assert ("rpn_labelled_pixels" in net._predictions) == sparse
+            if sparse:
+                idx, count = net._predictions["rpn_labelled_pixels"]
+                n_lab = int((net._anchor_targets["labels"] != -1).sum())
+                assert 0 < int(count[1]) <= min(n_lab, N.cfg.TRAIN.RPN_BATCHSIZE) and int(count[0]) == int(count[1])
+            net.backward(net._losses["total_loss"])
+            torch.cuda.synchronize()
+            results.append(({k: float(v) for k, v in net._losses.items()},
+                            {n_: p.grad.clone() for n_, p in net.named_parameters() if p.grad is not None}))
+        finally:
+            N.RPN_BACKWARD_ON_LABELLED_PIXELS = True
+    (l_s, g_s), (l_d, g_d) = results
+    for k in l_d:
+        assert abs(l_s[k] - l_d[k]) <= 2e-5 * max(1.0, abs(l_d[k])), (k, l_s[k], l_d[k])
+    assert set(g_s) == set(g_d) and any(k.startswith("rpn_net") for k in g_d)
+    floor = 0.01 * max(float(v.abs().max()) for v in g_d.values())
+    worst = max(float((g_s[k] - g_d[k]).abs().max()) / max(float(g_d[k].abs().max()), floor) for k in g_d)
+    assert worst <= 1e-4, "gradients differ by %.3e of their scale" % worst
+
+
 def test_train_step_as_hipgraph_equals_eager_step(hip):
     """model/train_graph.TrainStepRunner: the captured training step (forward, target layers with device-side seeds, losses,
     backward with the filter gradients on a side stream) replayed per frame gives the eager step's losses and gradients, keeps
