@@ -1566,10 +1566,23 @@ extern "C" size_t frcnn_conv2d_bwd_data_ws_bytes(int n, int h, int w, int c, int
   return dil + frcnn_conv2d_fwd_ws_bytes(n, g.hd, g.wd, k, c, r, s, 1, g.pad_t, 0);
 }
 
+extern "C" int frcnn_conv2d_bwd_data_pre(const float* dy, const float* w_crsk_flipped, const float* w_winograd,
+                                         const float* add, float* dx, int n, int h, int w, int c, int k, int r, int s,
+                                         int stride, int pad, void* ws, size_t ws_bytes, void* stream_);
+
 extern "C" int frcnn_conv2d_bwd_data(const float* dy, const float* w_crsk_flipped, const float* add, float* dx, int n,
                                      int h, int w, int c, int k, int r, int s, int stride, int pad, void* ws,
                                      size_t ws_bytes, void* stream_) {
+  return frcnn_conv2d_bwd_data_pre(dy, w_crsk_flipped, nullptr, add, dx, n, h, w, c, k, r, s, stride, pad, ws, ws_bytes,
+                                   stream_);
+}
+
+extern "C" int frcnn_conv2d_bwd_data_pre(const float* dy, const float* w_crsk_flipped, const float* w_winograd,
+                                         const float* add, float* dx, int n, int h, int w, int c, int k, int r, int s,
+                                         int stride, int pad, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FRCNN_REQUIRE(!w_winograd || (stride == 1 && !add && winograd_ok(r, s, 1, r - 1 - pad, k, c, 1)),
+                "conv2d_bwd_data_pre: a Winograd filter only goes with a 3x3 / stride 1 / pad 1 layer without `add`");
   FRCNN_REQUIRE(dy && w_crsk_flipped && dx, "conv2d_bwd_data: null tensor");
   FRCNN_REQUIRE(dgrad_args_ok(n, h, w, c, k, r, s, stride, pad),
                 "conv2d_bwd_data: bad shape n=%d h=%d w=%d c=%d k=%d r=%d s=%d stride=%d pad=%d (need c%%4==0, k%%4==0, "
@@ -1580,7 +1593,7 @@ extern "C" int frcnn_conv2d_bwd_data(const float* dy, const float* w_crsk_flippe
     return frcnn::fail(FRCNN_ERR_WS, "conv2d_bwd_data: workspace %zu < %zu bytes", ws_bytes, need);
   if (stride == 1)  // dx (n,h,w,c) = conv(dy (n,ho,wo,k), w^T flipped), same-size output
     return run_conv(dy, w_crsk_flipped, nullptr, nullptr, add, dx, n, g.ho, g.wo, k, c, r, s, 1, g.pad_t, 0, 0, ws,
-                    ws_bytes, stream, 1, 0, 0);
+                    ws_bytes, stream, 1, 0, 0, w_winograd);
   if (!g.dilate) {
     // strided 1x1: only pixels (ho*stride, wo*stride) receive a gradient; the rest is `add` (or zero)
     const size_t bytes = (size_t)n * h * w * c * sizeof(float);

@@ -92,6 +92,26 @@ def _transposed_filter(conv_like, w_krsc):
                         refresh=lambda: _transposed_filter(conv_like, w_krsc))[0]
 
 
+def _dgrad_winograd(conv_like, w_t, x_shape, stride, pad):
+    """Winograd transform of the data-gradient filter ``w_t`` (C,3,3,K), cached next to it: the weights change once per
+    optimizer step, the data gradient runs once per frame.  None when that convolution's plan is not a Winograd plan (see
+    hip_modules._winograd_filter for the rules; a miss inside a stream capture raises)."""
+    c, r, s, k = w_t.shape
+    if not ops.dgrad_winograd_wanted(x_shape, k, r, s, stride, pad):
+        conv_like.__dict__.pop('_frcnn_dgrad_winograd', None)
+        conv_like.__dict__.pop('_frcnn_dgrad_winograd_refresh', None)
+        return None
+    cache = conv_like.__dict__.get('_frcnn_dgrad_winograd')
+    key = (w_t.data_ptr(), w_t._version)
+    if cache is not None and cache[0] == key:
+        return cache[1][0]
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("Winograd data-gradient filter of a %dx%dx3x3 layer is not prepared: run an eager step before capturing"
+                           % (k, c))
+    return stable_store(conv_like, '_frcnn_dgrad_winograd', key, (ops.winograd_filter(w_t),),
+                        refresh=lambda: _dgrad_winograd(conv_like, w_t, x_shape, stride, pad))[0]
+
+
 def _param_grad_from_krsc(dw_krsc, param):
     """(K,R,S,Cpad) -> the parameter's own layout ((K,C,R,S) conv, (out,in) linear)."""
     k, r, s, _ = dw_krsc.shape
@@ -145,7 +165,9 @@ class _ConvFn(torch.autograd.Function):
             if bias is not None and need_b:
                 db = grads[-1]
         if need_x:
-            dx = ops.conv2d_bwd_data(d_conv, _transposed_filter(owner, w_krsc), tuple(x.shape), stride=stride, pad=pad)
+            w_t = _transposed_filter(owner, w_krsc)
+            dx = ops.conv2d_bwd_data(d_conv, w_t, tuple(x.shape), stride=stride, pad=pad,
+                                     w_winograd=_dgrad_winograd(owner, w_t, tuple(x.shape), stride, pad))
         return dx, d_res, dw, db, None
 
 
@@ -366,7 +388,9 @@ class _BottleneckFn(torch.autograd.Function):
         d_o2 = ops.conv2d_bwd_data(dz3, _transposed_filter(blk.conv3, p3[0]), tuple(o2.shape))
         dz2, _ = ops.act_bwd(d_o2, o2, p2[1], relu=True)
         dw2 = wg(o1, dz2, blk.conv2, 3, s2, 1) if need_w[1] else None
-        d_o1 = ops.conv2d_bwd_data(dz2, _transposed_filter(blk.conv2, p2[0]), tuple(o1.shape), stride=s2, pad=1)
+        w2_t = _transposed_filter(blk.conv2, p2[0])
+        d_o1 = ops.conv2d_bwd_data(dz2, w2_t, tuple(o1.shape), stride=s2, pad=1,
+                                   w_winograd=_dgrad_winograd(blk.conv2, w2_t, tuple(o1.shape), s2, 1))
         dz1, _ = ops.act_bwd(d_o1, o1, p1[1], relu=True)
         dw1 = wg(x, dz1, blk.conv1, 1, s1, 0) if need_w[0] else None
         dwd = None

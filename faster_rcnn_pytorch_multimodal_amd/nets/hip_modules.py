@@ -45,7 +45,8 @@ def stable_store(holder, name, key, fresh, refresh=None):
 
 
 # derived entries that read other derived entries (the KRSC filter) come second
-_REFRESH_ORDER = ('_frcnn_prepared', '_frcnn_perm', '_fused_cache', '_heads_cache', '_frcnn_wt', '_frcnn_winograd')
+_REFRESH_ORDER = ('_frcnn_prepared', '_frcnn_perm', '_fused_cache', '_heads_cache', '_frcnn_wt', '_frcnn_winograd',
+                  '_frcnn_dgrad_winograd')
 
 
 def refresh_derived_weights(net):

@@ -189,8 +189,19 @@ def conv2d_transpose_filter(w_krsc):
     return out
 
 
-def conv2d_bwd_data(dy, w_t, x_shape, stride=1, pad=0, add=None):
-    """dx (n,h,w,c) = conv_transpose(dy, w) [+ add].  w_t = conv2d_transpose_filter(w); x_shape = forward input shape."""
+def dgrad_winograd_wanted(x_shape, k, r, s, stride, pad):
+    """Whether the data-gradient convolution of this layer (a stride-1 3x3 convolution of dy with the transposed filter) can
+    read a pre-transformed Winograd filter now (see ``winograd_filter_wanted``)."""
+    n, h, w, c = x_shape
+    if stride != 1 or r != 3 or s != 3 or r - 1 - pad != 1:
+        return False
+    ho, wo = conv_out_hw(h, w, r, s, stride, pad)
+    return winograd_filter_wanted(n, ho, wo, k, c, r, s, 1, 1)
+
+
+def conv2d_bwd_data(dy, w_t, x_shape, stride=1, pad=0, add=None, w_winograd=None):
+    """dx (n,h,w,c) = conv_transpose(dy, w) [+ add].  w_t = conv2d_transpose_filter(w); x_shape = forward input shape.
+    ``w_winograd`` = winograd_filter(w_t) (16, c, k): frcnn_conv2d_bwd_data_pre."""
     lib = _hip.load()
     _dev_f32(dy, "dy"); _dev_f32(w_t, "w_t")
     n, h, w, c = x_shape
@@ -206,6 +217,13 @@ def conv2d_bwd_data(dy, w_t, x_shape, stride=1, pad=0, add=None):
     dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
     ws_bytes = lib.frcnn_conv2d_bwd_data_ws_bytes(n, h, w, c, k, r, s, stride, pad)
     ws = _workspace(ws_bytes, dy.device) if ws_bytes else None
+    if w_winograd is not None and add is None:
+        _dev_f32(w_winograd, "w_winograd")
+        if tuple(w_winograd.shape) != (16, c, k):
+            raise _hip.HipError("conv2d_bwd_data: w_winograd has shape %s, expected %s" % (tuple(w_winograd.shape), (16, c, k)))
+        _hip.check(lib.frcnn_conv2d_bwd_data_pre(_ptr(dy), _ptr(w_t), _ptr(w_winograd), None, _ptr(dx), n, h, w, c, k, r, s,
+                                                 stride, pad, _ptr(ws), ws_bytes, _stream()), "frcnn_conv2d_bwd_data_pre")
+        return dx
     _hip.check(lib.frcnn_conv2d_bwd_data(_ptr(dy), _ptr(w_t), _ptr(add), _ptr(dx), n, h, w, c, k, r, s, stride, pad,
                                          _ptr(ws), ws_bytes, _stream()), "frcnn_conv2d_bwd_data")
     return dx

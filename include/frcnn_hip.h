@@ -65,6 +65,13 @@ size_t frcnn_conv2d_bwd_data_ws_bytes(int n, int h, int w, int c, int k, int r, 
 int frcnn_conv2d_bwd_data(const float* dy, const float* w_crsk_flipped, const float* add, float* dx, int n, int h,
                           int w, int c, int k, int r, int s, int stride, int pad, void* ws, size_t ws_bytes,
                           void* stream);
+/* frcnn_conv2d_bwd_data with the Winograd transform of the data-gradient filter supplied by the caller: w_winograd =
+ * frcnn_conv2d_winograd_filter(w_crsk_flipped viewed as a (c,3,3,k) filter), (16,c,k), or NULL.  The weights change once per
+ * optimizer step (every cfg.TRAIN.BATCH_SIZE frames, lib/model/train_val.py:379-382), so a caller transforms once per step
+ * instead of once per frame.  Only for 3x3 / stride 1 / pad 1 layers and add == NULL. */
+int frcnn_conv2d_bwd_data_pre(const float* dy, const float* w_crsk_flipped, const float* w_winograd, const float* add,
+                              float* dx, int n, int h, int w, int c, int k, int r, int s, int stride, int pad, void* ws,
+                              size_t ws_bytes, void* stream);
 size_t frcnn_conv2d_bwd_weight_ws_bytes(int n, int h, int w, int c, int k, int r, int s, int stride, int pad);
 int frcnn_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, int n, int h, int w, int c, int k,
                             int r, int s, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
