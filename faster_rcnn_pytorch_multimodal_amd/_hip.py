@@ -88,7 +88,8 @@ PROTOTYPES = {
     "frcnn_spatial_mean_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "frcnn_upsample_bilinear_add_fwd": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P]),
     "frcnn_upsample_bilinear_bwd": (c_int, [_P, _P] + [c_int] * 6 + [_P]),
-    "frcnn_labelled_pixels": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    "frcnn_labelled_pixels_ws_bytes": (c_size_t, [c_int]),
+    "frcnn_labelled_pixels": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "frcnn_gather_patches": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "frcnn_scatter_add_patches": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "frcnn_roi_align_bwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_float, c_int, _P, c_int, _P, _P]),

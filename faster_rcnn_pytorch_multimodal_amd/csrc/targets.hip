@@ -543,8 +543,18 @@ extern "C" int frcnn_proposal_target_layer_lidar(const float* rois, const float*
 namespace {
 constexpr int AP_THREADS = 1024;
 
-// pixels (ascending) with at least one label != -1; idx[i] = -1 for i >= count[0].  count[0] = min(total, cap), count[1] = total
-__global__ __launch_bounds__(AP_THREADS) void labelled_pixels_kernel(const float* __restrict__ labels, int hw, int A, int cap,
+// flag[px] = 1 when any of the pixel's A labels is != -1 (one thread per pixel, chip-wide)
+__global__ __launch_bounds__(256) void labelled_flags_kernel(const float* __restrict__ labels, int hw, int A,
+                                                            int* __restrict__ flag) {
+  const int px = blockIdx.x * blockDim.x + threadIdx.x;
+  if (px >= hw) return;
+  int on = 0;
+  for (int a = 0; a < A; ++a) on |= labels[(size_t)px * A + a] != -1.0f ? 1 : 0;   // no short circuit: independent loads
+  flag[px] = on;
+}
+
+// compaction of the flags (ascending); idx[i] = -1 for i >= count[0].  count[0] = min(total, cap), count[1] = total
+__global__ __launch_bounds__(AP_THREADS) void labelled_pixels_kernel(const int* __restrict__ flag, int hw, int cap,
                                                                      int64_t* __restrict__ idx, int* __restrict__ count) {
   __shared__ int s_wave[AP_THREADS / 64];
   __shared__ int s_base;
@@ -554,9 +564,7 @@ __global__ __launch_bounds__(AP_THREADS) void labelled_pixels_kernel(const float
   __syncthreads();
   for (int p0 = 0; p0 < hw; p0 += AP_THREADS) {
     const int px = p0 + t;
-    bool on = false;
-    if (px < hw)
-      for (int a = 0; a < A; ++a) on = on || labels[(size_t)px * A + a] != -1.0f;
+    const bool on = px < hw && flag[px] != 0;
     const unsigned long long m = __ballot(on);
     if (lane == 0) s_wave[wave] = __popcll(m);
     __syncthreads();
@@ -619,11 +627,20 @@ __global__ __launch_bounds__(256) void scatter_add_patches_kernel(const float* _
 }
 }  // namespace
 
-extern "C" int frcnn_labelled_pixels(const float* labels, int hw, int num_anchors, int cap, int64_t* idx, int* count,
-                                     void* stream_) {
+extern "C" size_t frcnn_labelled_pixels_ws_bytes(int hw) { return hw > 0 ? (size_t)hw * sizeof(int) : 0; }
+
+extern "C" int frcnn_labelled_pixels(const float* labels, int hw, int num_anchors, int cap, int64_t* idx, int* count, void* ws,
+                                     size_t ws_bytes, void* stream_) {
   FRCNN_REQUIRE(labels && idx && count && hw > 0 && num_anchors > 0 && cap > 0, "labelled_pixels: bad arguments");
-  hipLaunchKernelGGL(labelled_pixels_kernel, dim3(1), dim3(AP_THREADS), 0, static_cast<hipStream_t>(stream_), labels, hw,
-                     num_anchors, cap, idx, count);
+  if (!ws || ws_bytes < frcnn_labelled_pixels_ws_bytes(hw))
+    return fail(FRCNN_ERR_WS, "labelled_pixels: workspace %zu < %zu bytes", ws_bytes, frcnn_labelled_pixels_ws_bytes(hw));
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  int* flag = static_cast<int*>(ws);
+  hipLaunchKernelGGL(labelled_flags_kernel, dim3((unsigned)((hw + 255) / 256)), dim3(256), 0, stream, labels, hw, num_anchors,
+                     flag);
+  int rc = check_launch("labelled_flags_kernel");
+  if (rc != FRCNN_OK) return rc;
+  hipLaunchKernelGGL(labelled_pixels_kernel, dim3(1), dim3(AP_THREADS), 0, stream, flag, hw, cap, idx, count);
   return check_launch("labelled_pixels_kernel");
 }
 

@@ -720,8 +720,10 @@ def labelled_pixels(labels, hw, num_anchors, cap):
         raise _hip.HipError("labelled_pixels: labels has %d elements, expected %d x %d" % (labels.numel(), hw, num_anchors))
     idx = torch.empty((cap,), dtype=torch.int64, device=labels.device)
     count = torch.empty((2,), dtype=torch.int32, device=labels.device)
-    _hip.check(lib.frcnn_labelled_pixels(_ptr(labels), hw, num_anchors, cap, _ptr(idx), _ptr(count), _stream()),
-               "frcnn_labelled_pixels")
+    ws_bytes = lib.frcnn_labelled_pixels_ws_bytes(hw)
+    ws = _workspace(ws_bytes, labels.device)
+    _hip.check(lib.frcnn_labelled_pixels(_ptr(labels), hw, num_anchors, cap, _ptr(idx), _ptr(count), _ptr(ws), ws_bytes,
+                                         _stream()), "frcnn_labelled_pixels")
     return idx, count
 
 

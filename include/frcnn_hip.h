@@ -387,7 +387,9 @@ int frcnn_roi_align_bwd(const float* dout, int h, int w, int c, const float* roi
  * frcnn_gather_patches: out (cap, r, s, c) = the r x s window of x (h, w, c) around each listed pixel (zero outside the map and
  * for rows >= count[0]) - the input of a VALID r x s convolution that reproduces the padded convolution at those pixels
  * (lib/nets/network.py rpn_net on net_conv).  frcnn_scatter_add_patches: its adjoint, dx += scatter(d) with float atomics. */
-int frcnn_labelled_pixels(const float* labels, int hw, int num_anchors, int cap, int64_t* idx, int* count, void* stream);
+size_t frcnn_labelled_pixels_ws_bytes(int hw);
+int frcnn_labelled_pixels(const float* labels, int hw, int num_anchors, int cap, int64_t* idx, int* count, void* ws,
+                          size_t ws_bytes, void* stream);
 int frcnn_gather_patches(const float* x, int h, int w, int c, const int64_t* idx, const int* count, int cap, int r, int s,
                          int pad, float* out, void* stream);
 int frcnn_scatter_add_patches(const float* d, int h, int w, int c, const int64_t* idx, const int* count, int cap, int r, int s,
