@@ -93,6 +93,8 @@ PROTOTYPES = {
     "frcnn_gather_patches": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "frcnn_scatter_add_patches": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "frcnn_roi_align_bwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_float, c_int, _P, c_int, _P, _P]),
+    "frcnn_roi_align_bwd_planned": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_float, c_int, _P, c_int, _P, _P,
+                                            c_size_t, _P]),
     "frcnn_rpn_loss_ws_bytes": (c_size_t, []),
     "frcnn_rpn_loss": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, c_size_t, _P]),
     "frcnn_det_loss": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_float, c_float, _P, _P, _P, _P]),

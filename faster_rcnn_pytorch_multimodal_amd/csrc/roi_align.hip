@@ -492,6 +492,91 @@ __global__ __launch_bounds__(256) void roi_align_fwd_planned(const float* __rest
 
 
 // ------------------------------------------------------------------------------------------------
+// Backward of the planned separable form (training: torchvision's roi_align autograd, aligned=False).
+//   dfeat[y][x] += 1/count * sum_ph sum_pw Wy[ph][y] * Wx[pw][x] * dout[ph][pw]
+// The sample-by-sample backward issues 4 float atomics per sample (49 bins x grid_h x grid_w x 4 per RoI and channel); here
+// a wave-item (item, column bin pw) first folds the row bins of a window row into T = sum_ph Wy[ph][y] * dout[ph][pw]
+// (registers, wave-uniform weights from the plan tables) and then adds Wx[pw][x] * T once per window pixel of that column
+// bin: one atomic per (RoI, pixel of a column bin, channel) whatever the sampling grid.  Same plan kernel, same item
+// list and tables as the forward; float atomics because windows of different RoIs (and neighbouring column bins) overlap.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void roi_align_bwd_planned(const float* __restrict__ dout, int H, int W, int C4, int nslices,
+                                                             const RoiPlanHead* __restrict__ head,
+                                                             const RoiItem* __restrict__ items,
+                                                             const float* __restrict__ wxt, const float* __restrict__ wyt,
+                                                             float* __restrict__ dfeat) {
+  constexpr int P = PLAN_P;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wpad = plan_pad(W), hpad = plan_pad(H);
+  const int slice = blockIdx.x % nslices;
+  const int n_slice = head->total_items / nslices;
+  const int nt = n_slice * P;
+  const int stride = (gridDim.x / nslices) * 4;
+  for (int t = (blockIdx.x / nslices) * 4 + wave; t < nt; t += stride) {
+    const int e = t / P, pw = t - e * P;
+    const RoiItem* it = items + (size_t)e * nslices + slice;
+    const int flag = it->flag;
+    if (flag != ROI_LIGHT && flag != ROI_HEAVY) continue;
+    const int r = it->r, sp = it->sp, y0 = it->y0, y1 = it->y1, bimg = it->bimg;
+    const float inv_count = it->inv_count;
+    const int xlo_all = it->xlo[pw], xhi_all = it->xhi[pw];
+    const bool heavy = flag == ROI_HEAVY;
+    const int ph_begin = heavy ? sp : 0, nph = heavy ? 1 : P;
+    const int ncols_all = xhi_all - xlo_all + 1;
+    if (ncols_all <= 0 || y1 < y0) continue;
+    // the item's output gradients, scaled by 1/count once.  Lane l owns channels slice*256 + q*64 + l (q = 0..3): every
+    // atomic instruction of the wave then covers 256 contiguous bytes of a pixel (two cache lines), not 64 lanes x 16 bytes
+    float g[P][4];
+    const int cbase = slice * 256 + lane;
+    const int C = C4 * 4;
+    const float* gb = dout + ((size_t)r * P * P + pw) * C;
+#pragma unroll
+    for (int ph = 0; ph < P; ++ph)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = cbase + q * 64;
+        g[ph][q] = (ph < nph && c < C) ? gb[(size_t)(ph_begin + ph) * P * C + c] * inv_count : 0.f;
+      }
+    float* fb = dfeat + (size_t)bimg * H * W * C;
+    for (int xc = 0; xc < ncols_all; xc += 64) {
+      const int ncols = min(64, ncols_all - xc), xlo = xlo_all + xc;
+      const float wx = wxt[((size_t)r * P + pw) * wpad + xc + lane];
+      for (int yc = y0 & ~63; yc <= y1; yc += 64) {
+        const int ys = max(yc, y0), ye = min(yc + 63, y1);
+        float wy[P];
+#pragma unroll
+        for (int ph = 0; ph < P; ++ph)
+          wy[ph] = ph < nph ? wyt[((size_t)r * P + ph_begin + ph) * hpad + min(yc + lane, hpad - 1)] : 0.f;
+        for (int y = ys; y <= ye; ++y) {
+          float T[4] = {0.f, 0.f, 0.f, 0.f};
+          bool any = false;
+#pragma unroll
+          for (int ph = 0; ph < P; ++ph) {
+            if (ph >= nph) continue;
+            const float wr = lane_bcast(wy[ph], y - yc);
+            any = any || wr != 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) T[q] += wr * g[ph][q];
+          }
+          if (!any) continue;                                   // wave-uniform: a row no row bin of the item touches
+          float* row = fb + ((size_t)y * W + xlo) * C + cbase;
+          for (int x = 0; x < ncols; ++x) {
+            const float wc = lane_bcast(wx, x);
+            if (wc == 0.f) continue;                            // wave-uniform
+            float* px = row + (size_t)x * C;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (cbase + q * 64 < C) atomicAdd(px + q * 64, wc * T[q]);
+          }
+        }
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // Map-resident form — the fastest path (P == 7, the map slice fits the LDS).
 //
 // What bounded the planned pair above: every RoI reads its own window through the vector L1 (326 MB per launch for the
@@ -917,4 +1002,34 @@ extern "C" int frcnn_roi_align_fwd(const float* feat, int n, int h, int w, int c
                                    void* stream_) {
   return frcnn_roi_align_fwd_affine(feat, n, h, w, c, rois, roi_count, num_rois, rois_per_image, pooled, spatial_scale,
                                     sampling_ratio, level_of_roi, level, out, nullptr, nullptr, 0, ws, ws_bytes, stream_);
+}
+
+// Backward through the plan (see roi_align_bwd_planned): dfeat (n,H,W,C) += scatter(dout (R,P,P,C)); dfeat is zero-filled
+// by the caller.  ws: frcnn_roi_align_fwd_ws_bytes of the same shape; returns FRCNN_ERR_ARG when the shape has no planned
+// form (pooled != 7, c % 4 != 0) - the caller then uses frcnn_roi_align_bwd.
+extern "C" int frcnn_roi_align_bwd_planned(const float* dout, int h, int w, int c, const float* rois, const int* roi_count,
+                                           int num_rois, int pooled, float spatial_scale, int sampling_ratio,
+                                           const int* level_of_roi, int level, float* dfeat, void* ws, size_t ws_bytes,
+                                           void* stream_) {
+  FRCNN_REQUIRE(dout && rois && dfeat && h > 0 && w > 0 && c > 0 && c % 4 == 0 && num_rois > 0 && planned_ok(pooled),
+                "roi_align_bwd_planned: bad arguments (pooled 7, c%%4==0)");
+  if (!ws || ws_bytes < plan_bytes(h, w, c, num_rois))
+    return frcnn::fail(FRCNN_ERR_WS, "roi_align_bwd_planned: workspace %zu < %zu bytes", ws_bytes, plan_bytes(h, w, c, num_rois));
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int c4 = c / 4, nslices = (c4 + 63) / 64;
+  RoiPlanHead* head = static_cast<RoiPlanHead*>(ws);
+  RoiItem* items = reinterpret_cast<RoiItem*>(head + 1);
+  float* wxt = reinterpret_cast<float*>(items + (size_t)num_rois * PLAN_P * nslices);
+  float* wyt = wxt + (size_t)num_rois * PLAN_P * plan_pad(w);
+  hipLaunchKernelGGL(roi_plan_kernel, dim3((unsigned)num_rois), dim3(64 * 2 * PLAN_P), 0, stream, h, w, rois, roi_count,
+                     num_rois, spatial_scale, sampling_ratio, level_of_roi, level, nslices, g_roi_heavy_loads, head, items, wxt,
+                     wyt);
+  int rc = frcnn::check_launch("roi_plan_kernel");
+  if (rc != FRCNN_OK) return rc;
+  const long max_wave_items = (long)num_rois * nslices * PLAN_P * PLAN_P;
+  long nwg = std::min<long>(256 * 5, (max_wave_items + 3) / 4);
+  nwg = std::max<long>(nslices, nwg / nslices * nslices);
+  hipLaunchKernelGGL(roi_align_bwd_planned, dim3((unsigned)nwg), dim3(256), 0, stream, dout, h, w, c4, nslices, head, items,
+                     wxt, wyt, dfeat);
+  return frcnn::check_launch("roi_align_bwd_planned");
 }

@@ -696,15 +696,28 @@ def upsample_bilinear_bwd(dout, in_hw):
     return dx
 
 
+ROI_ALIGN_BWD_PLANNED = True      # False: always the sample-by-sample backward (frcnn_roi_align_bwd)
+
+
 def roi_align_bwd(dout, feat_shape, rois, spatial_scale, sampling_ratio=0, roi_count=None, level_of_roi=None, level=-1,
                   dfeat=None):
-    """Scatter dout (R,P,P,C) into dfeat (1,H,W,C) (created zero-filled unless given, then accumulated into)."""
+    """Scatter dout (R,P,P,C) into dfeat (1,H,W,C) (created zero-filled unless given, then accumulated into).  7x7 bins and
+    C % 4 == 0 go through the forward's plan (frcnn_roi_align_bwd_planned), anything else sample by sample."""
     lib = _hip.load()
     _dev_f32(dout, "dout"); _dev_f32(rois, "rois")
     _, h, w, c = feat_shape
     r, p = dout.shape[0], dout.shape[1]
     if dfeat is None:
         dfeat = torch.zeros(tuple(feat_shape), dtype=torch.float32, device=dout.device)
+    if ROI_ALIGN_BWD_PLANNED and feat_shape[0] == 1 and c % 4 == 0:
+        ws_bytes = lib.frcnn_roi_align_fwd_ws_bytes(h, w, c, r, p)
+        if ws_bytes:
+            ws = _workspace(ws_bytes, dout.device)
+            _hip.check(lib.frcnn_roi_align_bwd_planned(_ptr(dout), h, w, c, _ptr(rois), _ptr(roi_count), r, p,
+                                                       float(spatial_scale), int(sampling_ratio), _ptr(level_of_roi), int(level),
+                                                       _ptr(dfeat), _ptr(ws), ws_bytes, _stream()),
+                       "frcnn_roi_align_bwd_planned")
+            return dfeat
     _hip.check(lib.frcnn_roi_align_bwd(_ptr(dout), h, w, c, _ptr(rois), _ptr(roi_count), r, p, float(spatial_scale),
                                        int(sampling_ratio), _ptr(level_of_roi), int(level), _ptr(dfeat), _stream()),
                "frcnn_roi_align_bwd")

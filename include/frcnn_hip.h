@@ -379,6 +379,13 @@ int frcnn_upsample_bilinear_bwd(const float* dout, float* dx, int n, int h, int 
 int frcnn_roi_align_bwd(const float* dout, int h, int w, int c, const float* rois, const int* roi_count,
                         int num_rois, int pooled, float spatial_scale, int sampling_ratio, const int* level_of_roi,
                         int level, float* dfeat, void* stream);
+/* The same gradient through the forward's plan (frcnn_roi_align_fwd_ws_bytes of the shape as workspace; pooled 7, c % 4 == 0):
+ * the row bins of a window row are folded in registers first, so ONE atomic is issued per (RoI, window pixel of a column bin,
+ * channel) instead of four per sample - 2.5x (2x2 samples per bin) to 10x+ (larger adaptive grids) fewer atomics.  Same sums
+ * in another order (float atomics either way). */
+int frcnn_roi_align_bwd_planned(const float* dout, int h, int w, int c, const float* rois, const int* roi_count,
+                                int num_rois, int pooled, float spatial_scale, int sampling_ratio, const int* level_of_roi,
+                                int level, float* dfeat, void* ws, size_t ws_bytes, void* stream);
 
 /* The RPN losses read only the anchors the anchor target layer labelled (<= cfg.TRAIN.RPN_BATCHSIZE,
  * lib/layer_utils/anchor_target_layer.py:91-107), so the gradient of the RPN head is non-zero on at most that many pixels.

@@ -1294,8 +1294,49 @@ def test_upsample_bilinear_add_fwd_bwd(hip, shape):
     assert torch.equal(dx, ops.upsample_bilinear_bwd(dout.to(DEV), (h, w)))          # deterministic
 
 
+@pytest.fixture(params=[True, False], ids=["bwd-planned", "bwd-per-sample"])
+def roi_bwd_form(request):
+    """Both forms of the RoIAlign backward: through the forward's plan (default) and sample by sample."""
+    ops = _ops()
+    old = ops.ROI_ALIGN_BWD_PLANNED
+    ops.ROI_ALIGN_BWD_PLANNED = request.param
+    yield request.param
+    ops.ROI_ALIGN_BWD_PLANNED = old
+
+
+def test_roi_align_bwd_planned_equals_per_sample(hip):
+    """frcnn_roi_align_bwd_planned against frcnn_roi_align_bwd on RoIs of every kind the plan distinguishes: small (light
+    items), frame-sized (heavy items split into row bins), off-map, clipped at the border, a level mask and a device count;
+    150 x 250 map (more than 64 columns: several column chunks) and 75 rows (two row chunks)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(33)
+    for (h, w, c, scale) in ((150, 250, 64, 0.25), (75, 40, 256, 1 / 16.0)):
+        ext = (int(w / scale), int(h / scale))
+        rois = torch.cat((torch.zeros(48, 1), _rand_boxes(48, g, extent=ext, max_wh=int(0.6 * min(ext)))), 1)
+        rois[0, 1:] = torch.tensor([0., 0, ext[0] - 1, ext[1] - 1])
+        rois[1, 1:] = torch.tensor([ext[0] + 50., ext[1] + 50, ext[0] + 90, ext[1] + 90])      # no valid sample
+        rois[2, 1:] = torch.tensor([-40., -30, 20, 10])
+        rois[3, 1:] = torch.tensor([ext[0] - 30., 5, ext[0] + 60, ext[1] - 1])
+        rois = rois.to(DEV)
+        gout = torch.randn(48, 7, 7, c, generator=g).to(DEV)
+        lvl = (torch.arange(48) % 3).to(torch.int32).to(DEV)
+        cnt = torch.tensor([41], dtype=torch.int32, device=DEV)
+        outs = []
+        for planned in (True, False):
+            ops.ROI_ALIGN_BWD_PLANNED = planned
+            try:
+                a = ops.roi_align_bwd(gout, (1, h, w, c), rois, scale, 0)
+                b = ops.roi_align_bwd(gout, (1, h, w, c), rois, scale, 2, roi_count=cnt, level_of_roi=lvl, level=1)
+            finally:
+                ops.ROI_ALIGN_BWD_PLANNED = True
+            outs.append((a, b))
+        for x, y in zip(outs[0], outs[1]):
+            tol = 2e-6 * float(y.abs().max())
+            assert float((x - y).abs().max()) <= tol, (h, w, float((x - y).abs().max()), tol)
+
+
 @pytest.mark.parametrize("sampling", [0, 2])
-def test_roi_align_bwd_is_the_adjoint_of_fwd(hip, sampling):
+def test_roi_align_bwd_is_the_adjoint_of_fwd(hip, sampling, roi_bwd_form):
     """RoIAlign is linear in the feature map: <fwd(f), g> == <f, bwd(g)> for random f, g pins the backward to the
     (oracle-checked) forward without a second reference."""
     ops = _ops()

@@ -225,7 +225,15 @@ def main():
     ap.add_argument("--no-autotune", action="store_true", help="heuristic conv plans in the training step")
     ap.add_argument("--graph", action="store_true", help="--train: replay the step as a hipGraph (Network.enable_train_graphs)")
     ap.add_argument("--inflight", type=int, default=1, help="--train: frames of a pseudo batch in flight (TrainPipeline)")
+    ap.add_argument("--roi-bwd-per-sample", action="store_true", help="A/B: sample-by-sample RoIAlign backward instead of the planned one")
+    ap.add_argument("--rpn-dense-backward", action="store_true", help="A/B: dense backward through the RPN head")
     args = ap.parse_args()
+    if args.roi_bwd_per_sample:
+        from faster_rcnn_pytorch_multimodal_amd import ops as _o
+        _o.ROI_ALIGN_BWD_PLANNED = False
+    if args.rpn_dense_backward:
+        from faster_rcnn_pytorch_multimodal_amd.nets import network as _n
+        _n.RPN_BACKWARD_ON_LABELLED_PIXELS = False
     both = not (args.lidar or args.train or args.lidar_train)
     if args.lidar or both:
         print(json.dumps(lidar_forward(args.steps or 80)))
