@@ -92,11 +92,16 @@ def _transposed_filter(conv_like, w_krsc):
                         refresh=lambda: _transposed_filter(conv_like, w_krsc))[0]
 
 
+DGRAD_WINOGRAD_CACHE = True     # False: the data-gradient convolution transforms its filter on every call
+
+
 def _dgrad_winograd(conv_like, w_t, x_shape, stride, pad):
     """Winograd transform of the data-gradient filter ``w_t`` (C,3,3,K), cached next to it: the weights change once per
     optimizer step, the data gradient runs once per frame.  None when that convolution's plan is not a Winograd plan (see
     hip_modules._winograd_filter for the rules; a miss inside a stream capture raises)."""
     c, r, s, k = w_t.shape
+    if not DGRAD_WINOGRAD_CACHE or r != 3 or stride != 1:
+        return None
     if not ops.dgrad_winograd_wanted(x_shape, k, r, s, stride, pad):
         conv_like.__dict__.pop('_frcnn_dgrad_winograd', None)
         conv_like.__dict__.pop('_frcnn_dgrad_winograd_refresh', None)

@@ -193,7 +193,8 @@ class Network(nn.Module):
     def _rpn_head(self, net_conv_nhwc):
         """relu(rpn_net) then the fused cls+bbox 1x1.  Returns (1, H, W, ld >= 6A) NHWC logits|deltas."""
         self._rpn_grad_src = None
-        if torch.is_grad_enabled() and not self._rpn_backward_on_labelled_pixels():
+        hw = net_conv_nhwc.shape[1] * net_conv_nhwc.shape[2]
+        if torch.is_grad_enabled() and not self._rpn_backward_on_labelled_pixels(hw):
             rpn = conv_bn_act_train(net_conv_nhwc, self.rpn_net, None, relu=True)
             self._act_summaries['rpn'] = rpn
             return fused_head_train(rpn, self, self.rpn_cls_score_net, self.rpn_bbox_pred_net, '_rpn_fused_cache')
@@ -209,11 +210,12 @@ class Network(nn.Module):
         w, b = self._fused_rpn_head()
         return ops.conv2d_nhwc(rpn, w, None, b, None, stride=1, pad=0, relu=False)
 
-    def _rpn_backward_on_labelled_pixels(self):
-        """Training: may the RPN's differentiable pass be restricted to the pixels that carry a labelled anchor?  Yes for the
+    def _rpn_backward_on_labelled_pixels(self, hw):
+        """Training: is the RPN's differentiable pass restricted to the pixels that carry a labelled anchor?  Possible for the
         plain losses (cross-entropy over labels != -1, smooth-L1 with zero inside-weights elsewhere: no other anchor
-        contributes to loss or gradient); not with the RPN uncertainty heads, whose terms read every anchor."""
-        if not RPN_BACKWARD_ON_LABELLED_PIXELS or self._mode != 'TRAIN':
+        contributes to loss or gradient), not with the RPN uncertainty heads, whose terms read every anchor; worthwhile when
+        the map has several times more pixels than the sampler labels anchors (the LiDAR detector's 25 x 22 map has not)."""
+        if not RPN_BACKWARD_ON_LABELLED_PIXELS or self._mode != 'TRAIN' or hw < 4 * int(cfg.TRAIN.RPN_BATCHSIZE):
             return False
         if any(cfg.UC.get(k, False) for k in ('EN_RPN_BBOX_ALEATORIC', 'EN_RPN_CLS_ALEATORIC', 'EN_RPN_BBOX_EPISTEMIC',
                                                'EN_RPN_CLS_EPISTEMIC')):

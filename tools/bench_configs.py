@@ -227,10 +227,14 @@ def main():
     ap.add_argument("--inflight", type=int, default=1, help="--train: frames of a pseudo batch in flight (TrainPipeline)")
     ap.add_argument("--roi-bwd-per-sample", action="store_true", help="A/B: sample-by-sample RoIAlign backward instead of the planned one")
     ap.add_argument("--rpn-dense-backward", action="store_true", help="A/B: dense backward through the RPN head")
+    ap.add_argument("--no-dgrad-winograd-cache", action="store_true", help="A/B: transform the data-gradient filter per call")
     args = ap.parse_args()
     if args.roi_bwd_per_sample:
         from faster_rcnn_pytorch_multimodal_amd import ops as _o
         _o.ROI_ALIGN_BWD_PLANNED = False
+    if args.no_dgrad_winograd_cache:
+        from faster_rcnn_pytorch_multimodal_amd.nets import autograd_ops as _a
+        _a.DGRAD_WINOGRAD_CACHE = False
     if args.rpn_dense_backward:
         from faster_rcnn_pytorch_multimodal_amd.nets import network as _n
         _n.RPN_BACKWARD_ON_LABELLED_PIXELS = False
