@@ -37,6 +37,7 @@ PROTOTYPES = {
     "frcnn_conv2d_bwd_data_ws_bytes": (c_size_t, [c_int] * 9),
     "frcnn_conv2d_bwd_data": (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
     "frcnn_conv2d_bwd_data_pre": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
+    "frcnn_conv2d_bwd_data_act": (c_int, [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
     "frcnn_conv2d_bwd_weight_ws_bytes": (c_size_t, [c_int] * 9),
     "frcnn_conv2d_bwd_weight": (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
     "frcnn_conv2d_bwd_weight_acc": (c_int, [_P, _P, _P, c_int, _P] + [c_int] * 9 + [_P, c_size_t, _P]),

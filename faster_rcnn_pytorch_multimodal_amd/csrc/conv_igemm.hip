@@ -65,6 +65,10 @@ struct ConvParams {
   // grouped launch (blockIdx.y = group): element offsets of a group's activations / filter / output.  Used by the
   // Winograd path (16 independent GEMMs in one launch); 0 for an ordinary convolution (gridDim.y = 1).
   size_t gx, gw, gy;
+  // optional activation-backward epilogue (data-gradient calls): y = mask[m][n] > 0 ? y * mscale[n] : 0 - the ReLU /
+  // folded-BatchNorm backward of the layer BELOW, applied to this layer's input gradient before it is stored
+  const float* mask;
+  const float* mscale;
   const float* u_pre;   // host side: Winograd-transformed filter supplied by the caller (frcnn_conv2d_fwd_pre) or nullptr
 };
 
@@ -132,11 +136,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
           }
           continue;
         }
-        f32x4 rv[4];
+        f32x4 rv[4], mv[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = nb + 8 * g;
           rv[g] = (p.res && n < p.K) ? *reinterpret_cast<const f32x4*>(p.res + orow + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+          mv[g] = (p.mask && n < p.K) ? *reinterpret_cast<const f32x4*>(p.mask + orow + n) : f32x4{1.f, 1.f, 1.f, 1.f};
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -144,12 +149,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
           if (n >= p.K) continue;
           const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
           const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+          const f32x4 ms = (p.mask && p.mscale) ? *reinterpret_cast<const f32x4*>(p.mscale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float t = acc[i][j][4 * g + e] * sc[e] + sh[e];
             t += rv[g][e];
-            v[e] = p.relu ? fmaxf(t, 0.f) : t;
+            t = p.relu ? fmaxf(t, 0.f) : t;
+            if (p.mask) t = mv[g][e] > 0.f ? t * ms[e] : 0.f;
+            v[e] = t;
           }
           *reinterpret_cast<f32x4*>(p.y + orow + n) = v;
         }
@@ -162,7 +170,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
           if (slab) { slab[row + n] = acc[i][j][r]; continue; }
           float t = acc[i][j][r] * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
           if (p.res) t += p.res[orow + n];
-          p.y[orow + n] = p.relu ? fmaxf(t, 0.f) : t;
+          t = p.relu ? fmaxf(t, 0.f) : t;
+          if (p.mask) t = p.mask[orow + n] > 0.f ? t * (p.mscale ? p.mscale[n] : 1.f) : 0.f;
+          p.y[orow + n] = t;
         }
       }
     }
@@ -705,7 +715,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma2_f32(const ConvParams p
 __global__ __launch_bounds__(256) void conv_splitk_epilogue(const float* __restrict__ partial, int splits,
                                                            size_t mk, int K, const float* scale,
                                                            const float* shift, const float* res, float* y,
-                                                           int relu) {
+                                                           int relu, const float* mask, const float* mscale) {
   for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < mk; o += (size_t)gridDim.x * blockDim.x) {
     float v = partial[o];
     for (int z = 1; z < splits; ++z) v += partial[(size_t)z * mk + o];
@@ -713,6 +723,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue(const float* __restr
     v = v * (scale ? scale[n] : 1.f) + (shift ? shift[n] : 0.f);
     if (res) v += res[o];
     if (relu) v = fmaxf(v, 0.f);
+    if (mask) v = mask[o] > 0.f ? v * (mscale ? mscale[n] : 1.f) : 0.f;
     y[o] = v;
   }
 }
@@ -1159,7 +1170,9 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 // y[2ty+a][2tx+b] = act((A^T m A)[a][b] * scale + shift),  A^T = [[1,1,1,0],[0,1,-1,-1]];  one thread per (tile, 4 channels)
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mo, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, float* __restrict__ y, int H,
-                                                         int W, int K4, int th, int tw, long T, int relu) {
+                                                         int W, int K4, int th, int tw, long T, int relu,
+                                                         const float* __restrict__ mask,
+                                                         const float* __restrict__ mscale) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)T * K4) return;
   const int k4 = (int)(idx % K4);
@@ -1198,7 +1211,14 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       }
-      reinterpret_cast<f32x4*>(y)[((size_t)(n * H + ho) * W + wo) * K4 + k4] = v;
+      const size_t at = ((size_t)(n * H + ho) * W + wo) * K4 + k4;
+      if (mask) {
+        const f32x4 mv = reinterpret_cast<const f32x4*>(mask)[at];
+        const f32x4 ms = mscale ? reinterpret_cast<const f32x4*>(mscale)[k4] : f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] * ms[e] : 0.f;
+      }
+      reinterpret_cast<f32x4*>(y)[at] = v;
     }
   }
 }
@@ -1276,11 +1296,12 @@ int launch_winograd(const ConvParams& p, const Plan& pl, const float* scale, con
   q.ys = 1; q.Hy = 0; q.Wy = 0;
   q.gx = (size_t)g.T * p.C; q.gw = (size_t)p.K * p.C; q.gy = (size_t)g.T * p.K;
   q.u_pre = nullptr;
+  q.mask = q.mscale = nullptr;
   Plan gp{pl.cfg, 1, q.ksteps};
   rc = launch_gemm(q, gp, g.T, p.K, 16, stream);
   if (rc != FRCNN_OK) return rc;
   return launch_1d("wino_output_kernel", wino_output_kernel, (size_t)g.T * (p.K / 4), stream, (const float*)Mo, scale, shift, y,
-                   p.Ho, p.Wo, p.K / 4, g.th, g.tw, g.T, relu);
+                   p.Ho, p.Wo, p.K / 4, g.th, g.tw, g.T, relu, p.mask, p.mscale);
 }
 
 int launch_plan(ConvParams p, const Plan& pl, long M, int k, const float* scale, const float* shift,
@@ -1295,10 +1316,10 @@ int launch_plan(ConvParams p, const Plan& pl, long M, int k, const float* scale,
     hipEvent_t e0, e1;
     if (prof_events(1, &e0, &e1, stream))
       hipExtLaunchKernelGGL(conv_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, e0, e1, 0,
-                            (const float*)p.partial, pl.splits, mk, k, scale, shift, residual, y, relu);
+                            (const float*)p.partial, pl.splits, mk, k, scale, shift, residual, y, relu, p.mask, p.mscale);
     else
       hipLaunchKernelGGL(conv_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, p.partial, pl.splits, mk, k,
-                         scale, shift, residual, y, relu);
+                         scale, shift, residual, y, relu, p.mask, p.mscale);
     return frcnn::check_launch("conv_splitk_epilogue");
   }
   return FRCNN_OK;
@@ -1361,9 +1382,12 @@ bool tune_plan(const ConvParams& p, long M, int k, const float* scale, const flo
 // a (hy x wy) map at stride out_stride (the map must be zero-filled by the caller); split-K is disabled then.
 int run_conv(const float* x, const float* wgt, const float* scale, const float* shift, const float* residual,
              float* y, int n, int h, int w, int c, int k, int r, int s, int stride, int pad, int relu, int split_k,
-             void* ws, size_t ws_bytes, hipStream_t stream, int out_stride, int hy, int wy, const float* u_pre = nullptr) {
+             void* ws, size_t ws_bytes, hipStream_t stream, int out_stride, int hy, int wy, const float* u_pre = nullptr,
+             const float* mask = nullptr, const float* mscale = nullptr) {
   ConvParams p;
   p.u_pre = u_pre;
+  p.mask = mask;
+  p.mscale = mscale;
   p.x = x; p.w = wgt; p.scale = scale; p.shift = shift; p.res = residual; p.y = y; p.partial = nullptr;
   p.H = h; p.W = w; p.C = c; p.K = k; p.R = r; p.S = s; p.stride = stride; p.pad = pad;
   p.Ho = (h + 2 * pad - r) / stride + 1;
@@ -1577,10 +1601,26 @@ extern "C" int frcnn_conv2d_bwd_data(const float* dy, const float* w_crsk_flippe
                                    stream_);
 }
 
+extern "C" int frcnn_conv2d_bwd_data_act(const float* dy, const float* w_crsk_flipped, const float* w_winograd,
+                                         const float* add, const float* act_y, const float* act_scale, float* dx, int n,
+                                         int h, int w, int c, int k, int r, int s, int stride, int pad, void* ws,
+                                         size_t ws_bytes, void* stream_);
+
 extern "C" int frcnn_conv2d_bwd_data_pre(const float* dy, const float* w_crsk_flipped, const float* w_winograd,
                                          const float* add, float* dx, int n, int h, int w, int c, int k, int r, int s,
                                          int stride, int pad, void* ws, size_t ws_bytes, void* stream_) {
+  return frcnn_conv2d_bwd_data_act(dy, w_crsk_flipped, w_winograd, add, nullptr, nullptr, dx, n, h, w, c, k, r, s, stride,
+                                   pad, ws, ws_bytes, stream_);
+}
+
+extern "C" int frcnn_conv2d_bwd_data_act(const float* dy, const float* w_crsk_flipped, const float* w_winograd,
+                                         const float* add, const float* act_y, const float* act_scale, float* dx, int n,
+                                         int h, int w, int c, int k, int r, int s, int stride, int pad, void* ws,
+                                         size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FRCNN_REQUIRE(!act_scale || act_y, "conv2d_bwd_data_act: act_scale without act_y");
+  FRCNN_REQUIRE(!act_y || stride == 1 || (r > 1 || s > 1),
+                "conv2d_bwd_data_act: the strided 1x1 data gradient (scattered output) has no activation epilogue");
   FRCNN_REQUIRE(!w_winograd || (stride == 1 && !add && winograd_ok(r, s, 1, r - 1 - pad, k, c, 1)),
                 "conv2d_bwd_data_pre: a Winograd filter only goes with a 3x3 / stride 1 / pad 1 layer without `add`");
   FRCNN_REQUIRE(dy && w_crsk_flipped && dx, "conv2d_bwd_data: null tensor");
@@ -1593,7 +1633,7 @@ extern "C" int frcnn_conv2d_bwd_data_pre(const float* dy, const float* w_crsk_fl
     return frcnn::fail(FRCNN_ERR_WS, "conv2d_bwd_data: workspace %zu < %zu bytes", ws_bytes, need);
   if (stride == 1)  // dx (n,h,w,c) = conv(dy (n,ho,wo,k), w^T flipped), same-size output
     return run_conv(dy, w_crsk_flipped, nullptr, nullptr, add, dx, n, g.ho, g.wo, k, c, r, s, 1, g.pad_t, 0, 0, ws,
-                    ws_bytes, stream, 1, 0, 0, w_winograd);
+                    ws_bytes, stream, 1, 0, 0, w_winograd, act_y, act_scale);
   if (!g.dilate) {
     // strided 1x1: only pixels (ho*stride, wo*stride) receive a gradient; the rest is `add` (or zero)
     const size_t bytes = (size_t)n * h * w * c * sizeof(float);
@@ -1610,7 +1650,7 @@ extern "C" int frcnn_conv2d_bwd_data_pre(const float* dy, const float* w_crsk_fl
   int rc = frcnn::check_launch("dilate_kernel");
   if (rc != FRCNN_OK) return rc;
   return run_conv(dyd, w_crsk_flipped, nullptr, nullptr, add, dx, n, g.hd, g.wd, k, c, r, s, 1, g.pad_t, 0, 0,
-                  static_cast<char*>(ws) + dil, ws_bytes - dil, stream, 1, 0, 0);
+                  static_cast<char*>(ws) + dil, ws_bytes - dil, stream, 1, 0, 0, nullptr, act_y, act_scale);
 }
 
 // ------------------------------------------------------------------------------------------------

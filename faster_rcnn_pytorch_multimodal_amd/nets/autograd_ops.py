@@ -92,6 +92,7 @@ def _transposed_filter(conv_like, w_krsc):
                         refresh=lambda: _transposed_filter(conv_like, w_krsc))[0]
 
 
+FUSE_ACT_BWD = True             # False: a separate frcnn_act_bwd pass after each data gradient inside a Bottleneck
 DGRAD_WINOGRAD_CACHE = True     # False: the data-gradient convolution transforms its filter on every call
 
 
@@ -390,13 +391,21 @@ class _BottleneckFn(torch.autograd.Function):
 
         dz3, d_id = ops.act_bwd(dy.contiguous(), out, p3[1], relu=True, want_res=True)
         dw3 = wg(o2, dz3, blk.conv3, 1, 1, 0) if need_w[2] else None
-        d_o2 = ops.conv2d_bwd_data(dz3, _transposed_filter(blk.conv3, p3[0]), tuple(o2.shape))
-        dz2, _ = ops.act_bwd(d_o2, o2, p2[1], relu=True)
-        dw2 = wg(o1, dz2, blk.conv2, 3, s2, 1) if need_w[1] else None
+        # the ReLU / folded-BatchNorm backward of conv2 (conv1) is applied by the data-gradient launch of conv3 (conv2) as it
+        # stores its result (frcnn_conv2d_bwd_data_act): no separate pass over d_o2 / d_o1
+        w3_t = _transposed_filter(blk.conv3, p3[0])
         w2_t = _transposed_filter(blk.conv2, p2[0])
-        d_o1 = ops.conv2d_bwd_data(dz2, w2_t, tuple(o1.shape), stride=s2, pad=1,
-                                   w_winograd=_dgrad_winograd(blk.conv2, w2_t, tuple(o1.shape), s2, 1))
-        dz1, _ = ops.act_bwd(d_o1, o1, p1[1], relu=True)
+        u2_t = _dgrad_winograd(blk.conv2, w2_t, tuple(o1.shape), s2, 1)
+        if FUSE_ACT_BWD:
+            dz2 = ops.conv2d_bwd_data(dz3, w3_t, tuple(o2.shape), act_y=o2, act_scale=p2[1])
+        else:
+            dz2, _ = ops.act_bwd(ops.conv2d_bwd_data(dz3, w3_t, tuple(o2.shape)), o2, p2[1], relu=True)
+        dw2 = wg(o1, dz2, blk.conv2, 3, s2, 1) if need_w[1] else None
+        if FUSE_ACT_BWD:
+            dz1 = ops.conv2d_bwd_data(dz2, w2_t, tuple(o1.shape), stride=s2, pad=1, w_winograd=u2_t, act_y=o1, act_scale=p1[1])
+        else:
+            dz1, _ = ops.act_bwd(ops.conv2d_bwd_data(dz2, w2_t, tuple(o1.shape), stride=s2, pad=1, w_winograd=u2_t), o1, p1[1],
+                                 relu=True)
         dw1 = wg(x, dz1, blk.conv1, 1, s1, 0) if need_w[0] else None
         dwd = None
         dx = None

@@ -199,9 +199,11 @@ def dgrad_winograd_wanted(x_shape, k, r, s, stride, pad):
     return winograd_filter_wanted(n, ho, wo, k, c, r, s, 1, 1)
 
 
-def conv2d_bwd_data(dy, w_t, x_shape, stride=1, pad=0, add=None, w_winograd=None):
+def conv2d_bwd_data(dy, w_t, x_shape, stride=1, pad=0, add=None, w_winograd=None, act_y=None, act_scale=None):
     """dx (n,h,w,c) = conv_transpose(dy, w) [+ add].  w_t = conv2d_transpose_filter(w); x_shape = forward input shape.
-    ``w_winograd`` = winograd_filter(w_t) (16, c, k): frcnn_conv2d_bwd_data_pre."""
+    ``w_winograd`` = winograd_filter(w_t) (16, c, k): frcnn_conv2d_bwd_data_pre.  ``act_y`` (shape of dx) [, ``act_scale``
+    (c,)]: the result is masked / scaled like ``act_bwd(dx, act_y, act_scale, relu=True)`` would in a second pass
+    (frcnn_conv2d_bwd_data_act; not for the strided 1x1 form)."""
     lib = _hip.load()
     _dev_f32(dy, "dy"); _dev_f32(w_t, "w_t")
     n, h, w, c = x_shape
@@ -217,6 +219,22 @@ def conv2d_bwd_data(dy, w_t, x_shape, stride=1, pad=0, add=None, w_winograd=None
     dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
     ws_bytes = lib.frcnn_conv2d_bwd_data_ws_bytes(n, h, w, c, k, r, s, stride, pad)
     ws = _workspace(ws_bytes, dy.device) if ws_bytes else None
+    if act_y is not None:
+        _dev_f32(act_y, "act_y")
+        if tuple(act_y.shape) != tuple(x_shape):
+            raise _hip.HipError("conv2d_bwd_data: act_y shape %s != x shape %s" % (tuple(act_y.shape), tuple(x_shape)))
+        if act_scale is not None:
+            _dev_f32(act_scale, "act_scale")
+            if act_scale.numel() != c:
+                raise _hip.HipError("conv2d_bwd_data: act_scale has %d elements, expected %d" % (act_scale.numel(), c))
+        if w_winograd is not None:
+            _dev_f32(w_winograd, "w_winograd")
+            if tuple(w_winograd.shape) != (16, c, k) or add is not None:
+                w_winograd = None
+        _hip.check(lib.frcnn_conv2d_bwd_data_act(_ptr(dy), _ptr(w_t), _ptr(w_winograd), _ptr(add), _ptr(act_y), _ptr(act_scale),
+                                                 _ptr(dx), n, h, w, c, k, r, s, stride, pad, _ptr(ws), ws_bytes, _stream()),
+                   "frcnn_conv2d_bwd_data_act")
+        return dx
     if w_winograd is not None and add is None:
         _dev_f32(w_winograd, "w_winograd")
         if tuple(w_winograd.shape) != (16, c, k):

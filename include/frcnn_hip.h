@@ -72,6 +72,14 @@ int frcnn_conv2d_bwd_data(const float* dy, const float* w_crsk_flipped, const fl
 int frcnn_conv2d_bwd_data_pre(const float* dy, const float* w_crsk_flipped, const float* w_winograd, const float* add,
                               float* dx, int n, int h, int w, int c, int k, int r, int s, int stride, int pad, void* ws,
                               size_t ws_bytes, void* stream);
+/* ... and with the activation backward of the layer BELOW folded into the store: dx = act_y > 0 ? dx * act_scale[c] : 0, i.e.
+ * what frcnn_act_bwd(dx, act_y, act_scale, relu = 1) would make of the result in a second pass (act_y = that layer's ReLU
+ * output, same shape as dx; act_scale = its folded BatchNorm scale or NULL).  lib/nets/resnet.py:98-127 backward: the data
+ * gradient of conv3 directly yields the gradient of conv2's pre-activation output, that of conv2 the one of conv1's.  Not for
+ * the strided 1x1 form. */
+int frcnn_conv2d_bwd_data_act(const float* dy, const float* w_crsk_flipped, const float* w_winograd, const float* add,
+                              const float* act_y, const float* act_scale, float* dx, int n, int h, int w, int c, int k, int r,
+                              int s, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
 size_t frcnn_conv2d_bwd_weight_ws_bytes(int n, int h, int w, int c, int k, int r, int s, int stride, int pad);
 int frcnn_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, int n, int h, int w, int c, int k,
                             int r, int s, int stride, int pad, void* ws, size_t ws_bytes, void* stream);

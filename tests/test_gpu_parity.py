@@ -1805,6 +1805,35 @@ def _assert_derived_weights_fresh(net, what):
     return checked
 
 
+@pytest.mark.parametrize("case", [(1, 38, 63, 256, 1024, 1, 1, 0), (1, 38, 63, 256, 256, 3, 1, 1), (1, 19, 32, 512, 512, 3, 2, 1),
+                                  (2, 9, 11, 64, 2048, 1, 1, 0)])
+@pytest.mark.parametrize("algo", [0, 1, 2])
+def test_conv_bwd_data_with_activation_epilogue(hip, case, algo):
+    """frcnn_conv2d_bwd_data_act: the data gradient with the ReLU / scale backward of the layer below applied at the store is
+    bit-equal to frcnn_conv2d_bwd_data followed by frcnn_act_bwd, in the implicit-GEMM kernels (also split-K), behind the
+    Winograd output transform (algo 2) and on the zero-inserted strided form."""
+    ops = _ops()
+    n, h, w, c, k, r, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    ho, wo = ops.conv_out_hw(h, w, r, r, stride, pad)
+    dy = torch.randn(n, ho, wo, k, generator=g).to(DEV)
+    wt = (torch.randn(k, r, r, c, generator=g) * 0.05).to(DEV)
+    w_t = ops.conv2d_transpose_filter(wt)
+    act_y = torch.relu(torch.randn(n, h, w, c, generator=g)).to(DEV)
+    scale = (torch.rand(c, generator=g) + 0.5).to(DEV)
+    ops.set_conv_algo(algo)
+    try:
+        plain = ops.conv2d_bwd_data(dy, w_t, (n, h, w, c), stride=stride, pad=pad)
+        want, _ = ops.act_bwd(plain, act_y, scale, relu=True)
+        want_noscale, _ = ops.act_bwd(plain, act_y, None, relu=True)
+        got = ops.conv2d_bwd_data(dy, w_t, (n, h, w, c), stride=stride, pad=pad, act_y=act_y, act_scale=scale)
+        got_noscale = ops.conv2d_bwd_data(dy, w_t, (n, h, w, c), stride=stride, pad=pad, act_y=act_y)
+    finally:
+        ops.set_conv_algo(0)
+    assert torch.equal(got, want) and torch.equal(got_noscale, want_noscale)
+    assert float(got.abs().max()) > 0 and float((got == 0).float().mean()) > 0.3
+
+
 def test_labelled_pixels_gather_and_scatter_patches(hip):
     """frcnn_labelled_pixels / frcnn_gather_patches / frcnn_scatter_add_patches: the ascending list of pixels with a label
     != -1 (capacity-limited, total reported), the 3x3 windows around them with zeros outside the map and past the count, and

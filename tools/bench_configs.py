@@ -228,10 +228,14 @@ def main():
     ap.add_argument("--roi-bwd-per-sample", action="store_true", help="A/B: sample-by-sample RoIAlign backward instead of the planned one")
     ap.add_argument("--rpn-dense-backward", action="store_true", help="A/B: dense backward through the RPN head")
     ap.add_argument("--no-dgrad-winograd-cache", action="store_true", help="A/B: transform the data-gradient filter per call")
+    ap.add_argument("--no-fuse-act-bwd", action="store_true", help="A/B: separate frcnn_act_bwd passes inside the Bottleneck backward")
     args = ap.parse_args()
     if args.roi_bwd_per_sample:
         from faster_rcnn_pytorch_multimodal_amd import ops as _o
         _o.ROI_ALIGN_BWD_PLANNED = False
+    if args.no_fuse_act_bwd:
+        from faster_rcnn_pytorch_multimodal_amd.nets import autograd_ops as _a2
+        _a2.FUSE_ACT_BWD = False
     if args.no_dgrad_winograd_cache:
         from faster_rcnn_pytorch_multimodal_amd.nets import autograd_ops as _a
         _a.DGRAD_WINOGRAD_CACHE = False
