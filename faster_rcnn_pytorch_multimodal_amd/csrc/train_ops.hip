@@ -1,7 +1,7 @@
 // Training-path kernels other than the convolutions: activation backward, FPN bilinear upsample-add
 // (forward/backward), RoIAlign backward, the RPN / detection losses with their gradients.
 // HBM/latency-bound elementwise and gather work: 16-byte accesses along the channel dimension, wave-uniform
-// sampling weights, fixed-order reductions (the only non-deterministic piece is RoIAlign's atomic scatter).
+// sampling weights, fixed-order reductions (the only non-deterministic pieces are the float-atomic scatters: RoIAlign backward, patch gradients).
 // Built with -ffp-contract=off: the reference evaluates these expressions as separate torch ops.
 #include "common.h"
 #include "box_math.h"

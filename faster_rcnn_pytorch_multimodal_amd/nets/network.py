@@ -248,7 +248,11 @@ class Network(nn.Module):
         tgt, inw, outw = (ops.gather_rows(at[k].contiguous().view(hw, 4 * a), idx, live).view(cap * a, 4)
                           for k in ('targets', 'inside', 'outside'))
         self._predictions['rpn_labelled_pixels'] = (idx, count)
-        return rpn_loss_train(out, lab.view(-1), tgt, inw, outw, a)
+        losses = rpn_loss_train(out, lab.view(-1), tgt, inw, outw, a)
+        # more labelled pixels than the list holds cannot happen with the sampler's cap; if it ever did, the step must not
+        # train on a truncated loss silently: the losses (and through them every gradient) turn NaN
+        poison = torch.where(count[1:2] > cap, float('nan'), 0.0).to(losses.dtype)
+        return losses + poison
 
     def _region_proposal(self, net_conv):
         """RPN head -> proposal_layer.  Returns rois (post_nms_topN, 5) [0,x1,y1,x2,y2]; rows past

@@ -383,7 +383,8 @@ int frcnn_upsample_bilinear_bwd(const float* dout, float* dx, int n, int h, int 
                                 void* stream);
 
 /* Backward of frcnn_roi_align_fwd: dfeat (1,H,W,C) += scatter(dout (R,P,P,C)); dfeat must be zero-filled by the
- * caller (float atomics: the only non-deterministic kernel of the library). */
+ * caller (float atomics: the summation order, hence the last bits, vary from run to run; the same holds for
+ * frcnn_roi_align_bwd_planned and frcnn_scatter_add_patches - every other kernel of the library is deterministic). */
 int frcnn_roi_align_bwd(const float* dout, int h, int w, int c, const float* rois, const int* roi_count,
                         int num_rois, int pooled, float spatial_scale, int sampling_ratio, const int* level_of_roi,
                         int level, float* dfeat, void* stream);

@@ -1903,6 +1903,21 @@ def test_rpn_backward_on_labelled_pixels_equals_dense_backward(hip):
     floor = 0.01 * max(float(v.abs().max()) for v in g_d.values())
     worst = max(float((g_s[k] - g_d[k]).abs().max()) / max(float(g_d[k].abs().max()), floor) for k in g_d)
     assert worst <= 1e-4, "gradients differ by %.3e of their scale" % worst
+    # a pixel list shorter than the labelled pixels (impossible with the sampler's cap) must not train silently on a
+    # truncated loss: the RPN losses turn NaN
+    cap_old = N.cfg.TRAIN.RPN_BATCHSIZE
+    try:
+        torch.manual_seed(77)
+        net.forward(blobs["data"], blobs["info"], blobs["gt_boxes"], None, mode="TRAIN")
+        n_px = int(net._predictions["rpn_labelled_pixels"][1][1])
+        assert n_px > 8
+        N.cfg.TRAIN.RPN_BATCHSIZE = 8
+        net._rpn_grad_src = torch.zeros((1,) + tuple(net._predictions["rpn_out"].shape[1:3]) + (net.rpn_net.in_channels,),
+                                        device=DEV)
+        l = net._rpn_losses_on_labelled_pixels(net._anchor_targets)
+        assert torch.isnan(l).all()
+    finally:
+        N.cfg.TRAIN.RPN_BATCHSIZE = cap_old
 
 
 def test_train_step_as_hipgraph_equals_eager_step(hip):
