@@ -41,6 +41,8 @@ PROTOTYPES = {
     "frcnn_conv2d_bwd_weight_ws_bytes": (c_size_t, [c_int] * 9),
     "frcnn_conv2d_bwd_weight": (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
     "frcnn_conv2d_bwd_weight_acc": (c_int, [_P, _P, _P, c_int, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
+    "frcnn_conv2d_bwd_weight_acc_grouped_ws_bytes": (c_size_t, [c_int] * 5),
+    "frcnn_conv2d_bwd_weight_acc_grouped": (c_int, [_P, _P, _P, c_int, c_int] + [c_int] * 9 + [_P, c_size_t, _P]),
     "frcnn_maxpool3x3s2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "frcnn_maxpool3x3s2_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "frcnn_pad_channels": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),

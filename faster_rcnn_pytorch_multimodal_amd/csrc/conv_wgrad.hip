@@ -44,7 +44,8 @@ struct WgradParams {
 };
 
 template <int TI>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const WgradParams p) {
+__device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const float* __restrict__ px,
+                                                const float* __restrict__ pdy, float* __restrict__ pout) {
   constexpr int BT = 64 * TI;
   constexpr int CH = BT / 4;            // 16-byte chunks per staged pixel row
   constexpr int RP = 256 / CH;          // pixel rows staged per pass
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const WgradParams p) {
     for (int i = 0; i < NP; ++i) {
       const int m = step * BR + prow + RP * i;
       const bool m_ok = m < p.M;
-      ra[i] = (m_ok && ka_ok) ? *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.K + ka) : f32x4{0.f, 0.f, 0.f, 0.f};
+      ra[i] = (m_ok && ka_ok) ? *reinterpret_cast<const f32x4*>(pdy + (size_t)m * p.K + ka) : f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (m_ok && qb_ok) {
         const int img = m / (p.Ho * p.Wo);
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const WgradParams p) {
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
         const int hi = ho * p.stride - p.pad + tr, wi = wo * p.stride - p.pad + ts;
         if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-          v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(img * p.H + hi) * p.W + wi) * p.C + cb);
+          v = *reinterpret_cast<const f32x4*>(px + ((size_t)(img * p.H + hi) * p.W + wi) * p.C + cb);
       }
       rb[i] = v;
     }
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const WgradParams p) {
   }
 
   // D: column (lane & 31) = q, row (r&3) + 8*(r>>2) + 4*(lane>>5) = k
-  float* out = p.out + (size_t)blockIdx.z * p.K * p.Q;
+  float* out = pout + (size_t)blockIdx.z * p.K * p.Q;
 #pragma unroll
   for (int j = 0; j < TI; ++j) {
     const int q = q0 + (wc * TI + j) * 32 + l31;
@@ -144,6 +145,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const WgradParams p) {
         if (k < p.K) out[(size_t)k * p.Q + q] = acc[i][j][r];
       }
   }
+}
+
+template <int TI>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f32(const WgradParams p) {
+  conv_wgrad_body<TI>(p, p.x, p.dy, p.out);
+}
+
+// Grouped form: blockIdx.y selects one of up to WG_MAX_GROUPS convolutions of IDENTICAL shape (the 22 repeated Bottlenecks
+// of layer3, lib/nets/resnet.py:131-240): together they have enough output tiles to fill the chip WITHOUT splitting the
+// pixel reduction, so every tile runs the whole M-pixel loop (75 steps instead of ~9) and no slabs are summed afterwards.
+// Group g writes its (K, Q) result to p.out + g * K * Q.
+constexpr int WG_MAX_GROUPS = 24;
+struct WgradGroups {
+  const float* x[WG_MAX_GROUPS];
+  const float* dy[WG_MAX_GROUPS];
+};
+struct WgradOuts {
+  float* grad[WG_MAX_GROUPS];
+};
+template <int TI>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_grouped_f32(const WgradParams p, const WgradGroups g) {
+  const int grp = blockIdx.y;
+  conv_wgrad_body<TI>(p, g.x[grp], g.dy[grp], p.out + (size_t)grp * p.K * p.Q);
 }
 
 // dw = sum_z slab[z] (z order), 16 bytes per thread
@@ -179,6 +203,23 @@ __global__ __launch_bounds__(256) void wgrad_accumulate_kernel(const float* __re
     float v = slabs[src];
     for (int z = 1; z < splits; ++z) v += slabs[(size_t)z * slab + src];
     grad[i] += v;
+  }
+}
+
+// the same for the grouped filter gradient: one (K, R, S, C) result per group, added into that group's parameter gradient
+__global__ __launch_bounds__(256) void wgrad_accumulate_grouped_kernel(const float* __restrict__ results, int K, int R, int S,
+                                                                      int C, int c_real, const WgradOuts o) {
+  const size_t total = (size_t)K * c_real * R * S, slab = (size_t)K * R * S * C;
+  const float* src0 = results + (size_t)blockIdx.y * slab;
+  float* grad = o.grad[blockIdx.y];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int s = (int)(i % S);
+    size_t t = i / S;
+    const int r = (int)(t % R);
+    t /= R;
+    const int c = (int)(t % c_real);
+    const int k = (int)(t / c_real);
+    grad[i] += src0[(((size_t)k * R + r) * S + s) * C + c];
   }
 }
 
@@ -453,4 +494,58 @@ extern "C" int frcnn_conv2d_bwd_weight_acc(const float* x, const float* dy, floa
   if (rc != FRCNN_OK) return rc;
   hipLaunchKernelGGL(bias_grad_accumulate_kernel, dim3((k + 255) / 256), dim3(256), 0, stream, partial, k, BIAS_GROUPS, grad_b);
   return frcnn::check_launch("bias_grad_accumulate_kernel");
+}
+
+// Filter gradients of `groups` convolutions of identical shape in one launch pair (conv_wgrad_grouped_f32 +
+// wgrad_accumulate_grouped_kernel): grad_w[g] (K, c_real, R, S) += dW(x[g], dy[g]).  x / dy / grad_w are HOST arrays of device
+// pointers.  No pixel split, fixed summation order: deterministic.
+extern "C" size_t frcnn_conv2d_bwd_weight_acc_grouped_ws_bytes(int groups, int c, int k, int r, int s) {
+  if (groups <= 0 || c <= 0 || k <= 0 || r <= 0 || s <= 0) return 0;
+  return frcnn::align_up((size_t)groups * k * r * s * c * sizeof(float), 256);
+}
+
+extern "C" int frcnn_conv2d_bwd_weight_acc_grouped(const float* const* x, const float* const* dy, float* const* grad_w,
+                                                   int groups, int c_real, int n, int h, int w, int c, int k, int r, int s,
+                                                   int stride, int pad, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FRCNN_REQUIRE(x && dy && grad_w && groups > 0 && groups <= WG_MAX_GROUPS && c_real > 0 && c_real <= c,
+                "conv2d_bwd_weight_acc_grouped: bad arguments (1..%d groups)", WG_MAX_GROUPS);
+  FRCNN_REQUIRE(wgrad_args_ok(n, h, w, c, k, r, s, stride, pad),
+                "conv2d_bwd_weight_acc_grouped: bad shape n=%d h=%d w=%d c=%d k=%d r=%d s=%d stride=%d pad=%d", n, h, w, c, k,
+                r, s, stride, pad);
+  WgradParams p;
+  p.x = nullptr; p.dy = nullptr; p.out = static_cast<float*>(ws);
+  p.H = h; p.W = w; p.C = c; p.K = k; p.R = r; p.S = s; p.stride = stride; p.pad = pad;
+  p.Ho = (h + 2 * pad - r) / stride + 1;
+  p.Wo = (w + 2 * pad - s) / stride + 1;
+  const long M = (long)n * p.Ho * p.Wo;
+  FRCNN_REQUIRE(M * (long)k < (1L << 31) && (long)n * h * w * c < (1L << 31), "conv2d_bwd_weight_acc_grouped: tensor too large");
+  p.M = (int)M;
+  p.Q = r * s * c;
+  p.steps = (p.M + BR - 1) / BR;
+  p.steps_per_split = p.steps;
+  const size_t need = frcnn_conv2d_bwd_weight_acc_grouped_ws_bytes(groups, c, k, r, s);
+  if (!ws || ws_bytes < need)
+    return frcnn::fail(FRCNN_ERR_WS, "conv2d_bwd_weight_acc_grouped: workspace %zu < %zu bytes", ws_bytes, need);
+  WgradGroups g;
+  WgradOuts o;
+  for (int i = 0; i < WG_MAX_GROUPS; ++i) {
+    const int j = i < groups ? i : 0;
+    FRCNN_REQUIRE(x[j] && dy[j] && grad_w[j], "conv2d_bwd_weight_acc_grouped: null tensor in group %d", j);
+    g.x[i] = x[j]; g.dy[i] = dy[j]; o.grad[i] = grad_w[j];
+  }
+  // the 128 x 128 tile when the groups together still give every CU a workgroup, else 64 x 64
+  const int ti = (long)tiles_for(k, p.Q, 2) * groups >= NUM_CU ? 2 : 1;
+  const int bt = 64 * ti;
+  p.tiles_k = (p.K + bt - 1) / bt;
+  p.tiles_q = (p.Q + bt - 1) / bt;
+  const dim3 grid(p.tiles_k * p.tiles_q, groups, 1);
+  if (ti == 2) hipLaunchKernelGGL(conv_wgrad_grouped_f32<2>, grid, dim3(256), 0, stream, p, g);
+  else hipLaunchKernelGGL(conv_wgrad_grouped_f32<1>, grid, dim3(256), 0, stream, p, g);
+  int rc = frcnn::check_launch("conv_wgrad_grouped_f32");
+  if (rc != FRCNN_OK) return rc;
+  const size_t total = (size_t)k * c_real * r * s;
+  hipLaunchKernelGGL(wgrad_accumulate_grouped_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 2048), groups),
+                     dim3(256), 0, stream, static_cast<const float*>(ws), k, r, s, c, c_real, o);
+  return frcnn::check_launch("wgrad_accumulate_grouped_kernel");
 }

@@ -614,7 +614,11 @@ class Network(nn.Module):
     def backward(self, loss):
         """loss.backward() plus the join of the filter-gradient side stream (autograd_ops.ASYNC_WGRAD): afterwards every
         ``param.grad`` is complete as seen from the current stream."""
-        loss.backward()
+        try:
+            loss.backward()
+        except BaseException:
+            autograd_ops.drop_deferred_weight_grads()
+            raise
         autograd_ops.join_weight_grads(self._device)
 
     def enable_train_graphs(self, enabled=True, max_graphs=8):

@@ -284,6 +284,36 @@ def conv2d_bwd_weight_acc(x, dy, r, s, grad_w, grad_b=None, stride=1, pad=0):
                                                stride, pad, _ptr(ws), ws_bytes, _stream()), "frcnn_conv2d_bwd_weight_acc")
 
 
+WGRAD_MAX_GROUPS = 24
+
+
+def conv2d_bwd_weight_acc_grouped(xs, dys, r, s, grads, stride=1, pad=0):
+    """``grads[g]`` += filter gradient of convolution g for up to WGRAD_MAX_GROUPS convolutions of identical shape
+    (frcnn_conv2d_bwd_weight_acc_grouped): one launch pair, no pixel split, no slab reduction."""
+    import ctypes
+    lib = _hip.load()
+    groups = len(xs)
+    if not (0 < groups <= WGRAD_MAX_GROUPS) or len(dys) != groups or len(grads) != groups:
+        raise _hip.HipError("conv2d_bwd_weight_acc_grouped: 1..%d groups, same number of x / dy / grad tensors" % WGRAD_MAX_GROUPS)
+    n, h, w, c = xs[0].shape
+    k = dys[0].shape[-1]
+    c_real = grads[0].shape[1]
+    for x, dy, gw in zip(xs, dys, grads):
+        _dev_f32(x, "x"); _dev_f32(dy, "dy"); _dev_f32(gw, "grad_w")
+        if tuple(x.shape) != (n, h, w, c) or tuple(dy.shape) != (n,) + conv_out_hw(h, w, r, s, stride, pad) + (k,):
+            raise _hip.HipError("conv2d_bwd_weight_acc_grouped: every group must have the shape of the first")
+        if gw.shape[0] != k or gw.shape[1] != c_real or c_real > c or gw.numel() != k * c_real * r * s:
+            raise _hip.HipError("conv2d_bwd_weight_acc_grouped: grad_w %s does not fit k=%d c<=%d r=%d s=%d"
+                                % (tuple(gw.shape), k, c, r, s))
+    arr = ctypes.c_void_p * groups
+    ws_bytes = lib.frcnn_conv2d_bwd_weight_acc_grouped_ws_bytes(groups, c, k, r, s)
+    ws = _workspace(ws_bytes, xs[0].device)
+    _hip.check(lib.frcnn_conv2d_bwd_weight_acc_grouped(arr(*[t.data_ptr() for t in xs]), arr(*[t.data_ptr() for t in dys]),
+                                                       arr(*[t.data_ptr() for t in grads]), groups, c_real, n, h, w, c, k, r, s,
+                                                       stride, pad, _ptr(ws), ws_bytes, _stream()),
+               "frcnn_conv2d_bwd_weight_acc_grouped")
+
+
 def maxpool3x3s2_nhwc(x):
     lib = _hip.load()
     _dev_f32(x, "x")

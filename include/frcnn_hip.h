@@ -91,6 +91,15 @@ int frcnn_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* d
  * for the shape; workspace of frcnn_conv2d_bwd_weight_ws_bytes. */
 int frcnn_conv2d_bwd_weight_acc(const float* x, const float* dy, float* grad_w, int c_real, float* grad_b, int n, int h, int w,
                                 int c, int k, int r, int s, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+/* The same for `groups` (<= 24) convolutions of IDENTICAL shape in one launch pair: grad_w[g] += dW(x[g], dy[g]).  x, dy, grad_w
+ * are HOST arrays of `groups` device pointers.  The repeated Bottlenecks of a ResNet stage (22 of the 23 blocks of layer3,
+ * lib/nets/resnet.py:131-240) have identical filter-gradient problems whose outputs are too small to fill the chip one at a
+ * time (hence pixel-split slabs and a reduction pass per layer); together they do, so every tile runs the whole pixel loop
+ * and nothing is reduced afterwards.  ws: frcnn_conv2d_bwd_weight_acc_grouped_ws_bytes.  Deterministic. */
+size_t frcnn_conv2d_bwd_weight_acc_grouped_ws_bytes(int groups, int c, int k, int r, int s);
+int frcnn_conv2d_bwd_weight_acc_grouped(const float* const* x, const float* const* dy, float* const* grad_w, int groups,
+                                        int c_real, int n, int h, int w, int c, int k, int r, int s, int stride, int pad,
+                                        void* ws, size_t ws_bytes, void* stream);
 
 /* Tuning / test hook: force the workgroup tile to (64*tm) x (64*tn) output pixels x channels for all
  * following frcnn_conv2d_fwd calls of this process; (tm,tn) in {(4,2),(2,4)} (8 waves, one workgroup per

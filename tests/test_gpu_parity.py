@@ -1834,6 +1834,37 @@ def test_conv_bwd_data_with_activation_epilogue(hip, case, algo):
     assert float(got.abs().max()) > 0 and float((got == 0).float().mean()) > 0.3
 
 
+@pytest.mark.parametrize("case", [(1, 38, 63, 256, 256, 3, 1, 1, 22), (1, 38, 63, 1024, 256, 1, 1, 0, 5),
+                                  (1, 19, 32, 512, 2048, 1, 1, 0, 2), (2, 9, 13, 64, 128, 3, 2, 1, 24), (1, 38, 63, 256, 1024, 1, 1, 0, 1)])
+def test_grouped_filter_gradient_equals_per_layer(hip, case):
+    """frcnn_conv2d_bwd_weight_acc_grouped: the filter gradients of several convolutions of one shape in one launch pair, added
+    into each parameter's own gradient buffer, against frcnn_conv2d_bwd_weight per layer (different summation order: 1e-5 of the
+    gradient's scale); accumulates (+=), is deterministic, and refuses mismatching shapes / too many groups."""
+    from faster_rcnn_pytorch_multimodal_amd import _hip
+    ops = _ops()
+    n, h, w, c, k, r, stride, pad, groups = case
+    g = torch.Generator().manual_seed(sum(case))
+    ho, wo = ops.conv_out_hw(h, w, r, r, stride, pad)
+    xs = [torch.randn(n, h, w, c, generator=g).to(DEV) for _ in range(groups)]
+    dys = [torch.randn(n, ho, wo, k, generator=g).to(DEV) for _ in range(groups)]
+    start = [torch.randn(k, c, r, r, generator=g).to(DEV) for _ in range(groups)]
+    grads = [t.clone() for t in start]
+    ops.conv2d_bwd_weight_acc_grouped(xs, dys, r, r, grads, stride=stride, pad=pad)
+    again = [t.clone() for t in start]
+    ops.conv2d_bwd_weight_acc_grouped(xs, dys, r, r, again, stride=stride, pad=pad)
+    for x, dy, g0, got, rep in zip(xs, dys, start, grads, again):
+        dw, _ = ops.conv2d_bwd_weight(x, dy, r, r, stride=stride, pad=pad)
+        want = g0 + dw.permute(0, 3, 1, 2)
+        tol = 1e-5 * float(dw.abs().max())
+        assert float((got - want).abs().max()) <= tol
+        assert torch.equal(got, rep)
+    if groups > 1:
+        with pytest.raises(_hip.HipError):
+            ops.conv2d_bwd_weight_acc_grouped(xs, dys[:-1] + [dys[-1][..., :k // 2].contiguous()], r, r, grads, stride=stride, pad=pad)
+    with pytest.raises(_hip.HipError):
+        ops.conv2d_bwd_weight_acc_grouped(xs[:1] * 25, dys[:1] * 25, r, r, grads[:1] * 25, stride=stride, pad=pad)
+
+
 def test_labelled_pixels_gather_and_scatter_patches(hip):
     """frcnn_labelled_pixels / frcnn_gather_patches / frcnn_scatter_add_patches: the ascending list of pixels with a label
     != -1 (capacity-limited, total reported), the 3x3 windows around them with zeros outside the map and past the count, and
@@ -1918,6 +1949,35 @@ def test_rpn_backward_on_labelled_pixels_equals_dense_backward(hip):
         assert torch.isnan(l).all()
     finally:
         N.cfg.TRAIN.RPN_BATCHSIZE = cap_old
+
+
+def test_train_step_with_grouped_filter_gradients(hip):
+    """autograd_ops.GROUP_WGRAD (off by default): the filter gradients of a stage's equal Bottlenecks collected and launched
+    together give the per-layer gradients (res101+FPN step, side-stream mode as inside a captured step)."""
+    from faster_rcnn_pytorch_multimodal_amd.nets import autograd_ops as A
+    net, _ = _build_fpn_pair(seed=23)
+    data, info, gt, _, _ = _fpn_case()
+    net.train()
+    results = []
+    old = (A.GROUP_WGRAD, A.ASYNC_WGRAD)
+    try:
+        for grouped in (False, True):
+            A.GROUP_WGRAD, A.ASYNC_WGRAD = grouped, True
+            for p in net.parameters():
+                if p.requires_grad:
+                    p.grad = torch.zeros_like(p)
+            torch.manual_seed(55)
+            net.forward(data, info, gt, None, mode="TRAIN")
+            net.backward(net._losses["total_loss"])
+            torch.cuda.synchronize()
+            assert not A._DEFER
+            results.append({n_: p.grad.clone() for n_, p in net.named_parameters() if p.grad is not None})
+    finally:
+        A.GROUP_WGRAD, A.ASYNC_WGRAD = old
+    g_ref, g_grp = results
+    floor = 0.01 * max(float(v.abs().max()) for v in g_ref.values())
+    worst = max(float((g_grp[k] - g_ref[k]).abs().max()) / max(float(g_ref[k].abs().max()), floor) for k in g_ref)
+    assert worst <= 1e-4, "gradients differ by %.3e of their scale" % worst
 
 
 def test_train_step_as_hipgraph_equals_eager_step(hip):

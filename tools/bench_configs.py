@@ -110,6 +110,11 @@ def _timed_pipeline_windows(net, blobs, opt, steps, inflight, windows=3):
     return losses, sorted(times)[len(times) // 2]
 
 
+def _wgrad_grouped():
+    from faster_rcnn_pytorch_multimodal_amd.nets import autograd_ops
+    return autograd_ops.GROUP_WGRAD
+
+
 def fpn_train(steps, autotune=True, graph=False, inflight=1):
     from faster_rcnn_pytorch_multimodal_amd import ops
     from faster_rcnn_pytorch_multimodal_amd.model import config as C
@@ -161,8 +166,10 @@ def fpn_train(steps, autotune=True, graph=False, inflight=1):
             "unit": "steps/s", "ms_per_step": 1e3 * dt / steps, "n_gpus": 1, "steps": steps, "dtype": "f32",
             "config": {"workload": "BASELINE.json configs[3]: 8 random gt boxes, 12000/2000 proposals, 256 sampled RoIs, "
                                    "FIXED_BLOCKS=1, SGD update every 16 steps",
-                       "launch": ("hipGraph replay, %d frames of a pseudo batch in flight" % inflight) if inflight > 1 else
-                                 "hipGraph replay of the whole step, filter gradients on a side stream" if graph else "eager (autograd)",
+                       "launch": ("hipGraph replay of the whole step, %d frames of a pseudo batch in flight (TrainPipeline)" % inflight)
+                                 if inflight > 1 else
+                                 "hipGraph replay of the whole step, one frame at a time" if graph else "eager (autograd)",
+                       "filter_gradients": "on a side stream, grouped per ResNet stage" if _wgrad_grouped() else "on a side stream, one launch chain per layer",
                        "forward_conv_gflop": fwd_flops / 1e9, "loss_first": losses[0], "loss_last": losses[-1]}}
 
 
@@ -229,10 +236,18 @@ def main():
     ap.add_argument("--rpn-dense-backward", action="store_true", help="A/B: dense backward through the RPN head")
     ap.add_argument("--no-dgrad-winograd-cache", action="store_true", help="A/B: transform the data-gradient filter per call")
     ap.add_argument("--no-fuse-act-bwd", action="store_true", help="A/B: separate frcnn_act_bwd passes inside the Bottleneck backward")
+    ap.add_argument("--group-wgrad", action="store_true", help="A/B: grouped filter-gradient launches per ResNet stage (autograd_ops.GROUP_WGRAD)")
+    ap.add_argument("--group-wgrad-size", type=int, default=0, help="A/B: layers per grouped filter-gradient launch")
     args = ap.parse_args()
     if args.roi_bwd_per_sample:
         from faster_rcnn_pytorch_multimodal_amd import ops as _o
         _o.ROI_ALIGN_BWD_PLANNED = False
+    if args.group_wgrad_size:
+        from faster_rcnn_pytorch_multimodal_amd.nets import autograd_ops as _a4
+        _a4.GROUP_WGRAD_SIZE = args.group_wgrad_size
+    if args.group_wgrad:
+        from faster_rcnn_pytorch_multimodal_amd.nets import autograd_ops as _a3
+        _a3.GROUP_WGRAD = True
     if args.no_fuse_act_bwd:
         from faster_rcnn_pytorch_multimodal_amd.nets import autograd_ops as _a2
         _a2.FUSE_ACT_BWD = False
