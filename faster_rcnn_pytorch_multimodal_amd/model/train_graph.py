@@ -29,6 +29,14 @@ from ..nets.hip_modules import refresh_derived_weights
 from .config import cfg
 
 
+def inline_graphs_supported():
+    """May a training step be captured as ONE chain (filter gradients in line)?  Only when the HIP runtime was started with
+    DEBUG_CLR_GRAPH_PACKET_CAPTURE=0: ROCm 7's packet-captured replay of single-chain graphs replays this step wrongly from
+    the second replay on (wrong filter gradients; profiles/r03_train_step.md), the general replay path is correct."""
+    import os
+    return os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') == '0'
+
+
 def graphable(net, blobs):
     """Why this step cannot run as a graph (a string), or None."""
     from ..nets import uncertainty
@@ -49,10 +57,11 @@ class TrainStepRunner:
     """``run(blobs)`` -> (loss (device scalar tensor), candidate counts (device int32)) with the gradients of this frame
     added to every ``param.grad``."""
 
-    def __init__(self, net, height, width, channels, num_gt, info, warmup=2, autotune=True, grads=None):
+    def __init__(self, net, height, width, channels, num_gt, info, warmup=2, autotune=True, grads=None, inline=False):
         """``grads``: gradient buffers (one per trainable parameter, in net.parameters() order) the captured backward
         accumulates into; default: the parameters' own ``.grad`` (created as zeros when missing).  A pipeline slot passes
-        its private buffers (``TrainPipeline``)."""
+        its private buffers (``TrainPipeline``).  ``inline``: capture the filter gradients in line (one chain, see
+        ``inline_graphs_supported``) instead of on a side stream."""
         self.net = net
         self.info = np.asarray(info, dtype=np.float32).copy()
         dev = torch.device(net._device)
@@ -89,13 +98,15 @@ class TrainStepRunner:
         # created on (the default stream, outside the capture) and were measured to race with the captured backward
         # (up to 1 % gradient error); the side-stream form is exact and lets the filter gradients overlap the chain.
         self.graph = torch.cuda.CUDAGraph()
-        prev = autograd_ops.ASYNC_WGRAD
+        prev = (autograd_ops.ASYNC_WGRAD, autograd_ops.WGRAD_ON_SIDE_STREAM)
         autograd_ops.ASYNC_WGRAD = True
+        autograd_ops.WGRAD_ON_SIDE_STREAM = not inline
+        self.inline = bool(inline)
         try:
             with torch.cuda.graph(self.graph):
                 self.loss, self.counts = self._step()
         finally:
-            autograd_ops.ASYNC_WGRAD = prev
+            autograd_ops.ASYNC_WGRAD, autograd_ops.WGRAD_ON_SIDE_STREAM = prev
         # the warm-up and capture passes ran on zero inputs: drop what they added to the gradients
         with torch.no_grad():
             for p, g in zip(params, saved):
@@ -150,7 +161,12 @@ class TrainPipeline:
     the efficiency of the individual small-GEMM kernels, not idle CUs.  The class stays as the host-side pipelining of the
     solver loop (cfg.TRAIN.FRAMES_IN_FLIGHT, default 1)."""
 
-    def __init__(self, net, slots=4, max_graphs=8):
+    def __init__(self, net, slots=4, max_graphs=8, inline=None):
+        """``inline``: capture every slot's step as one chain so that the slots' replays overlap (default: when
+        ``inline_graphs_supported()``); a forked graph (filter gradients on a side stream) is correct everywhere but its
+        replays do not overlap - then the pipeline only hides the host's launch / read-back time."""
+        self.inline = inline_graphs_supported() if inline is None else bool(inline)
+        self._checked = False
         self.net = net
         self.dev = torch.device(net._device)
         self.slots = max(1, int(slots))
@@ -193,8 +209,11 @@ class TrainPipeline:
                 raise RuntimeError("TrainPipeline: more than %d distinct frame shapes" % self.max_graphs)
             torch.cuda.synchronize(self.dev)       # captures happen with the device idle
             runner = TrainStepRunner(self.net, key[0], key[1], key[2], key[3], info, grads=self.grads[s],
-                                     autotune=not any(self.runners))
+                                     autotune=not any(self.runners), inline=self.inline)
             self.runners[s][key] = runner
+            if self.inline and not self._checked:
+                self._check_replays(runner, blobs, self.grads[s])
+                self._checked = True
         st = self.streams[s]
         st.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(st):
@@ -204,6 +223,30 @@ class TrainPipeline:
         self.pending[s] = [runner, ev, None, None]
         self.order.append(s)
         return s
+
+    def _check_replays(self, runner, blobs, grads):
+        """A single-chain graph must give the same gradients on every replay (the runtime fault described at
+        ``inline_graphs_supported`` shows from the second replay on): replay the first captured step three times on this
+        frame with the same sampling seeds and compare the increments.  Raises instead of training on wrong gradients."""
+        torch.cuda.synchronize(self.dev)
+        held = [g.clone() for g in grads]
+        incs = []
+        with torch.no_grad():
+            for _ in range(3):
+                torch._foreach_zero_(grads)
+                state = torch.random.get_rng_state()
+                runner.run(blobs)
+                torch.random.set_rng_state(state)               # the same two sampling seeds for every replay
+                torch.cuda.synchronize(self.dev)
+                incs.append([g.clone() for g in grads])
+            for g, h in zip(grads, held):
+                g.copy_(h)
+        scale = max(float(a.abs().max()) for a in incs[0]) or 1.0
+        worst = max(float((a - b).abs().max()) for k in (1, 2) for a, b in zip(incs[0], incs[k])) / scale
+        if not worst <= 1e-3:
+            raise RuntimeError("TrainPipeline: a replayed single-chain training graph does not reproduce its own gradients "
+                               "(deviation %.3e of their scale).  Start the process with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, or "
+                               "build the pipeline with inline=False." % worst)
 
     def in_flight(self):
         return len(self.order)

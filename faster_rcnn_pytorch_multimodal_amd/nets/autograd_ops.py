@@ -26,7 +26,18 @@ _SIDE = {}
 _KEEP = []      # operands of side-stream launches, held until the main stream has joined the side stream
 
 
+# True (default): filter gradients run on a side stream next to the data-gradient chain (a captured step is a forked graph).
+# False: in line on the step's own stream - a captured step is then ONE chain of kernel nodes, the form the runtime overlaps
+# when several replays are in flight on different streams (model/train_graph.TrainPipeline: two replays of a forked graph were
+# measured not to overlap at all).  ONLY with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before the HIP runtime starts:
+# with ROCm 7's packet-captured replay of single-chain graphs this step's graph adds wrong filter gradients from its second
+# replay on (train_graph.inline_graphs_supported / TrainPipeline's replay check guard it).
+WGRAD_ON_SIDE_STREAM = True
+
+
 def _side_stream(device):
+    if not WGRAD_ON_SIDE_STREAM:
+        return torch.cuda.current_stream(device)
     key = str(device)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
@@ -56,7 +67,8 @@ def _flush_group(key):
     r, s, stride, pad = key[2:6]
     main = torch.cuda.current_stream(x0.device)
     side = _side_stream(x0.device)
-    side.wait_stream(main)
+    if WGRAD_ON_SIDE_STREAM:
+        side.wait_stream(main)
     with torch.cuda.stream(side):
         if len(entries) == 1:
             ops.conv2d_bwd_weight_acc(entries[0][0], entries[0][1], r, s, entries[0][2], None, stride=stride, pad=pad)
@@ -65,8 +77,9 @@ def _flush_group(key):
                                               stride=stride, pad=pad)
     for x, d, _ in entries:
         _KEEP.append((x, d))
-        x.record_stream(side)
-        d.record_stream(side)
+        if WGRAD_ON_SIDE_STREAM:
+            x.record_stream(side)
+            d.record_stream(side)
 
 
 def _defer_wgrad(x, d_conv, r, s, stride, pad, grad):
@@ -123,7 +136,8 @@ def _wgrad(x, d_conv, r, s, stride, pad, targets):
         return [None]
     main = torch.cuda.current_stream(x.device)
     side = _side_stream(x.device)
-    side.wait_stream(main)
+    if WGRAD_ON_SIDE_STREAM:
+        side.wait_stream(main)
     with torch.cuda.stream(side):
         # plain Conv2d / Linear targets ('w' [+ 'b'] of one module, gradient buffers in place): one launch chain sums the
         # pixel-split slabs, changes the layout and adds into param.grad - no temporaries, no permute copy, no add_
@@ -139,8 +153,9 @@ def _wgrad(x, d_conv, r, s, stride, pad, targets):
     # was observed not to (run-to-run different gradients from the replayed graph), so the operands are simply kept alive
     # until join_weight_grads() has made the main stream wait for the side stream.
     _KEEP.append((x, d_conv))
-    x.record_stream(side)
-    d_conv.record_stream(side)
+    if WGRAD_ON_SIDE_STREAM:
+        x.record_stream(side)
+        d_conv.record_stream(side)
     return [None for _ in targets]
 
 

@@ -10,6 +10,11 @@ import os
 import sys
 import time
 
+if "--inflight" in sys.argv:
+    # frames of a pseudo batch in flight replay single-chain graphs (model/train_graph.inline_graphs_supported): the general
+    # graph replay path of the runtime has to be selected before HIP starts
+    os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import numpy as np
 import torch
 
@@ -110,6 +115,11 @@ def _timed_pipeline_windows(net, blobs, opt, steps, inflight, windows=3):
     return losses, sorted(times)[len(times) // 2]
 
 
+def _inline(inflight):
+    from faster_rcnn_pytorch_multimodal_amd.model.train_graph import inline_graphs_supported
+    return inflight > 1 and inline_graphs_supported()
+
+
 def _wgrad_grouped():
     from faster_rcnn_pytorch_multimodal_amd.nets import autograd_ops
     return autograd_ops.GROUP_WGRAD
@@ -169,7 +179,8 @@ def fpn_train(steps, autotune=True, graph=False, inflight=1):
                        "launch": ("hipGraph replay of the whole step, %d frames of a pseudo batch in flight (TrainPipeline)" % inflight)
                                  if inflight > 1 else
                                  "hipGraph replay of the whole step, one frame at a time" if graph else "eager (autograd)",
-                       "filter_gradients": "on a side stream, grouped per ResNet stage" if _wgrad_grouped() else "on a side stream, one launch chain per layer",
+                       "filter_gradients": ("in line (single-chain graphs, DEBUG_CLR_GRAPH_PACKET_CAPTURE=0)" if _inline(inflight)
+                                            else "on a side stream") + (", grouped per ResNet stage" if _wgrad_grouped() else ""),
                        "forward_conv_gflop": fwd_flops / 1e9, "loss_first": losses[0], "loss_last": losses[-1]}}
 
 

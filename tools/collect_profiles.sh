@@ -23,6 +23,7 @@ done
 python3 $R/tools/bench_configs.py --lidar > $O/${TAG}_configs.jsonl 2> $O/${TAG}_configs.err
 python3 $R/tools/bench_configs.py --train --steps 32 >> $O/${TAG}_configs.jsonl 2>> $O/${TAG}_configs.err
 python3 $R/tools/bench_configs.py --train --graph --steps 32 >> $O/${TAG}_configs.jsonl 2>> $O/${TAG}_configs.err
+python3 $R/tools/bench_configs.py --train --graph --inflight 3 --steps 48 >> $O/${TAG}_configs.jsonl 2>> $O/${TAG}_configs.err
 python3 $R/tools/bench_configs.py --lidar-train >> $O/${TAG}_configs.jsonl 2>> $O/${TAG}_configs.err
 echo "secondary configs done"; cut -c1-160 $O/${TAG}_configs.jsonl
 # training step (BASELINE.json configs[3] names a "rocprof MFMA capture"): MfmaUtil per kernel over the last steps
