@@ -98,15 +98,18 @@ class TrainStepRunner:
         # created on (the default stream, outside the capture) and were measured to race with the captured backward
         # (up to 1 % gradient error); the side-stream form is exact and lets the filter gradients overlap the chain.
         self.graph = torch.cuda.CUDAGraph()
-        prev = (autograd_ops.ASYNC_WGRAD, autograd_ops.WGRAD_ON_SIDE_STREAM)
+        prev = (autograd_ops.ASYNC_WGRAD, autograd_ops.WGRAD_ON_SIDE_STREAM, autograd_ops.GROUP_WGRAD)
         autograd_ops.ASYNC_WGRAD = True
         autograd_ops.WGRAD_ON_SIDE_STREAM = not inline
+        # in line, the grouped filter gradients of a stage (autograd_ops.GROUP_WGRAD) cost nothing in overlap - there is no side
+        # chain to trail - and save 1.3 ms of kernel time per step
+        autograd_ops.GROUP_WGRAD = bool(inline) or prev[2]
         self.inline = bool(inline)
         try:
             with torch.cuda.graph(self.graph):
                 self.loss, self.counts = self._step()
         finally:
-            autograd_ops.ASYNC_WGRAD, autograd_ops.WGRAD_ON_SIDE_STREAM = prev
+            autograd_ops.ASYNC_WGRAD, autograd_ops.WGRAD_ON_SIDE_STREAM, autograd_ops.GROUP_WGRAD = prev
         # the warm-up and capture passes ran on zero inputs: drop what they added to the gradients
         with torch.no_grad():
             for p, g in zip(params, saved):

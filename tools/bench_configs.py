@@ -181,7 +181,7 @@ def fpn_train(steps, autotune=True, graph=False, inflight=1):
                                  "hipGraph replay of the whole step, one frame at a time" if graph else "eager (autograd)",
                        "filter_gradients": "per layer inside autograd's backward (synchronous)" if not graph and inflight <= 1 else
                                            ("in line (single-chain graphs, DEBUG_CLR_GRAPH_PACKET_CAPTURE=0)" if _inline(inflight)
-                                            else "on a side stream") + (", grouped per ResNet stage" if _wgrad_grouped() else ""),
+                                            else "on a side stream") + (", grouped per ResNet stage" if (_wgrad_grouped() or _inline(inflight)) else ""),
                        "forward_conv_gflop": fwd_flops / 1e9, "loss_first": losses[0], "loss_last": losses[-1]}}
 
 
