@@ -261,6 +261,147 @@ def map_delta(net, sd, frames_host, info):
                             % (THRESH, MAX_DETS)}
 
 
+class ResidentFrames:
+    """Frame source of model.test.test_net (the ``blobs_at`` protocol of its docstring) over frames resident in HBM: frame
+    i of the sequence is resident frame i % len(frames), exactly what the timed steps of this file replay."""
+    name = "bench_resident_frames"
+
+    def __init__(self, frames, info, n, num_classes=NUM_CLASSES):
+        self.frames, self.info, self.n, self.num_classes = frames, info, int(n), num_classes
+
+    def num_frames(self, mode):
+        return self.n
+
+    def blobs_at(self, i, mode):
+        return {"data": self.frames[i % len(self.frames)], "info": self.info}
+
+
+def drop_in_timing(net, frames, info, n_frames, value, calls=3):
+    """frames/s of the DROP-IN entry point: ``model.test.test_net(net, db, out_dir, max_dets, thresh, mode)`` as
+    tools/test_net.py:290 calls it (lib/model/test.py:138-257), over `n_frames` frames resident in HBM.  The whole call is
+    timed - frame loop, collate, unpacking into all_boxes, detections.pkl and the per-class text files.  test_net replays
+    captured frames, cfg.TEST.FRAMES_IN_FLIGHT in flight (model/frame_graph.FramePool); every all_boxes[cls][frame] of
+    the timed calls is compared with the eager single-stream record of that frame, bit for bit."""
+    import shutil
+    import tempfile
+    from faster_rcnn_pytorch_multimodal_amd.model import collate
+    from faster_rcnn_pytorch_multimodal_amd.model.config import cfg
+    from faster_rcnn_pytorch_multimodal_amd.model.test import detect_frame_device, test_net
+    out_dir = tempfile.mkdtemp(prefix="frcnn_bench_dropin_")
+    try:
+        lanes = int(cfg.TEST.FRAMES_IN_FLIGHT)
+        test_net(net, ResidentFrames(frames, info, 3 * lanes), out_dir, max_dets=MAX_DETS, thresh=THRESH, mode="val")  # captures
+        db = ResidentFrames(frames, info, n_frames)
+        runs = []
+        for _ in range(calls):
+            timers = {}
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            boxes = test_net(net, db, out_dir, max_dets=MAX_DETS, thresh=THRESH, mode="val", timers=timers)
+            torch.cuda.synchronize()
+            runs.append((time.perf_counter() - t0, timers, boxes))
+        max_out = max(MAX_DETS, int(cfg.TEST.RPN_POST_NMS_TOP_N))
+        expected = []
+        for f in frames:
+            dets, counts = detect_frame_device(net, f, info, THRESH, MAX_DETS, max_out)
+            expected.append(collate.unpack_records(collate.pack_record(dets, counts).unsqueeze(0), NUM_CLASSES, max_out)[0])
+        bad = sum(1 for _, _, boxes in runs for i in range(n_frames) for j in range(1, NUM_CLASSES)
+                  if not np.array_equal(np.asarray(boxes[j][i]).reshape(-1, 5), expected[i % len(frames)][j]))
+        runs.sort(key=lambda r: r[0])
+        dt, timers, _ = runs[len(runs) // 2]
+        fps = n_frames / dt
+        return {"frames_s": fps, "ms_per_frame": 1e3 * dt / n_frames, "frames": n_frames, "calls": calls,
+                "loop_only_frames_s": n_frames / timers["loop_s"], "ratio_to_value": fps / value,
+                "seconds_each_call": [r[0] for r in runs], "pool": timers["pool"],
+                "records_equal_to_eager_path": bad == 0, "mismatching_entries": bad,
+                "entry_point": "model.test.test_net(net, db, out_dir, max_dets=%d, thresh=%.1f, mode='val') - the call of "
+                               "tools/test_net.py:290 / lib/model/test.py:138-257; whole call timed (frame loop + collate + "
+                               "all_boxes + detections.pkl + result text files), median of %d calls; frames resident in "
+                               "HBM; cfg.TEST.FRAME_GRAPHS=%s FRAMES_IN_FLIGHT=%d (the defaults)"
+                               % (MAX_DETS, THRESH, calls, bool(cfg.TEST.FRAME_GRAPHS), lanes)}
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+
+
+def drop_in_uncertainty(device, n_frames, frames_host, info, calls=3):
+    """The same two measurements with the uncertainty heads on (cfg.UC.EN_{BBOX,CLS}_{ALEATORIC,EPISTEMIC}, E_NUM_SAMPLE =
+    10 Monte-Carlo passes per frame: lib/model/test.py:73-77, lib/model/config.py:46): FrameRunner x 4 streams driven
+    like the timed steps of this file (`runner_frames_s`) and the drop-in call test_net (`frames_s`)."""
+    import shutil
+    import tempfile
+    from faster_rcnn_pytorch_multimodal_amd.model import config as Cfg
+    from faster_rcnn_pytorch_multimodal_amd.model.frame_graph import FrameRunner
+    from faster_rcnn_pytorch_multimodal_amd.model.test import detect_frame_device, test_net
+    from faster_rcnn_pytorch_multimodal_amd.nets.imagenet import imagenet
+    from faster_rcnn_pytorch_multimodal_amd.nets.uncertainty import num_uncertainty_pos
+    from faster_rcnn_pytorch_multimodal_amd.utils.init_utils import seeded_state_dict
+    from faster_rcnn_pytorch_multimodal_amd.model import collate
+    Cfg.reset_cfg()
+    out_dir = tempfile.mkdtemp(prefix="frcnn_bench_dropin_uc_")
+    try:
+        cfg = Cfg.cfg
+        cfg.NET_TYPE = "image"
+        for k in ("EN_BBOX_ALEATORIC", "EN_CLS_ALEATORIC", "EN_BBOX_EPISTEMIC", "EN_CLS_EPISTEMIC"):
+            cfg.UC[k] = True
+        net = imagenet(num_layers=101)
+        net.create_architecture(NUM_CLASSES, tag="default", anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
+        net.load_state_dict(seeded_state_dict(net, WEIGHT_SEED, bn_mode=BN_MODE), strict=True)
+        net.eval()
+        net._device = device
+        net.to(device)
+        frames = [torch.from_numpy(f).to(device) for f in frames_host]
+        lanes = int(cfg.TEST.FRAMES_IN_FLIGHT)
+        max_out = max(MAX_DETS, int(cfg.TEST.RPN_POST_NMS_TOP_N))
+        runners = [FrameRunner(net, H, W, C, info, THRESH, MAX_DETS, max_out=max_out) for _ in range(lanes)]
+        streams = [torch.cuda.Stream(device=device) for _ in range(lanes)]
+
+        def loop(n):
+            for i in range(n):
+                with torch.cuda.stream(streams[i % lanes]):
+                    runners[i % lanes].run(frames[i % len(frames)])
+            torch.cuda.synchronize()
+
+        loop(2 * lanes)
+        t = []
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            loop(n_frames)
+            t.append(time.perf_counter() - t0)
+        runner_fps = n_frames / sorted(t)[len(t) // 2]
+        del runners
+        net.set_uc_seed(1)
+        test_net(net, ResidentFrames(frames, info, 3 * lanes), out_dir, max_dets=MAX_DETS, thresh=THRESH, mode="val")
+        db = ResidentFrames(frames, info, n_frames)
+        runs = []
+        for _ in range(calls):
+            net.set_uc_seed(1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            boxes = test_net(net, db, out_dir, max_dets=MAX_DETS, thresh=THRESH, mode="val")
+            torch.cuda.synchronize()
+            runs.append((time.perf_counter() - t0, boxes))
+        # the eager path draws the same masks for the same forward count: replay the first frames eagerly and compare
+        width = 5 + num_uncertainty_pos(NUM_CLASSES, 4)
+        net.set_uc_seed(1)
+        bad, checked = 0, min(n_frames, 2 * len(frames))
+        for i in range(checked):
+            dets, counts = detect_frame_device(net, frames[i % len(frames)], info, THRESH, MAX_DETS, max_out)
+            exp = collate.unpack_records(collate.pack_record(dets, counts).unsqueeze(0), NUM_CLASSES, max_out, width)[0]
+            bad += sum(1 for _, boxes in runs for j in range(1, NUM_CLASSES)
+                       if not np.array_equal(np.asarray(boxes[j][i]).reshape(-1, width), exp[j]))
+        runs.sort(key=lambda r: r[0])
+        fps = n_frames / runs[len(runs) // 2][0]
+        return {"frames_s": fps, "runner_frames_s": runner_fps, "ratio_to_runner": fps / runner_fps, "frames": n_frames,
+                "e_num_sample": int(cfg.UC.E_NUM_SAMPLE), "a_num_ce_sample": int(cfg.UC.A_NUM_CE_SAMPLE),
+                "row_width": width, "records_equal_to_eager_path": bad == 0, "frames_checked_against_eager": checked,
+                "what": "cfg.UC.EN_BBOX/CLS_ALEATORIC + EN_BBOX/CLS_EPISTEMIC: 10 Monte-Carlo passes of the heads per frame as "
+                        "batched launches, uncertainty columns per detection; frames_s through model.test.test_net (whole "
+                        "call), runner_frames_s = FrameRunner x %d streams driven directly" % lanes}
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+        Cfg.reset_cfg()
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/r02_pmc_traffic.json:
     FETCH_SIZE and WRITE_SIZE are collected in separate runs, so they cannot be measured inside the timed run)."""
@@ -305,6 +446,8 @@ def parse_args(argv=None):
     ap.add_argument("--regions", type=int, default=0, help="timed repetitions of the --steps region (0 = until ~1 s is timed)")
     ap.add_argument("--no-upload", action="store_true", help="skip the extra region that uploads every frame inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-drop-in", action="store_true", help="skip the legs that time model.test.test_net (drop_in, drop_in_uncertainty)")
+    ap.add_argument("--drop-in-frames", type=int, default=240, help="frames per timed test_net call")
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--layers", action="store_true", help="print the per-layer conv table to stderr")
     ap.add_argument("--rehearse-collate", action="store_true",
@@ -652,9 +795,15 @@ def main(argv=None):
                           file=sys.stderr)
             out["roofline_roi_align"] = roi_align_timing(net, 20)
             out["roofline_nms"] = nms_timing(net, 20)
+            if world == 1 and not args.no_drop_in:
+                out["drop_in"] = drop_in_timing(net, frames, info, max(args.steps, args.drop_in_frames), out["value"])
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"], _ = cpu_baseline(sd, frames_host[:args.cpu_frames], info)
                 out["map_delta_vs_cpu"] = map_delta(net, sd, frames_host[:2], info)
+            if world == 1 and not args.no_drop_in:
+                del runners, net
+                out["drop_in_uncertainty"] = drop_in_uncertainty(device, max(args.steps, args.drop_in_frames),
+                                                                 frames_host, info)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -108,10 +108,10 @@ PROTOTYPES = {
     "frcnn_mc_bbox_var": (c_int, [_P, c_int, c_int64, _P, _P]),
     "frcnn_mc_cls_stats": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "frcnn_mc_mean": (c_int, [_P, c_int, c_int64, _P, _P]),
-    "frcnn_dropout_fwd": (c_int, [_P, c_int64, c_int, c_float, c_uint32, c_uint32, _P, _P]),
-    "frcnn_dropout_bwd": (c_int, [_P, c_int64, c_int, c_float, c_uint32, c_uint32, _P, _P]),
-    "frcnn_logit_distort": (c_int, [_P, _P, c_int64, c_int, c_uint32, c_uint32, c_int, _P, _P, _P]),
-    "frcnn_bayesian_cross_entropy": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_uint32, c_uint32, c_int, c_float, _P, _P, _P,
+    "frcnn_dropout_fwd": (c_int, [_P, c_int64, c_int, c_float, c_uint32, _P, c_uint32, _P, _P]),
+    "frcnn_dropout_bwd": (c_int, [_P, c_int64, c_int, c_float, c_uint32, _P, c_uint32, _P, _P]),
+    "frcnn_logit_distort": (c_int, [_P, _P, c_int64, c_int, c_uint32, _P, c_uint32, c_int, _P, _P, _P]),
+    "frcnn_bayesian_cross_entropy": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_uint32, _P, c_uint32, c_int, c_float, _P, _P, _P,
                                              _P, _P]),
     "frcnn_exp": (c_int, [_P, c_int64, _P, _P]),
     "frcnn_bbox_transform": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),

@@ -17,5 +17,5 @@ int fail(int code, const char* fmt, ...) {
 
 }  // namespace frcnn
 
-extern "C" int frcnn_version(void) { return 106; }
+extern "C" int frcnn_version(void) { return 107; }
 extern "C" const char* frcnn_last_error(void) { return frcnn::error_buffer(); }

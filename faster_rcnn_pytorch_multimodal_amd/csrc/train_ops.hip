@@ -613,8 +613,10 @@ __global__ __launch_bounds__(256) void mc_mean_kernel(const float* __restrict__ 
 // keep = uniform01(seed, stream, t * n_in + i) >= p.  repeat > 1 starts the Monte-Carlo passes of the epistemic heads
 // from ONE deterministic activation (lib/model/test.py:74-77: E_NUM_SAMPLE passes per frame).
 __global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, size_t n_in, int repeat, float p,
-                                                         float scale, uint32_t seed, uint32_t stream,
+                                                         float scale, uint32_t seed,
+                                                         const uint32_t* __restrict__ seed_dev, uint32_t stream,
                                                          float* __restrict__ y) {
+  if (seed_dev) seed += *seed_dev;      // per-frame seed from device memory (a replayed hipGraph keeps `seed` itself)
   const size_t total = n_in * (size_t)repeat;
   for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
     const float v = x[j % n_in];
@@ -623,8 +625,10 @@ __global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restric
 }
 // dx[i] = sum_t keep(t, i) * dy[t][i] / (1 - p), summed in t order
 __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dy, size_t n_in, int repeat, float p,
-                                                         float scale, uint32_t seed, uint32_t stream,
+                                                         float scale, uint32_t seed,
+                                                         const uint32_t* __restrict__ seed_dev, uint32_t stream,
                                                          float* __restrict__ dx) {
+  if (seed_dev) seed += *seed_dev;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += (size_t)gridDim.x * blockDim.x) {
     float g = 0.f;
     for (int t = 0; t < repeat; ++t) {
@@ -639,8 +643,11 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restric
 // var_is_log: the head predicts s = log(var) (the convention of the box-variance head, lib/model/test.py:82); var_out
 // (n, may be NULL) then receives exp(s), the a_cls_var column of the detections.
 __global__ __launch_bounds__(256) void logit_distort_kernel(const float* __restrict__ score, const float* __restrict__ var,
-                                                           size_t n, int S, uint32_t seed, uint32_t stream, int var_is_log,
-                                                           float* __restrict__ out, float* __restrict__ var_out) {
+                                                           size_t n, int S, uint32_t seed,
+                                                           const uint32_t* __restrict__ seed_dev, uint32_t stream,
+                                                           int var_is_log, float* __restrict__ out,
+                                                           float* __restrict__ var_out) {
+  if (seed_dev) seed += *seed_dev;
   const size_t total = n * (size_t)S;
   for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
     const size_t i = j % n;
@@ -659,10 +666,12 @@ __global__ __launch_bounds__(256) void exp_kernel(const float* __restrict__ x, s
 // One thread per RoI; gradients w.r.t. score and var (through sqrt(var) * eps), scaled by grad / N.
 __global__ __launch_bounds__(256) void bayes_ce_kernel(const float* __restrict__ score, const float* __restrict__ var,
                                                       const float* __restrict__ labels, int N, int K, int S,
-                                                      uint32_t seed, uint32_t stream, int var_is_log, float grad,
+                                                      uint32_t seed, const uint32_t* __restrict__ seed_dev,
+                                                      uint32_t stream, int var_is_log, float grad,
                                                       float* __restrict__ per_roi, float* __restrict__ dscore,
                                                       float* __restrict__ dvar) {
   constexpr int KMAX = 16;
+  if (seed_dev) seed += *seed_dev;
   for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
     const int tgt = (int)labels[n];
     float sc[KMAX], sd[KMAX], gs[KMAX], gv[KMAX];
@@ -737,44 +746,47 @@ extern "C" int frcnn_mc_mean(const float* samples, int num_samples, int64_t elem
   return check_launch("mc_mean_kernel");
 }
 
-extern "C" int frcnn_dropout_fwd(const float* x, int64_t elems, int repeat, float p, uint32_t seed, uint32_t stream_id,
-                                 float* y, void* stream_) {
+extern "C" int frcnn_dropout_fwd(const float* x, int64_t elems, int repeat, float p, uint32_t seed,
+                                 const uint32_t* seed_dev, uint32_t stream_id, float* y, void* stream_) {
   FRCNN_REQUIRE(x && y && elems > 0 && repeat > 0 && p >= 0.f && p < 1.f && elems * (int64_t)repeat < ((int64_t)1 << 32),
                 "dropout_fwd: bad arguments (0 <= p < 1, elems * repeat < 2^32)");
   hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for((size_t)elems * repeat)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream_), x, (size_t)elems, repeat, p, 1.0f / (1.0f - p), seed, stream_id, y);
+                     static_cast<hipStream_t>(stream_), x, (size_t)elems, repeat, p, 1.0f / (1.0f - p), seed, seed_dev,
+                     stream_id, y);
   return check_launch("dropout_fwd_kernel");
 }
 
-extern "C" int frcnn_dropout_bwd(const float* dy, int64_t elems, int repeat, float p, uint32_t seed, uint32_t stream_id,
-                                 float* dx, void* stream_) {
+extern "C" int frcnn_dropout_bwd(const float* dy, int64_t elems, int repeat, float p, uint32_t seed,
+                                 const uint32_t* seed_dev, uint32_t stream_id, float* dx, void* stream_) {
   FRCNN_REQUIRE(dy && dx && elems > 0 && repeat > 0 && p >= 0.f && p < 1.f && elems * (int64_t)repeat < ((int64_t)1 << 32),
                 "dropout_bwd: bad arguments (0 <= p < 1, elems * repeat < 2^32)");
   hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for((size_t)elems)), dim3(256), 0, static_cast<hipStream_t>(stream_),
-                     dy, (size_t)elems, repeat, p, 1.0f / (1.0f - p), seed, stream_id, dx);
+                     dy, (size_t)elems, repeat, p, 1.0f / (1.0f - p), seed, seed_dev, stream_id, dx);
   return check_launch("dropout_bwd_kernel");
 }
 
 extern "C" int frcnn_logit_distort(const float* score, const float* var, int64_t elems, int num_samples, uint32_t seed,
-                                   uint32_t stream_id, int var_is_log, float* samples, float* var_out, void* stream_) {
+                                   const uint32_t* seed_dev, uint32_t stream_id, int var_is_log, float* samples,
+                                   float* var_out, void* stream_) {
   FRCNN_REQUIRE(score && var && samples && elems > 0 && num_samples > 0 && elems * (int64_t)num_samples < ((int64_t)1 << 32),
                 "logit_distort: bad arguments (elems * num_samples < 2^32)");
   hipLaunchKernelGGL(logit_distort_kernel, dim3(grid_for((size_t)elems * num_samples)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream_), score, var, (size_t)elems, num_samples, seed, stream_id, var_is_log,
-                     samples, var_out);
+                     static_cast<hipStream_t>(stream_), score, var, (size_t)elems, num_samples, seed, seed_dev, stream_id,
+                     var_is_log, samples, var_out);
   return check_launch("logit_distort_kernel");
 }
 
 extern "C" int frcnn_bayesian_cross_entropy(const float* cls_score, const float* cls_var, const float* labels,
                                             int num_rois, int num_classes, int num_samples, uint32_t seed,
-                                            uint32_t stream_id, int var_is_log, float grad, float* loss, float* per_roi,
+                                            const uint32_t* seed_dev, uint32_t stream_id, int var_is_log, float grad,
+                                            float* loss, float* per_roi,
                                             float* dscore, float* dvar, void* stream_) {
   FRCNN_REQUIRE(cls_score && cls_var && labels && loss && per_roi && num_rois > 0 && num_classes > 1 && num_classes <= 16 &&
                     num_samples > 0 && (int64_t)num_rois * num_classes * num_samples < ((int64_t)1 << 32),
                 "bayesian_cross_entropy: bad arguments (2 <= classes <= 16)");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   hipLaunchKernelGGL(bayes_ce_kernel, dim3(grid_for((size_t)num_rois)), dim3(256), 0, stream, cls_score, cls_var, labels,
-                     num_rois, num_classes, num_samples, seed, stream_id, var_is_log, grad, per_roi, dscore, dvar);
+                     num_rois, num_classes, num_samples, seed, seed_dev, stream_id, var_is_log, grad, per_roi, dscore, dvar);
   int rc = check_launch("bayes_ce_kernel");
   if (rc != FRCNN_OK) return rc;
   hipLaunchKernelGGL(mean_reduce_kernel, dim3(1), dim3(256), 0, stream, per_roi, num_rois, loss);

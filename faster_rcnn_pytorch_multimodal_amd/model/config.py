@@ -67,7 +67,12 @@ def _defaults():
         IMAGE=dict(BBOX_NORMALIZE_MEANS=(0.0, 0.0, 0.0, 0.0), BBOX_NORMALIZE_STDS=(0.1, 0.1, 0.2, 0.2)))
     c.TEST = dict(SCALES=(1.0,), NMS_THRESH=0.6, BBOX_REG=True, HAS_RPN=True, RPN_NMS_THRESH=0.7,
                   RPN_PRE_NMS_TOP_N=6000, RPN_POST_NMS_TOP_N=300, MODE='nms', RPN_TOP_N=5000, IGNORE_DC=False,
-                  ITER=1, AUGMENT_EN=False, TOD_FILTER_LIST=['Day', 'Night', 'Dawn/Dusk'])
+                  ITER=1, AUGMENT_EN=False, TOD_FILTER_LIST=['Day', 'Night', 'Dawn/Dusk'],
+                  # not in the reference: how test_net / test_frame / run_eval execute a frame (model/frame_graph.FramePool)
+                  FRAME_GRAPHS=True,       # replay each frame as a captured hipGraph (False: eager launches)
+                  FRAMES_IN_FLIGHT=4,      # test_net: frames in flight, one HIP stream each
+                  GRAPH_MAX_SHAPES=4,      # distinct frame problems held as graphs (least recently used one is dropped)
+                  GRAPH_AUTOTUNE=True)     # time the convolution plans of a new frame shape during its warm-up frames
     c.RESNET = dict(MAX_POOL=False, FIXED_BLOCKS=1)
     c.PIXEL_MEANS = np.array([[[96.866, 98.76, 93.85]]])
     c.PIXEL_STDDEVS = np.array([[[1, 1, 1]]])

@@ -141,9 +141,16 @@ def bbox_voxel_grid_to_pc(bboxes, bev_extents, info):
     return bboxes
 
 
-def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=False, eval_det=False):
+def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=False, eval_det=False, timers=None):
     """Eval loop of lib/model/test.py:138-257 over a frame source, sharded one frame per rank per step when
     torch.distributed is initialised (BASELINE.json configs[4]).
+
+    Execution (cfg.TEST.FRAME_GRAPHS, default on): frame s is replayed as a captured hipGraph on HIP stream
+    s % cfg.TEST.FRAMES_IN_FLIGHT (``model/frame_graph.FramePool`` attached to the net: one graph per stream and frame
+    problem, captured at first use, eager launches for frame sizes it has not captured) - the arrangement bench.py times.
+    Records are bit-equal to ``detect_frame_device`` on the same blob (tests/test_reference_names.py).
+    ``timers``: optional dict that receives 'loop_s' (first frame queued -> last record on the host), 'frames' and
+    'pool' (replays / eager frames / captures) - the counterpart of the reference's _t timers (:171,196-250).
 
     ``db``: either an object with the reference's dataset protocol (``_val_index`` / ``_test_index``, ``path_at``,
     ``num_classes``, ``name``, ``evaluate_detections``; wrapped in ``ReferenceDb``, frames loaded by ``_get_blobs``), or a
@@ -156,6 +163,7 @@ def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=F
     LiDAR detections are converted from the voxel grid to metres (:223-224).  Writes ``detections.pkl`` like the
     reference (:246-248) plus the per-class text files of lib/datasets/db.py:305-367 (rank 0 only) and returns
     ``all_boxes[cls][frame]`` (rows [box..., score])."""
+    import contextlib
     import os
     import pickle
     import torch.distributed as dist
@@ -190,20 +198,35 @@ def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=F
     # EVAL_GATHER_EVERY frames is collated (one all-gather over the ranks) and copied to the host on the ring's own stream
     # (collate.RecordRing); the host unpacks a chunk of blocks at a time.
     chunk = collate.EVAL_GATHER_EVERY * 8
+    pool = net.frame_pool() if (cfg.TEST.FRAME_GRAPHS and dev.type == 'cuda' and hasattr(net, 'frame_pool')) else None
+    lanes = pool.n_streams if pool is not None else 1
+    if pool is not None:
+        pool.sync_weights()
+        cur = torch.cuda.current_stream(dev)
+        for st in pool.streams:
+            st.wait_stream(cur)
+    import time
+    t_loop = time.perf_counter()
     for c0 in range(0, steps, chunk):
         n = min(chunk, steps - c0)
         ring = collate.RecordRing(numel, n, every=collate.EVAL_GATHER_EVERY, device=dev, distributed=distributed,
                                   gather_device=gather_dev)
         for s in range(c0, c0 + n):
-            slot = ring.slot(s - c0)
             blobs = db.blobs_at(mine[s], mode) if s < len(mine) else None
-            if blobs is not None and blobs.get('data') is not None:
-                infos[mine[s]] = blobs['info']
-                dets, counts = detect_frame_device(net, blobs['data'], blobs['info'], thresh, max_dets, max_out)
-                collate.pack_record(dets, counts, slot)
-            else:
-                slot.zero_()              # a frame without data (the reference skips it, :198-203) or a padding step
-            ring.commit(s - c0)
+            with (torch.cuda.stream(pool.stream(s)) if pool is not None else contextlib.nullcontext()):
+                slot = ring.slot(s - c0)
+                if blobs is not None and blobs.get('data') is not None:
+                    infos[mine[s]] = blobs['info']
+                    runner = (pool.runner(blobs['data'].shape, blobs['info'], thresh, max_dets, max_out, lane=s % lanes)
+                              if pool is not None else None)
+                    if runner is not None:
+                        dets, counts = runner.run(blobs['data'])
+                    else:
+                        dets, counts = detect_frame_device(net, blobs['data'], blobs['info'], thresh, max_dets, max_out)
+                    collate.pack_record(dets, counts, slot)
+                else:
+                    slot.zero_()          # a frame without data (the reference skips it, :198-203) or a padding step
+                ring.commit(s - c0)
         host = ring.drain()
         for s in range(c0, c0 + n):
             rows = collate.unpack_records(host[s - c0], k, max_out, elem)
@@ -221,6 +244,14 @@ def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=F
                     if lidar and cls_boxes.size:
                         cls_boxes = bbox_voxel_grid_to_pc(cls_boxes, lidar_extents(), info)
                     all_boxes[j][i] = cls_boxes if cls_boxes.size else np.empty(0)
+    if pool is not None:
+        cur = torch.cuda.current_stream(dev)
+        for st in pool.streams:
+            cur.wait_stream(st)
+    if timers is not None:
+        timers['loop_s'] = time.perf_counter() - t_loop
+        timers['frames'] = len(mine)
+        timers['pool'] = dict(pool.stats) if pool is not None else None
     if rank == 0:
         os.makedirs(out_dir, exist_ok=True)
         with open(os.path.join(out_dir, 'detections.pkl'), 'wb') as f:

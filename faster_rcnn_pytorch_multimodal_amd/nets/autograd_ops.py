@@ -181,9 +181,13 @@ def _dgrad_winograd(conv_like, w_t, x_shape, stride, pad):
     if not DGRAD_WINOGRAD_CACHE or r != 3 or stride != 1:
         return None
     if not ops.dgrad_winograd_wanted(x_shape, k, r, s, stride, pad):
-        conv_like.__dict__.pop('_frcnn_dgrad_winograd', None)
-        conv_like.__dict__.pop('_frcnn_dgrad_winograd_refresh', None)
-        return None
+        return None          # an entry made for another shape stays (captured graphs read it by address), see _winograd_filter
+    return _dgrad_winograd_entry(conv_like, w_t)
+
+
+def _dgrad_winograd_entry(conv_like, w_t):
+    """Cached Winograd form of ``w_t``, re-derived in place when ``w_t`` changed; also the entry's refresh hook."""
+    c, _, _, k = w_t.shape
     cache = conv_like.__dict__.get('_frcnn_dgrad_winograd')
     key = (w_t.data_ptr(), w_t._version)
     if cache is not None and cache[0] == key:
@@ -192,7 +196,7 @@ def _dgrad_winograd(conv_like, w_t, x_shape, stride, pad):
         raise RuntimeError("Winograd data-gradient filter of a %dx%dx3x3 layer is not prepared: run an eager step before capturing"
                            % (k, c))
     return stable_store(conv_like, '_frcnn_dgrad_winograd', key, (ops.winograd_filter(w_t),),
-                        refresh=lambda: _dgrad_winograd(conv_like, w_t, x_shape, stride, pad))[0]
+                        refresh=lambda: _dgrad_winograd_entry(conv_like, w_t))[0]
 
 
 def _param_grad_from_krsc(dw_krsc, param):

@@ -121,16 +121,26 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, use_bn=True):
 def _winograd_filter(conv, w_krsc, nhw, stride, pad):
     """The Winograd-transformed filter U of an eligible 3x3 layer, cached next to the KRSC filter it was made from
     (``prepared_conv`` makes a new one per parameter version), so the inference path does not redo the transform per frame.
-    U (1.78x the filter) is only built - and only kept - for a layer whose plan reads it (``ops.winograd_filter_wanted``: a
-    cached Winograd plan, forced Winograd, or a shape the autotuner is about to time); under set_conv_algo(1) or an
-    implicit-GEMM plan nothing is transformed or held.  A cache miss inside a stream capture would launch the transform
+    U (1.78x the filter) is only built for a layer and shape whose plan reads it (``ops.winograd_filter_wanted``: a cached
+    Winograd plan, forced Winograd, or a shape the autotuner is about to time); under set_conv_algo(1) or an implicit-GEMM
+    plan nothing is transformed.  Once built it is kept for the lifetime of the module (a captured graph may have baked
+    its address in).  A cache miss inside a stream capture would launch the transform
     into the graph and pin a graph-pool tensor on the module: it raises instead (run one eager frame first)."""
     k, r, s, c = w_krsc.shape
     n, h, w = nhw
     if not ops.winograd_filter_wanted(n, h, w, c, k, r, s, stride, pad):
-        conv.__dict__.pop('_frcnn_winograd', None)
-        conv.__dict__.pop('_frcnn_winograd_refresh', None)
+        # this SHAPE's plan does not read U.  An entry made for another shape of the same layer stays, with its refresh
+        # hook: a captured graph of that shape (FrameRunner / TrainStepRunner) reads U by device address, so it must
+        # neither be freed nor fall out of refresh_derived_weights (two frame sizes whose plans differ, e.g. KITTI).
         return None
+    return _winograd_entry(conv, w_krsc)
+
+
+def _winograd_entry(conv, w_krsc):
+    """U of ``conv`` for the current contents of ``w_krsc``: the cached tensor, re-derived IN PLACE when the filter changed.
+    Also the entry's refresh hook - which therefore does not depend on the plan tables or the algorithm switch at the time
+    an optimizer step / load_state_dict is noticed."""
+    k, _, _, c = w_krsc.shape
     cache = conv.__dict__.get('_frcnn_winograd')
     key = (w_krsc.data_ptr(), w_krsc._version)
     if cache is not None and cache[0] == key:
@@ -138,7 +148,7 @@ def _winograd_filter(conv, w_krsc, nhw, stride, pad):
     if torch.cuda.is_current_stream_capturing():
         raise RuntimeError("Winograd filter of a %dx%dx3x3 layer is not prepared: run an eager frame before capturing" % (k, c))
     return stable_store(conv, '_frcnn_winograd', key, (ops.winograd_filter(w_krsc),),
-                        refresh=lambda: _winograd_filter(conv, w_krsc, nhw, stride, pad))[0]
+                        refresh=lambda: _winograd_entry(conv, w_krsc))[0]
 
 
 def to_nhwc(t):

@@ -74,6 +74,7 @@ class Network(nn.Module):
         self._rpn_fused = None
         self._uc_seed = int(cfg.RNG_SEED)      # counter-based draws of the uncertainty heads: seed + forward count
         self._uc_calls = 0
+        self._uc_seed_dev = None
 
     # ------------------------------------------------------------------------------------------
     # construction
@@ -144,6 +145,17 @@ class Network(nn.Module):
         s = (self._uc_seed + UC_SEED_RANK_STRIDE * rank + self._uc_calls) & 0xFFFFFFFF
         self._uc_calls += 1
         return s
+
+    def uc_seed_args(self):
+        """(seed, seed_dev) for the counter-based draws of this forward: eagerly the host counter (``next_uc_seed``) and no
+        device word; inside a captured frame / training step (model/frame_graph.py, model/train_graph.py set
+        ``_uc_seed_dev``) the scalar 0 and the device word the runner rewrites with ``next_uc_seed()`` before each replay -
+        a replayed launch keeps its scalar arguments.  Both forms draw from seed + *seed_dev, so a replayed frame gets the
+        masks the eager call of the same forward count gets."""
+        sd = getattr(self, '_uc_seed_dev', None)
+        if sd is not None:
+            return 0, sd
+        return self.next_uc_seed(), None
 
     # ------------------------------------------------------------------------------------------
     # forward pieces (reference names).  Public tensors are NCHW-shaped views of NHWC storage.
@@ -410,6 +422,13 @@ class Network(nn.Module):
         convolutions 1x1 / stride 1 / no bias and every BatchNorm of the block in eval mode."""
         if not PROJECT_BEFORE_POOLING or self._mode != 'TEST' or torch.is_grad_enabled() or cfg.ENABLE_CUSTOM_TAIL:
             return False
+        # the hook protocol: a subclass that supplies its own pooling or tail (lib/nets/vgg16.py:49-59 overrides
+        # _head_to_tail, mobilenet_v1.py likewise) must have its methods CALLED - the shortcut replaces exactly these
+        cls = type(self)
+        if (cls._crop_pool_layer is not Network._crop_pool_layer or cls._roi_align_layer is not Network._roi_align_layer
+                or cls._head_to_tail is not Network._head_to_tail or cls._layer4 is not Network._layer4
+                or any(k in self.__dict__ for k in ('_crop_pool_layer', '_roi_align_layer', '_head_to_tail', '_layer4'))):
+            return False
         if self._pyramid is not None and cfg.POOLING_MODE == 'multiscale':
             return False
         blk = self.resnet.layer4[0]
@@ -595,9 +614,41 @@ class Network(nn.Module):
     # ------------------------------------------------------------------------------------------
     # inference entry point used by lib/model/test.py:75
     # ------------------------------------------------------------------------------------------
+    def frame_pool(self, **kw):
+        """The pool of captured frames of this net (model/frame_graph.FramePool), created on first use with
+        cfg.TEST.FRAMES_IN_FLIGHT streams; keyword arguments re-create it (tests, bench.py)."""
+        from ..model.frame_graph import FramePool
+        pool = self.__dict__.get('_frame_pool')
+        if pool is None or kw or str(pool.dev) != str(torch.device(self._device)):
+            args = dict(streams=int(cfg.TEST.FRAMES_IN_FLIGHT), max_keys=int(cfg.TEST.GRAPH_MAX_SHAPES),
+                        autotune=bool(cfg.TEST.GRAPH_AUTOTUNE))
+            args.update(kw)
+            pool = self.__dict__['_frame_pool'] = FramePool(self, **args)
+        return pool
+
+    def enable_frame_graphs(self, enabled=True):
+        """``test_frame`` / ``run_eval`` replay the forward pass of a frame as a captured hipGraph (one per frame problem,
+        ``frame_pool``) instead of launching ~115 kernels from Python.  ``test_net`` uses the pool regardless
+        (cfg.TEST.FRAME_GRAPHS); this switch is for callers of the per-frame API (lib/model/test.py:75)."""
+        self._frame_graphs = bool(enabled)
+
     def test_frame(self, data, info):
         """Returns (cls_score, cls_prob, pred_boxes, rois, uncertainties) as device tensors with exactly
         ``n`` = number of proposals rows (one host sync to read n), like the reference."""
+        runner = None
+        if getattr(self, '_frame_graphs', False) and cfg.TEST.FRAME_GRAPHS and getattr(self, '_rpn_override', None) is None:
+            pool = self.frame_pool()
+            pool.sync_weights()
+            runner = pool.runner(data.shape, info, with_filter=False)
+        if runner is not None:
+            runner.run(data)
+            # the reference hands out fresh tensors: copies, because the graph's buffers are rewritten by the next frame
+            p = self._predictions = dict(runner.predictions)
+            self._info, self._mode = runner.info, 'TEST'
+            n = int(p['rois_count'].item())
+            out = {k: p[k][:n].clone() for k in ('cls_score', 'cls_prob', 'pred_boxes', 'rois')}
+            uncertainties = {k: v[:n].clone() for k, v in p.get('uncertainties', {}).items()}
+            return out['cls_score'], out['cls_prob'], out['pred_boxes'], out['rois'], uncertainties
         self.forward(data, info, None, None, mode='TEST')
         p = self._predictions
         n = int(p['rois_count'].item())

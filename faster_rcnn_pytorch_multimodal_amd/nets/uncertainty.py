@@ -154,7 +154,7 @@ def _linear(x2d, lin, bn=None, relu=False):
     return ops.conv2d_nhwc(x2d.contiguous().view(n, 1, 1, c), w.contiguous(), scale, shift, None, relu=relu).view(n, -1)
 
 
-def _branch(net, prefix, fc7, epistemic, samples, seed):
+def _branch(net, prefix, fc7, epistemic, samples, seed, seed_dev=None):
     """Features feeding ``<prefix>_pred`` heads: (T * R, D) and T.  T > 1 only when the dropout modules are stochastic."""
     if not epistemic:
         return fc7, 1
@@ -164,12 +164,12 @@ def _branch(net, prefix, fc7, epistemic, samples, seed):
     h = _linear(fc7, fc1, bn1, relu=True)                                   # deterministic: shared by the T passes
     t = samples if (d1.training or d2.training) else 1
     if d1.training:
-        h = ops.dropout(h, d1.p, seed, STREAM[prefix + '_drop1'], repeat=t).view(t * fc7.shape[0], -1)
+        h = ops.dropout(h, d1.p, seed, STREAM[prefix + '_drop1'], repeat=t, seed_dev=seed_dev).view(t * fc7.shape[0], -1)
     elif t > 1:
         h = h.repeat(t, 1)
     h = _linear(h, fc2, bn2, relu=True)
     if d2.training:
-        h = ops.dropout(h, d2.p, seed, STREAM[prefix + '_drop2'])
+        h = ops.dropout(h, d2.p, seed, STREAM[prefix + '_drop2'], seed_dev=seed_dev)
     return h, t
 
 
@@ -180,11 +180,11 @@ def classify_test(net, fc7, rois):
     r = fc7.shape[0]
     k, e = net._num_classes, net._bbox_elem()
     lidar = cfg.NET_TYPE == 'lidar'
-    seed = net.next_uc_seed()
+    seed, seed_dev = net.uc_seed_args()       # (host counter, None) eagerly; (0, device word) inside a captured frame
     t_req = max(int(net._e_num_sample), 1)
     unc = {}
     # ---- class branch ----
-    feat_c, tc = _branch(net, 'cls', fc7, u.EN_CLS_EPISTEMIC, t_req, seed)
+    feat_c, tc = _branch(net, 'cls', fc7, u.EN_CLS_EPISTEMIC, t_req, seed, seed_dev)
     score_s = _linear(feat_c, net.cls_score_net).view(tc, r, k)
     if u.EN_CLS_EPISTEMIC:
         cls_prob, e_ent, e_mi, e_var = ops.mc_cls_stats(score_s, want_var=True)
@@ -195,13 +195,13 @@ def classify_test(net, fc7, rois):
         logvar = _linear(feat_c, net.cls_al_var_net).view(tc, r, k)
         logvar = ops.mc_mean(logvar) if tc > 1 else logvar[0]
         dist, a_var = ops.logit_distort(cls_score.contiguous(), logvar.contiguous(), int(u.A_NUM_CE_SAMPLE), seed,
-                                        STREAM['logit_distort'], var_is_log=CLS_VAR_IS_LOG)
+                                        STREAM['logit_distort'], var_is_log=CLS_VAR_IS_LOG, seed_dev=seed_dev)
         _, a_ent, a_mi = ops.mc_cls_stats(dist)
         unc['a_entropy'], unc['a_mutual_info'], unc['a_cls_var'] = a_ent, a_mi, a_var
     if u.EN_CLS_EPISTEMIC:
         unc['e_entropy'], unc['e_mutual_info'], unc['e_cls_var'] = e_ent, e_mi, e_var
     # ---- box branch ----
-    feat_b, tb = _branch(net, 'bbox', fc7, u.EN_BBOX_EPISTEMIC, t_req, seed)
+    feat_b, tb = _branch(net, 'bbox', fc7, u.EN_BBOX_EPISTEMIC, t_req, seed, seed_dev)
     box_s = _linear(feat_b, net.bbox_pred_net).view(tb, r, k * e)
     bbox_pred = ops.mc_mean(box_s) if tb > 1 else box_s[0]
     key = 'LIDAR' if lidar else 'IMAGE'
@@ -259,17 +259,17 @@ def stack_uncertainty_columns(uncertainties, det_roi, num_classes):
 # ---------------------------------------------------------------------------------------------------------------------
 class _DropoutFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p, seed, stream):
-        ctx.meta = (p, seed, stream)
-        return ops.dropout(x.contiguous(), p, seed, stream)
+    def forward(ctx, x, p, seed, stream, seed_dev=None):
+        ctx.meta = (p, seed, stream, seed_dev)
+        return ops.dropout(x.contiguous(), p, seed, stream, seed_dev=seed_dev)
 
     @staticmethod
     def backward(ctx, dy):
-        p, seed, stream = ctx.meta
-        return ops.dropout_bwd(dy.contiguous(), p, seed, stream), None, None, None
+        p, seed, stream, seed_dev = ctx.meta
+        return ops.dropout_bwd(dy.contiguous(), p, seed, stream, seed_dev=seed_dev), None, None, None, None
 
 
-def _branch_train(net, prefix, fc7, epistemic, seed):
+def _branch_train(net, prefix, fc7, epistemic, seed, seed_dev=None):
     if not epistemic:
         return fc7
     fc1, fc2 = getattr(net, prefix + '_fc1'), getattr(net, prefix + '_fc2')
@@ -285,7 +285,7 @@ def _branch_train(net, prefix, fc7, epistemic, seed):
             raise NotImplementedError("BatchNorm1d of the uncertainty heads in eval() mode inside a training step")
         else:
             y = linear_train(x, lin, relu=True)
-        return _DropoutFn.apply(y, drop.p, seed, stream) if drop.training and drop.p > 0 else y
+        return _DropoutFn.apply(y, drop.p, seed, stream, seed_dev) if drop.training and drop.p > 0 else y
 
     h = layer(fc7, fc1, bn1, d1, STREAM[prefix + '_drop1'])
     return layer(h, fc2, bn2, d2, STREAM[prefix + '_drop2'])
@@ -349,10 +349,10 @@ def multi_head_train(x2d, net, modules, cache_name):
 def classify_train(net, fc7):
     """Training-time heads with cfg.UC.*: one stochastic pass (dropout masks of this step), raw log-variance outputs."""
     u = cfg.UC
-    seed = net.next_uc_seed()
+    seed, seed_dev = net.uc_seed_args()
     p = net._predictions
-    feat_c = _branch_train(net, 'cls', fc7, u.EN_CLS_EPISTEMIC, seed)
-    feat_b = _branch_train(net, 'bbox', fc7, u.EN_BBOX_EPISTEMIC, seed)
+    feat_c = _branch_train(net, 'cls', fc7, u.EN_CLS_EPISTEMIC, seed, seed_dev)
+    feat_b = _branch_train(net, 'bbox', fc7, u.EN_BBOX_EPISTEMIC, seed, seed_dev)
     cls_heads = [net.cls_score_net] + ([net.cls_al_var_net] if u.EN_CLS_ALEATORIC else [])
     box_heads = [net.bbox_pred_net] + ([net.bbox_al_var_net] if u.EN_BBOX_ALEATORIC else [])
     if feat_c is feat_b:                                   # no epistemic stacks: every head reads fc7
@@ -364,7 +364,7 @@ def classify_train(net, fc7):
     p['cls_score'], p['bbox_pred'] = cls_out[0], box_out[0]
     p['cls_var'] = cls_out[1] if u.EN_CLS_ALEATORIC else None
     p['bbox_var'] = box_out[1] if u.EN_BBOX_ALEATORIC else None
-    p['uc_seed'] = seed
+    p['uc_seed'], p['uc_seed_dev'] = seed, seed_dev
     return None, p['bbox_pred']
 
 
@@ -374,7 +374,7 @@ class _DetLossUcFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cls_score, bbox_pred, bbox_var, cls_var, labels, targets, inside, outside, meta):
-        bbox_elem, lidar, seed, num_ce = meta
+        bbox_elem, lidar, (seed, seed_dev), num_ce = meta
         weights, ry_sin = (lidar if lidar is not None else (None, False))
         dvar = dcvar = None
         if bbox_var is not None:
@@ -386,7 +386,7 @@ class _DetLossUcFn(torch.autograd.Function):
         losses = losses.clone()
         if cls_var is not None:
             ce, dcls, dcvar = ops.bayesian_cross_entropy(cls_score, cls_var, labels, num_ce, seed, STREAM['bayes_ce'],
-                                                         var_is_log=CLS_VAR_IS_LOG)
+                                                         var_is_log=CLS_VAR_IS_LOG, seed_dev=seed_dev)
             losses[0] = ce[0]
         ctx.save_for_backward(dcls, dbox, dvar, dcvar)
         return losses
@@ -400,7 +400,7 @@ class _DetLossUcFn(torch.autograd.Function):
 
 def det_loss_uc(net, labels, targets, inside, outside, lidar):
     p = net._predictions
-    meta = (net._bbox_elem(), lidar, p['uc_seed'], int(cfg.UC.A_NUM_CE_SAMPLE))
+    meta = (net._bbox_elem(), lidar, (p['uc_seed'], p.get('uc_seed_dev')), int(cfg.UC.A_NUM_CE_SAMPLE))
     c = lambda t: t.contiguous() if t is not None else None
     return _DetLossUcFn.apply(c(p['cls_score']), c(p['bbox_pred']), c(p['bbox_var']), c(p['cls_var']), labels, targets,
                               inside, outside, meta)

@@ -16,6 +16,27 @@ from . import _hip
 # Shape log for bench.py / tuning: when PROFILE is a list, every conv2d_nhwc call appends its shape dict, in call order -
 # the order of the call numbers conv_profile_end() reports with the per-dispatch durations.
 PROFILE = None
+# FLOP accounting for bench.py's training / LiDAR rooflines: when FLOPS is a dict, every forward / data-gradient /
+# filter-gradient convolution call adds its direct-form FLOPs under 'fwd' / 'dgrad' / 'wgrad' and what the matrix pipe
+# executes under '<kind>_executed' (a Winograd F(2x2,3x3) plan multiplies 16 values per 2x2 output tile instead of 36).
+FLOPS = None
+
+
+def flops_begin():
+    global FLOPS
+    FLOPS = {k: 0.0 for k in ('fwd', 'dgrad', 'wgrad', 'fwd_executed', 'dgrad_executed', 'wgrad_executed')}
+
+
+def flops_end():
+    global FLOPS
+    out, FLOPS = FLOPS, None
+    return out
+
+
+def _log_flops(kind, direct, winograd=False):
+    if FLOPS is not None:
+        FLOPS[kind] += direct
+        FLOPS[kind + '_executed'] += direct * (16.0 / 36.0 if winograd else 1.0)
 
 
 def _ptr(t):
@@ -158,6 +179,10 @@ def conv2d_nhwc(x, w_krsc, scale=None, shift=None, residual=None, stride=1, pad=
     if PROFILE is not None:
         PROFILE.append({"n": n, "h": h, "w": w, "c": c, "k": k, "r": r, "s": s, "stride": stride, "pad": pad,
                         "flops": 2.0 * n * ho * wo * k * r * s * c})
+    if FLOPS is not None:
+        _log_flops('fwd', 2.0 * n * ho * wo * k * r * s * c,
+                   residual is None and winograd_eligible(k, r, s, c, stride, pad) and _CONV_ALGO_MODE != 1 and
+                   (_CONV_ALGO_MODE == 2 or conv_plan_algo(n, h, w, c, k, r, s, stride, pad, False) == 1))
     return out
 
 
@@ -217,6 +242,9 @@ def conv2d_bwd_data(dy, w_t, x_shape, stride=1, pad=0, add=None, w_winograd=None
         if tuple(add.shape) != tuple(x_shape):
             raise _hip.HipError("conv2d_bwd_data: add shape %s != x shape %s" % (tuple(add.shape), tuple(x_shape)))
     dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    if FLOPS is not None:
+        _log_flops('dgrad', 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * k * r * s * c,
+                   add is None and dgrad_winograd_wanted(x_shape, k, r, s, stride, pad))
     ws_bytes = lib.frcnn_conv2d_bwd_data_ws_bytes(n, h, w, c, k, r, s, stride, pad)
     ws = _workspace(ws_bytes, dy.device) if ws_bytes else None
     if act_y is not None:
@@ -257,6 +285,7 @@ def conv2d_bwd_weight(x, dy, r, s, stride=1, pad=0, want_bias=False):
         raise _hip.HipError("conv2d_bwd_weight: dy shape %s does not match the forward output" % (tuple(dy.shape),))
     dw = torch.empty((k, r, s, c), dtype=torch.float32, device=x.device)
     db = torch.empty((k,), dtype=torch.float32, device=x.device) if want_bias else None
+    _log_flops('wgrad', 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * k * r * s * c)
     ws_bytes = lib.frcnn_conv2d_bwd_weight_ws_bytes(n, h, w, c, k, r, s, stride, pad)
     ws = _workspace(ws_bytes, x.device) if ws_bytes else None
     _hip.check(lib.frcnn_conv2d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), n, h, w, c, k, r, s, stride, pad,
@@ -278,6 +307,7 @@ def conv2d_bwd_weight_acc(x, dy, r, s, grad_w, grad_b=None, stride=1, pad=0):
         raise _hip.HipError("conv2d_bwd_weight_acc: grad_w %s does not fit k=%d c<=%d r=%d s=%d" % (tuple(grad_w.shape), k, c, r, s))
     if grad_b is not None:
         _dev_f32(grad_b, "grad_b")
+    _log_flops('wgrad', 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * k * r * s * c)
     ws_bytes = lib.frcnn_conv2d_bwd_weight_ws_bytes(n, h, w, c, k, r, s, stride, pad)
     ws = _workspace(ws_bytes, x.device)
     _hip.check(lib.frcnn_conv2d_bwd_weight_acc(_ptr(x), _ptr(dy), _ptr(grad_w), c_real, _ptr(grad_b), n, h, w, c, k, r, s,
@@ -306,6 +336,7 @@ def conv2d_bwd_weight_acc_grouped(xs, dys, r, s, grads, stride=1, pad=0):
             raise _hip.HipError("conv2d_bwd_weight_acc_grouped: grad_w %s does not fit k=%d c<=%d r=%d s=%d"
                                 % (tuple(gw.shape), k, c, r, s))
     arr = ctypes.c_void_p * groups
+    _log_flops('wgrad', 2.0 * groups * dys[0].shape[0] * dys[0].shape[1] * dys[0].shape[2] * k * r * s * c)
     ws_bytes = lib.frcnn_conv2d_bwd_weight_acc_grouped_ws_bytes(groups, c, k, r, s)
     ws = _workspace(ws_bytes, xs[0].device)
     _hip.check(lib.frcnn_conv2d_bwd_weight_acc_grouped(arr(*[t.data_ptr() for t in xs]), arr(*[t.data_ptr() for t in dys]),
@@ -482,6 +513,12 @@ def set_nms_suppress_at_equal(on):
     old = bool(lib.frcnn_nms_get_suppress_at_equal())
     _hip.check(lib.frcnn_nms_set_suppress_at_equal(1 if on else 0), "frcnn_nms_set_suppress_at_equal")
     return old
+
+
+def nms_suppress_at_equal():
+    """The current rule at IoU == threshold exactly (frcnn_nms_get_suppress_at_equal).  The rule is read at LAUNCH time, so
+    a captured frame keeps the rule of its capture: model/frame_graph.cfg_fingerprint keys the captured frames by it."""
+    return bool(_hip.load().frcnn_nms_get_suppress_at_equal())
 
 
 def nms_sorted(boxes, thresh, max_keep=None, n_dev=None, want_mask=False):
@@ -911,29 +948,38 @@ def mc_mean(samples):
     return out
 
 
-def dropout(x, p, seed, stream_id, repeat=1):
+def _seed_dev(seed_dev):
+    """Device word added to the scalar seed (a replayed hipGraph keeps its scalars): int32 / uint32 tensor of one element."""
+    if seed_dev is None:
+        return None
+    if not seed_dev.is_cuda or seed_dev.numel() != 1 or seed_dev.element_size() != 4:
+        raise _hip.HipError("seed_dev must be one 32-bit word on the device")
+    return seed_dev.data_ptr()
+
+
+def dropout(x, p, seed, stream_id, repeat=1, seed_dev=None):
     """nn.Dropout(p) in train() mode with counter-based masks; ``repeat`` stochastic copies: x (...) -> (repeat, ...)
-    (the leading dimension is dropped for repeat == 1)."""
+    (the leading dimension is dropped for repeat == 1).  The draws use ``seed + *seed_dev``."""
     lib = _hip.load()
     _dev_f32(x, "x")
     shape = tuple(x.shape) if repeat == 1 else (repeat,) + tuple(x.shape)
     y = torch.empty(shape, dtype=torch.float32, device=x.device)
-    _hip.check(lib.frcnn_dropout_fwd(_ptr(x), x.numel(), int(repeat), float(p), int(seed) & 0xFFFFFFFF,
+    _hip.check(lib.frcnn_dropout_fwd(_ptr(x), x.numel(), int(repeat), float(p), int(seed) & 0xFFFFFFFF, _seed_dev(seed_dev),
                                      int(stream_id) & 0xFFFFFFFF, _ptr(y), _stream()), "frcnn_dropout_fwd")
     return y
 
 
-def dropout_bwd(dy, p, seed, stream_id, repeat=1):
+def dropout_bwd(dy, p, seed, stream_id, repeat=1, seed_dev=None):
     lib = _hip.load()
     _dev_f32(dy, "dy")
     shape = tuple(dy.shape) if repeat == 1 else tuple(dy.shape[1:])
     dx = torch.empty(shape, dtype=torch.float32, device=dy.device)
-    _hip.check(lib.frcnn_dropout_bwd(_ptr(dy), dx.numel(), int(repeat), float(p), int(seed) & 0xFFFFFFFF,
+    _hip.check(lib.frcnn_dropout_bwd(_ptr(dy), dx.numel(), int(repeat), float(p), int(seed) & 0xFFFFFFFF, _seed_dev(seed_dev),
                                      int(stream_id) & 0xFFFFFFFF, _ptr(dx), _stream()), "frcnn_dropout_bwd")
     return dx
 
 
-def logit_distort(score, var, num_samples, seed, stream_id, var_is_log=False):
+def logit_distort(score, var, num_samples, seed, stream_id, var_is_log=False, seed_dev=None):
     """logit_distort (loss_utils.py:143-147): (N,K) logits and (log-)variances -> ((S, N, K) distorted logits, (N,K)
     variances)."""
     lib = _hip.load()
@@ -943,7 +989,7 @@ def logit_distort(score, var, num_samples, seed, stream_id, var_is_log=False):
     out = torch.empty((int(num_samples),) + tuple(score.shape), dtype=torch.float32, device=score.device)
     var_out = torch.empty_like(var)
     _hip.check(lib.frcnn_logit_distort(_ptr(score), _ptr(var), score.numel(), int(num_samples), int(seed) & 0xFFFFFFFF,
-                                       int(stream_id) & 0xFFFFFFFF, int(bool(var_is_log)), _ptr(out), _ptr(var_out),
+                                       _seed_dev(seed_dev), int(stream_id) & 0xFFFFFFFF, int(bool(var_is_log)), _ptr(out), _ptr(var_out),
                                        _stream()), "frcnn_logit_distort")
     return out, var_out
 
@@ -957,7 +1003,7 @@ def exp(x):
 
 
 def bayesian_cross_entropy(cls_score, cls_var, labels, num_samples, seed, stream_id, grad=1.0, want_grad=True,
-                           var_is_log=False):
+                           var_is_log=False, seed_dev=None):
     """bayesian_cross_entropy (loss_utils.py:149-169).  Returns (loss (1,), dscore, dvar) (gradients scaled by grad)."""
     lib = _hip.load()
     _dev_f32(cls_score, "cls_score"); _dev_f32(cls_var, "cls_var"); _dev_f32(labels, "labels")
@@ -968,8 +1014,8 @@ def bayesian_cross_entropy(cls_score, cls_var, labels, num_samples, seed, stream
     dscore = torch.empty_like(cls_score) if want_grad else None
     dvar = torch.empty_like(cls_var) if want_grad else None
     _hip.check(lib.frcnn_bayesian_cross_entropy(_ptr(cls_score), _ptr(cls_var), _ptr(labels), n, k, int(num_samples),
-                                                int(seed) & 0xFFFFFFFF, int(stream_id) & 0xFFFFFFFF, int(bool(var_is_log)),
-                                                float(grad), _ptr(loss), _ptr(per_roi), _ptr(dscore), _ptr(dvar), _stream()),
+                                                int(seed) & 0xFFFFFFFF, _seed_dev(seed_dev), int(stream_id) & 0xFFFFFFFF,
+                                                int(bool(var_is_log)), float(grad), _ptr(loss), _ptr(per_roi), _ptr(dscore), _ptr(dvar), _stream()),
                "frcnn_bayesian_cross_entropy")
     return loss, dscore, dvar
 

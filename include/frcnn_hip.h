@@ -533,17 +533,20 @@ int frcnn_mc_mean(const float* samples, int num_samples, int64_t elems, float* m
  *  - frcnn_logit_distort: logit_distort of loss_utils.py:143-147, samples (S, elems) = score + sqrt(var) * N(0,1).
  *  - frcnn_bayesian_cross_entropy: loss_utils.py:149-169 on the same draws: loss[0] = mean over RoIs of
  *    -log(mean_s softmax(score + sqrt(var) eps_s)[label]); per_roi (num_rois) scratch/diagnostic; dscore / dvar
- *    (num_rois, K, may be NULL) receive grad * d loss / d{score, var}. */
-int frcnn_dropout_fwd(const float* x, int64_t elems, int repeat, float p, uint32_t seed, uint32_t stream_id, float* y,
-                      void* stream);
-int frcnn_dropout_bwd(const float* dy, int64_t elems, int repeat, float p, uint32_t seed, uint32_t stream_id, float* dx,
-                      void* stream);
+ *    (num_rois, K, may be NULL) receive grad * d loss / d{score, var}.
+ *  `seed_dev` (device uint32, may be NULL): the draws use seed + *seed_dev - a launch replayed from a hipGraph keeps its
+ *  scalar `seed`, so the per-frame seed of a captured frame / training step comes through device memory (version 107). */
+int frcnn_dropout_fwd(const float* x, int64_t elems, int repeat, float p, uint32_t seed, const uint32_t* seed_dev,
+                      uint32_t stream_id, float* y, void* stream);
+int frcnn_dropout_bwd(const float* dy, int64_t elems, int repeat, float p, uint32_t seed, const uint32_t* seed_dev,
+                      uint32_t stream_id, float* dx, void* stream);
 int frcnn_logit_distort(const float* score, const float* var, int64_t elems, int num_samples, uint32_t seed,
-                        uint32_t stream_id, int var_is_log /* var holds log-variances */, float* samples,
-                        float* var_out /* (elems) exp(var) or var; may be NULL */, void* stream);
+                        const uint32_t* seed_dev, uint32_t stream_id, int var_is_log /* var holds log-variances */,
+                        float* samples, float* var_out /* (elems) exp(var) or var; may be NULL */, void* stream);
 int frcnn_bayesian_cross_entropy(const float* cls_score, const float* cls_var, const float* labels, int num_rois,
-                                 int num_classes, int num_samples, uint32_t seed, uint32_t stream_id, int var_is_log,
-                                 float grad, float* loss, float* per_roi, float* dscore, float* dvar, void* stream);
+                                 int num_classes, int num_samples, uint32_t seed, const uint32_t* seed_dev,
+                                 uint32_t stream_id, int var_is_log, float grad, float* loss, float* per_roi,
+                                 float* dscore, float* dvar, void* stream);
 /* y = exp(x) elementwise (log-variance heads -> variances at test time). */
 int frcnn_exp(const float* x, int64_t elems, float* y, void* stream);
 
