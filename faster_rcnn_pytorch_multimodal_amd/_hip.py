@@ -108,6 +108,8 @@ PROTOTYPES = {
     "frcnn_mc_bbox_var": (c_int, [_P, c_int, c_int64, _P, _P]),
     "frcnn_mc_cls_stats": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "frcnn_mc_mean": (c_int, [_P, c_int, c_int64, _P, _P]),
+    "frcnn_set_memops_mode": (c_int, [c_int]),
+    "frcnn_get_memops_mode": (c_int, []),
     "frcnn_dropout_fwd": (c_int, [_P, c_int64, c_int, c_float, c_uint32, _P, c_uint32, _P, _P]),
     "frcnn_dropout_bwd": (c_int, [_P, c_int64, c_int, c_float, c_uint32, _P, c_uint32, _P, _P]),
     "frcnn_logit_distort": (c_int, [_P, _P, c_int64, c_int, c_uint32, _P, c_uint32, c_int, _P, _P, _P]),
@@ -118,12 +120,12 @@ PROTOTYPES = {
     "frcnn_lidar_bbox_transform": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, _P]),
     "frcnn_bbox_overlaps": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, _P]),
     "frcnn_anchor_target_layer_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "frcnn_anchor_target_layer": (c_int, [_P, c_int, _P, c_int, POINTER(c_float), c_int, c_float, c_float, c_float,
+    "frcnn_anchor_target_layer": (c_int, [_P, c_int, _P, c_int, _P, POINTER(c_float), c_int, c_float, c_float, c_float,
                                           c_uint32, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
-    "frcnn_proposal_target_layer": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_float, c_float, c_float,
+    "frcnn_proposal_target_layer": (c_int, [_P, _P, _P, c_int, _P, c_int, _P, c_int, c_int, c_float, c_float, c_float,
                                             c_float, POINTER(c_float), POINTER(c_float), c_uint32, _P, _P, _P, _P, _P, _P,
                                             _P, _P, _P, _P, _P]),
-    "frcnn_proposal_target_layer_lidar": (c_int, [_P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_float, c_float,
+    "frcnn_proposal_target_layer_lidar": (c_int, [_P, _P, _P, c_int, _P, _P, _P, c_int, _P, c_int, c_int, c_float, c_float,
                                                   c_float, c_float, POINTER(c_float), POINTER(c_float), c_uint32, _P, _P, _P,
                                                   _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "frcnn_filter_per_class_ws_bytes": (c_size_t, [c_int, c_int]),

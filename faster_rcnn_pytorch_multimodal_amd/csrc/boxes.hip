@@ -1200,7 +1200,7 @@ extern "C" int frcnn_nms(const float* boxes, const int* n_dev, int n_max, float 
   uint64_t* mask = static_cast<uint64_t*>(ws);
   uint64_t* diag_t = mask + (size_t)n_max * nb;
   if (keep_mask) {
-    hipError_t e = hipMemsetAsync(keep_mask, 0, (size_t)n_max, stream);
+    hipError_t e = frcnn::fill_bytes(keep_mask, 0, (size_t)n_max, stream);
     if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "nms: memset: %s", hipGetErrorString(e));
   }
   hipLaunchKernelGGL(nms_mask_kernel, dim3(nb * (nb + 1) / 2), dim3(64), 0, stream, boxes, n_dev, n_max, nb,

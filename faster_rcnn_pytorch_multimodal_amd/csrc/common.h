@@ -20,6 +20,14 @@ inline int check_launch(const char* what) {
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Device memory initialisation / copies inside the library's launch sequences, as KERNEL launches (default) instead of
+// hipMemsetAsync / hipMemcpyAsync: a stream capture then holds kernel nodes only.  ROCm 7's packet-captured replay of a
+// single-chain hipGraph was measured to replay chains that mix kernel nodes with memset / memcpy nodes wrongly from the second
+// replay on (tools/graph_replay_repro.hip, tools/train_graph_trace.py); with kernel nodes only the same
+// step replays correctly.  frcnn_set_memops_mode(1) restores the runtime calls (A/B, reproducer).
+hipError_t fill_bytes(void* dst, int value, size_t bytes, hipStream_t stream);
+hipError_t copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t stream);
+
 // frcnn_conv2d_set_autotune state (conv_igemm.hip), shared with the filter-gradient kernel's own plan cache
 // (conv_wgrad.hip), which frcnn_conv2d_clear_plans empties as well.
 bool autotune_enabled();

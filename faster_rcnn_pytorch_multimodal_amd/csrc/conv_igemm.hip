@@ -1637,7 +1637,7 @@ extern "C" int frcnn_conv2d_bwd_data_act(const float* dy, const float* w_crsk_fl
   if (!g.dilate) {
     // strided 1x1: only pixels (ho*stride, wo*stride) receive a gradient; the rest is `add` (or zero)
     const size_t bytes = (size_t)n * h * w * c * sizeof(float);
-    hipError_t e = add ? hipMemcpyAsync(dx, add, bytes, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dx, 0, bytes, stream);
+    hipError_t e = add ? frcnn::copy_bytes(dx, add, bytes, stream) : frcnn::fill_bytes(dx, 0, bytes, stream);
     if (e != hipSuccess) return frcnn::fail(FRCNN_ERR_LAUNCH, "conv2d_bwd_data: init dx: %s", hipGetErrorString(e));
     return run_conv(dy, w_crsk_flipped, nullptr, nullptr, add, dx, n, g.ho, g.wo, k, c, 1, 1, 1, 0, 0, 1, nullptr, 0,
                     stream, stride, h, w);

@@ -60,9 +60,11 @@ struct AtlFrame {
 constexpr int ATL_MAX_GT_LDS = 512;
 
 __global__ __launch_bounds__(256) void atl_overlap_kernel(const float* __restrict__ anchors, int n,
-                                                         const float* __restrict__ gt, int g, AtlFrame fr,
+                                                         const float* __restrict__ gt, int g,
+                                                         const int* __restrict__ g_dev, AtlFrame fr,
                                                          float* __restrict__ max_ov, int* __restrict__ argmax,
                                                          unsigned* __restrict__ gt_max) {
+  if (g_dev) g = max(1, min(g, *g_dev));   // live rows of a gt buffer padded to capacity g (a replayed hipGraph: g is baked in)
   // Per-gt maxima: a wave reduces with shuffles only when one of its anchors overlaps the gt box at all (most waves of a
   // 10^6-anchor pyramid level do not), wave leaders merge into an LDS table, and each workgroup issues ONE global atomicMax
   // per gt box at its end (a per-wave global atomic was 117 K same-address atomics for 937 500 anchors x 8 boxes: 423 us).
@@ -107,6 +109,7 @@ __global__ __launch_bounds__(256) void atl_overlap_kernel(const float* __restric
 
 __global__ __launch_bounds__(256) void atl_label_kernel(const float* __restrict__ anchors, int n,
                                                        const float* __restrict__ gt, int g,
+                                                       const int* __restrict__ g_dev,
                                                        const float* __restrict__ max_ov,
                                                        const unsigned* __restrict__ gt_max, float neg_ov, float pos_ov,
                                                        uint32_t seed, const uint32_t* __restrict__ seed_dev,
@@ -114,6 +117,7 @@ __global__ __launch_bounds__(256) void atl_label_kernel(const float* __restrict_
                                                        float* __restrict__ key_fg, float* __restrict__ key_bg,
                                                        int* __restrict__ counters) {
   if (seed_dev) seed += *seed_dev;      // per-step seed from device memory (a replayed hipGraph keeps `seed` itself)
+  if (g_dev) g = max(1, min(g, *g_dev));
   const float eps = 1.1920929e-07f;  // torch.finfo(float32).eps (:62)
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float mo = max_ov[i];
@@ -218,7 +222,8 @@ __global__ __launch_bounds__(PTL_THREADS) void ptl_kernel(const float* __restric
                                                          const float* __restrict__ anchors3d,
                                                          const float* __restrict__ true_gt,
                                                          float* __restrict__ out_anchors3d,
-                                                         const float* __restrict__ gt, int g, int num_classes,
+                                                         const float* __restrict__ gt, int g,
+                                                         const int* __restrict__ g_dev, int num_classes,
                                                          int rois_per_frame, int fg_quota, float fg_thresh, float bg_hi,
                                                          float bg_lo, PtlNorm norm, uint32_t seed,
                                                          const uint32_t* __restrict__ seed_dev, int npad,
@@ -227,6 +232,7 @@ __global__ __launch_bounds__(PTL_THREADS) void ptl_kernel(const float* __restric
                                                          float* __restrict__ out_inside, float* __restrict__ out_outside,
                                                          int* __restrict__ out_assign, int* __restrict__ out_counts) {
   if (seed_dev) seed += *seed_dev;
+  if (g_dev) g = max(1, min(g, *g_dev));
   extern __shared__ __attribute__((aligned(16))) unsigned char ptl_smem[];
   uint64_t* kfg = reinterpret_cast<uint64_t*>(ptl_smem);
   uint64_t* kbg = kfg + npad;
@@ -404,7 +410,7 @@ extern "C" size_t frcnn_anchor_target_layer_ws_bytes(int num_anchors_total, int 
 }
 
 extern "C" int frcnn_anchor_target_layer(const float* anchors, int n, const float* gt_boxes, int num_gt,
-                                         const float* info_host, int rpn_batchsize, float fg_fraction,
+                                         const int* num_gt_dev, const float* info_host, int rpn_batchsize, float fg_fraction,
                                          float negative_overlap, float positive_overlap, uint32_t seed,
                                          const uint32_t* seed_dev, float* labels, float* targets, float* inside,
                                          float* outside, int* counts, void* ws, size_t ws_bytes, void* stream_) {
@@ -428,17 +434,17 @@ extern "C" int frcnn_anchor_target_layer(const float* anchors, int n, const floa
   float* sorted = reinterpret_cast<float*>(base + l.sorted);
   int* sort_count = reinterpret_cast<int*>(base + l.sort_count);
   // gt_max, counters .. up to max_ov are contiguous at the start; keep flags are contiguous too
-  hipError_t e = hipMemsetAsync(base, 0, l.max_ov, stream);
-  if (e == hipSuccess) e = hipMemsetAsync(keep_fg, 0, l.order - l.keep_fg, stream);
+  hipError_t e = fill_bytes(base, 0, l.max_ov, stream);
+  if (e == hipSuccess) e = fill_bytes(keep_fg, 0, l.order - l.keep_fg, stream);
   if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "anchor_target_layer: memset: %s", hipGetErrorString(e));
   const AtlFrame fr{info_host[0], info_host[1], info_host[2], info_host[3]};
   const unsigned grid = grid_for((size_t)n);
-  hipLaunchKernelGGL(atl_overlap_kernel, dim3(grid), dim3(256), 0, stream, anchors, n, gt_boxes, num_gt, fr, max_ov, argmax,
-                     gt_max);
+  hipLaunchKernelGGL(atl_overlap_kernel, dim3(grid), dim3(256), 0, stream, anchors, n, gt_boxes, num_gt, num_gt_dev, fr, max_ov,
+                     argmax, gt_max);
   int rc = check_launch("atl_overlap_kernel");
   if (rc != FRCNN_OK) return rc;
-  hipLaunchKernelGGL(atl_label_kernel, dim3(grid), dim3(256), 0, stream, anchors, n, gt_boxes, num_gt, max_ov, gt_max,
-                     negative_overlap, positive_overlap, seed, seed_dev, labels, key_fg, key_bg, counters);
+  hipLaunchKernelGGL(atl_label_kernel, dim3(grid), dim3(256), 0, stream, anchors, n, gt_boxes, num_gt, num_gt_dev, max_ov,
+                     gt_max, negative_overlap, positive_overlap, seed, seed_dev, labels, key_fg, key_bg, counters);
   rc = check_launch("atl_label_kernel");
   if (rc != FRCNN_OK) return rc;
   const int num_fg_cap = (int)(fg_fraction * (float)rpn_batchsize);   // :91
@@ -460,7 +466,7 @@ extern "C" int frcnn_anchor_target_layer(const float* anchors, int n, const floa
   rc = check_launch("atl_finalize_kernel");
   if (rc != FRCNN_OK) return rc;
   if (counts) {
-    e = hipMemcpyAsync(counts, counters, 2 * sizeof(int), hipMemcpyDeviceToDevice, stream);
+    e = copy_bytes(counts, counters, 2 * sizeof(int), stream);
     if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "anchor_target_layer: copy counts: %s", hipGetErrorString(e));
   }
   return FRCNN_OK;
@@ -470,8 +476,8 @@ namespace {
 template <int E>
 int launch_ptl(const float* rois, const float* roi_scores, const int* roi_count, int num_rois,
                const unsigned char* skip, const float* anchors3d,
-               const float* true_gt, float* out_anchors3d, const float* gt_boxes, int num_gt, int num_classes,
-               int rois_per_frame, float fg_fraction, float fg_thresh, float bg_thresh_hi, float bg_thresh_lo,
+               const float* true_gt, float* out_anchors3d, const float* gt_boxes, int num_gt, const int* num_gt_dev,
+               int num_classes, int rois_per_frame, float fg_fraction, float fg_thresh, float bg_thresh_hi, float bg_thresh_lo,
                const float* means_host, const float* stds_host, uint32_t seed, const uint32_t* seed_dev, float* labels,
                float* out_rois,
                float* out_scores, float* targets, float* inside, float* outside, int* gt_assignment, int* counts,
@@ -489,7 +495,7 @@ int launch_ptl(const float* rois, const float* roi_scores, const int* roi_count,
   }
   const int fg_quota = (int)lrintf(fg_fraction * (float)rois_per_frame);   // int(round(...)) (:44-45)
   hipLaunchKernelGGL(ptl_kernel<E>, dim3(1), dim3(PTL_THREADS), lds, static_cast<hipStream_t>(stream_), rois, roi_scores,
-                     roi_count, num_rois, skip, anchors3d, true_gt, out_anchors3d, gt_boxes, num_gt, num_classes,
+                     roi_count, num_rois, skip, anchors3d, true_gt, out_anchors3d, gt_boxes, num_gt, num_gt_dev, num_classes,
                      rois_per_frame, fg_quota, fg_thresh, bg_thresh_hi, bg_thresh_lo, norm, seed, seed_dev, npad, labels, out_rois,
                      out_scores, targets, inside, outside, gt_assignment, counts);
   return check_launch("ptl_kernel");
@@ -497,8 +503,9 @@ int launch_ptl(const float* rois, const float* roi_scores, const int* roi_count,
 }  // namespace
 
 extern "C" int frcnn_proposal_target_layer(const float* rois, const float* roi_scores, const int* roi_count,
-                                           int num_rois, const float* gt_boxes, int num_gt, int num_classes,
-                                           int rois_per_frame, float fg_fraction, float fg_thresh, float bg_thresh_hi,
+                                           int num_rois, const float* gt_boxes, int num_gt, const int* num_gt_dev,
+                                           int num_classes, int rois_per_frame, float fg_fraction, float fg_thresh,
+                                           float bg_thresh_hi,
                                            float bg_thresh_lo, const float* means_host, const float* stds_host,
                                            uint32_t seed, const uint32_t* seed_dev, float* labels, float* out_rois,
                                            float* out_scores,
@@ -508,15 +515,15 @@ extern "C" int frcnn_proposal_target_layer(const float* rois, const float* roi_s
                     outside && gt_assignment && counts && num_rois > 0 && num_rois <= 4096 && num_gt > 0 &&
                     num_classes > 1 && rois_per_frame > 0,
                 "proposal_target_layer: bad arguments (num_rois <= 4096, at least one gt box)");
-  return launch_ptl<4>(rois, roi_scores, roi_count, num_rois, skip_mask, nullptr, nullptr, nullptr, gt_boxes, num_gt, num_classes,
+  return launch_ptl<4>(rois, roi_scores, roi_count, num_rois, skip_mask, nullptr, nullptr, nullptr, gt_boxes, num_gt, num_gt_dev, num_classes,
                        rois_per_frame, fg_fraction, fg_thresh, bg_thresh_hi, bg_thresh_lo, means_host, stds_host, seed, seed_dev,
                        labels, out_rois, out_scores, targets, inside, outside, gt_assignment, counts, stream_);
 }
 
 extern "C" int frcnn_proposal_target_layer_lidar(const float* rois, const float* roi_scores, const int* roi_count,
                                                  int num_rois, const float* anchors3d, const float* gt_boxes,
-                                                 const float* true_gt_boxes, int num_gt, int num_classes,
-                                                 int rois_per_frame, float fg_fraction, float fg_thresh,
+                                                 const float* true_gt_boxes, int num_gt, const int* num_gt_dev,
+                                                 int num_classes, int rois_per_frame, float fg_fraction, float fg_thresh,
                                                  float bg_thresh_hi, float bg_thresh_lo, const float* means_host,
                                                  const float* stds_host, uint32_t seed, const uint32_t* seed_dev,
                                                  float* labels, float* out_rois,
@@ -528,7 +535,7 @@ extern "C" int frcnn_proposal_target_layer_lidar(const float* rois, const float*
                     num_rois > 0 && num_rois <= 4096 && num_gt > 0 && num_classes > 1 && rois_per_frame > 0,
                 "proposal_target_layer_lidar: bad arguments (num_rois <= 4096, at least one gt box)");
   return launch_ptl<7>(rois, roi_scores, roi_count, num_rois, skip_mask, anchors3d, true_gt_boxes, out_anchors3d, gt_boxes, num_gt,
-                       num_classes, rois_per_frame, fg_fraction, fg_thresh, bg_thresh_hi, bg_thresh_lo, means_host,
+                       num_gt_dev, num_classes, rois_per_frame, fg_fraction, fg_thresh, bg_thresh_hi, bg_thresh_lo, means_host,
                        stds_host, seed, seed_dev, labels, out_rois, out_scores, targets, inside, outside, gt_assignment, counts,
                        stream_);
 }

@@ -478,7 +478,7 @@ extern "C" int frcnn_rpn_loss(const float* rpn, int ld, int num_anchors, int hw,
   rc = check_launch("rpn_loss_final_kernel");
   if (rc != FRCNN_OK || !drpn) return rc;
   if (ld > 6 * num_anchors) {  // padding columns of the fused head carry no gradient
-    hipError_t e = hipMemsetAsync(drpn, 0, (size_t)hw * ld * sizeof(float), stream);
+    hipError_t e = fill_bytes(drpn, 0, (size_t)hw * ld * sizeof(float), stream);
     if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "rpn_loss: memset: %s", hipGetErrorString(e));
   }
   hipLaunchKernelGGL(rpn_loss_grad_kernel, dim3(grid_for((size_t)total, 4096)), dim3(256), 0, stream, rpn, ld, num_anchors,

@@ -262,10 +262,10 @@ extern "C" int frcnn_bev_voxelize(const float* points, int num_points, int point
   char* w = static_cast<char*>(ws);
   auto ip = [&](size_t o) { return reinterpret_cast<int*>(w + o); };
   const int C = num_slices + num_meta;
-  hipError_t e = hipMemsetAsync(bev, 0, (size_t)cols * C * sizeof(float), stream);
-  if (e == hipSuccess) e = hipMemsetAsync(ip(l.first), 0x7F, (size_t)cells * 4, stream);
-  if (e == hipSuccess) e = hipMemsetAsync(ip(l.cnt), 0, l.vcell - l.cnt, stream);          // cnt, off, cursor
-  if (e == hipSuccess) e = hipMemsetAsync(ip(l.col_last), 0xFF, (size_t)cols * 4, stream);
+  hipError_t e = fill_bytes(bev, 0, (size_t)cols * C * sizeof(float), stream);
+  if (e == hipSuccess) e = fill_bytes(ip(l.first), 0x7F, (size_t)cells * 4, stream);
+  if (e == hipSuccess) e = fill_bytes(ip(l.cnt), 0, l.vcell - l.cnt, stream);          // cnt, off, cursor
+  if (e == hipSuccess) e = fill_bytes(ip(l.col_last), 0xFF, (size_t)cols * 4, stream);
   if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "bev_voxelize: memset: %s", hipGetErrorString(e));
   const unsigned pb = blocks_for(num_points);
   hipLaunchKernelGGL(vox_cell_kernel, dim3(pb), dim3(256), 0, stream, points, p, ip(l.cell), ip(l.first));
@@ -285,7 +285,7 @@ extern "C" int frcnn_bev_voxelize(const float* points, int num_points, int point
   int rc = check_launch("bev_voxelize kernels");
   if (rc != FRCNN_OK) return rc;
   if (num_voxels) {
-    e = hipMemcpyAsync(num_voxels, ip(l.total), sizeof(int), hipMemcpyDeviceToDevice, stream);
+    e = copy_bytes(num_voxels, ip(l.total), sizeof(int), stream);
     if (e != hipSuccess) return fail(FRCNN_ERR_LAUNCH, "bev_voxelize: copy voxel count: %s", hipGetErrorString(e));
   }
   return FRCNN_OK;

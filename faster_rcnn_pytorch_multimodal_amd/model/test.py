@@ -212,8 +212,10 @@ def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=F
         ring = collate.RecordRing(numel, n, every=collate.EVAL_GATHER_EVERY, device=dev, distributed=distributed,
                                   gather_device=gather_dev)
         for s in range(c0, c0 + n):
-            blobs = db.blobs_at(mine[s], mode) if s < len(mine) else None
+            # the loader runs inside the lane's stream context: device-side producers (prep_im_for_blob, the BEV voxeliser)
+            # launch on the stream that consumes their blob
             with (torch.cuda.stream(pool.stream(s)) if pool is not None else contextlib.nullcontext()):
+                blobs = db.blobs_at(mine[s], mode) if s < len(mine) else None
                 slot = ring.slot(s - c0)
                 if blobs is not None and blobs.get('data') is not None:
                     infos[mine[s]] = blobs['info']

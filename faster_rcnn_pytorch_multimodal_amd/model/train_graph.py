@@ -29,47 +29,124 @@ from ..nets.hip_modules import refresh_derived_weights
 from .config import cfg
 
 
-def inline_graphs_supported():
-    """May a training step be captured as ONE chain (filter gradients in line)?  Only when the HIP runtime was started with
-    DEBUG_CLR_GRAPH_PACKET_CAPTURE=0: ROCm 7's packet-captured replay of single-chain graphs replays this step wrongly from
-    the second replay on (wrong filter gradients; profiles/r03_train_step.md), the general replay path is correct."""
+GT_CAPACITY_MIN = 32      # rows of a captured step's gt buffer: max(32, next power of two of the frame's boxes)
+
+
+def gt_capacity(num_gt):
+    cap = GT_CAPACITY_MIN
+    while cap < num_gt:
+        cap *= 2
+    return cap
+
+
+def packet_capture_disabled():
+    """Was the HIP runtime started with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (the general replay path for every graph)?"""
     import os
     return os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') == '0'
 
 
+def inline_graphs_supported():
+    """May a training step be captured as ONE chain (filter gradients in line)?  Yes.  Root cause of the round-3 fault
+    ("wrong filter gradients from the second replay on" under ROCm 7's packet-captured replay of single-chain graphs):
+    the hipMemsetAsync / hipMemcpyAsync NODES this library's launch sequences put into the chain (anchor target layer,
+    strided 1x1 data gradient, RPN loss) - tools/train_graph_trace.py: with them the chain diverges from replay 2, with the
+    same initialisations as kernel launches (csrc/common.hip fill_bytes / copy_bytes, the default since library version
+    107) it replays correctly on the default runtime path.  ``TrainStepRunner`` additionally refuses an in-line capture
+    that still contains a memset node (``InlineCaptureUnsafe``: e.g. a torch reduction's semaphore memset) and
+    ``TrainPipeline`` checks every captured runner's replays against each other."""
+    return True
+
+
+class InlineCaptureUnsafe(RuntimeError):
+    """An in-line (single-chain) capture holds node kinds the packet-captured replay path is known to mishandle."""
+
+
+_NODE_KINDS = {0: 'kernel', 1: 'memcpy', 2: 'memset', 3: 'host', 4: 'graph', 5: 'empty', 6: 'wait_event', 7: 'event_record',
+               8: 'ext_sem_signal', 9: 'ext_sem_wait', 10: 'mem_alloc', 11: 'mem_free', 12: 'memcpy_from_symbol',
+               13: 'memcpy_to_symbol'}
+
+
+def _hip_runtime():
+    """The libamdhip64 instance THIS process already runs on (torch ships its own copy: opening another one by name would
+    hand its entry points graph handles of a different runtime)."""
+    import ctypes
+    with open('/proc/self/maps') as f:
+        paths = {line.split()[-1] for line in f if 'libamdhip64' in line}
+    if not paths:
+        raise RuntimeError("libamdhip64 is not loaded in this process")
+    return ctypes.CDLL(sorted(paths)[0])
+
+
+def graph_node_kinds(graph):
+    """(histogram {kind: count}, nodes, edges) of a ``torch.cuda.CUDAGraph`` captured with ``keep_graph=True`` (before or
+    after ``instantiate()``), read through hipGraphGetNodes / hipGraphNodeGetType / hipGraphGetEdges.  A capture of one
+    stream is a chain: edges == nodes - 1."""
+    import ctypes
+    hip = _hip_runtime()
+    raw = ctypes.c_void_p(graph.raw_cuda_graph())
+    n = ctypes.c_size_t(0)
+    if hip.hipGraphGetNodes(raw, None, ctypes.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    nodes = (ctypes.c_void_p * max(n.value, 1))()
+    hip.hipGraphGetNodes(raw, nodes, ctypes.byref(n))
+    hist = {}
+    for i in range(n.value):
+        t = ctypes.c_int(-1)
+        hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t))
+        kind = _NODE_KINDS.get(t.value, 'type%d' % t.value)
+        hist[kind] = hist.get(kind, 0) + 1
+    e = ctypes.c_size_t(0)
+    hip.hipGraphGetEdges(raw, None, None, ctypes.byref(e))
+    return hist, int(n.value), int(e.value)
+
+
 def graphable(net, blobs):
     """Why this step cannot run as a graph (a string), or None."""
-    from ..nets import uncertainty
-    if uncertainty.enabled():
-        return "uncertainty heads draw from a host-side counter"
-    if cfg.NET_TYPE != 'image':
-        return "LiDAR detector: BatchNorm layers train on batch statistics through host-tracked state"
-    if cfg.RESNET.FIXED_BLOCKS == -1:
-        return "FIXED_BLOCKS == -1: BatchNorm on batch statistics"
     if cfg.TRAIN.IGNORE_DC and blobs.get('gt_boxes_dc') is not None and len(blobs['gt_boxes_dc']) > 0:
-        return "don't-care boxes"
+        return "don't-care boxes (their number varies per frame and they are read on the host)"
     if len(blobs['gt_boxes']) == 0:
         return "no ground-truth boxes"
+    for m in net.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training and m.track_running_stats and m.momentum is None:
+            return "BatchNorm with momentum=None (cumulative average: the factor is computed on the host per step)"
     return None
 
 
 class TrainStepRunner:
     """``run(blobs)`` -> (loss (device scalar tensor), candidate counts (device int32)) with the gradients of this frame
-    added to every ``param.grad``."""
+    added to every ``param.grad``.
 
-    def __init__(self, net, height, width, channels, num_gt, info, warmup=2, autotune=True, grads=None, inline=False):
-        """``grads``: gradient buffers (one per trainable parameter, in net.parameters() order) the captured backward
-        accumulates into; default: the parameters' own ``.grad`` (created as zeros when missing).  A pipeline slot passes
-        its private buffers (``TrainPipeline``).  ``inline``: capture the filter gradients in line (one chain, see
-        ``inline_graphs_supported``) instead of on a side stream."""
+    One runner serves every frame of its (H, W, C, info) problem: ground-truth boxes go through a buffer of ``gt_cap`` rows
+    (``gt_capacity``: 32, 64, ...) with the live row count in a device word that the target-layer kernels read
+    (``frcnn_*_target_layer``'s ``num_gt_dev``), like the sampling seeds.  LiDAR frames carry two such buffers (BEV
+    rectangles and 3-D rows, split on the host before the replay).  BatchNorm layers in train() mode (LiDAR backbone,
+    FIXED_BLOCKS == -1) update their running statistics inside the captured launches; ``run`` bumps the modules' host-side
+    statistics version afterwards so that an eval-mode forward re-folds them."""
+
+    def __init__(self, net, height, width, channels, num_gt, info, warmup=2, autotune=True, grads=None, inline=False,
+                 group_wgrad=None, debug_dump=None):
+        """``num_gt``: boxes of the first frame (fixes the buffer capacity).  ``grads``: gradient buffers (one per trainable
+        parameter, in net.parameters() order) the captured backward accumulates into; default: the parameters' own
+        ``.grad`` (created as zeros when missing).  A pipeline slot passes its private buffers (``TrainPipeline``).
+        ``inline``: capture the filter gradients in line (one chain) instead of on a side stream."""
         self.net = net
         self.info = np.asarray(info, dtype=np.float32).copy()
         dev = torch.device(net._device)
+        self.lidar = cfg.NET_TYPE == 'lidar'
+        self.gt_cap = gt_capacity(int(num_gt))
         self.static_in = torch.zeros((1, height, width, channels), dtype=torch.float32, device=dev)
-        self.static_gt = torch.zeros((num_gt, 5), dtype=torch.float32, device=dev)
+        self.static_gt = torch.zeros((self.gt_cap, 5), dtype=torch.float32, device=dev)
+        self.static_true_gt = torch.zeros((self.gt_cap, 8), dtype=torch.float32, device=dev) if self.lidar else None
+        self.gt_count = torch.ones((1,), dtype=torch.int32, device=dev)
         self.seed_dev = torch.zeros((2,), dtype=torch.int32, device=dev)
-        self.key = (height, width, channels, num_gt, tuple(float(v) for v in self.info))
+        from ..nets import uncertainty
+        self.uc_seed_dev = torch.zeros((1,), dtype=torch.int32, device=dev) if uncertainty.enabled() else None
+        self.key = (height, width, channels, self.gt_cap, tuple(float(v) for v in self.info))
+        self.bn_modules = [m for m in net.modules()
+                           if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training and m.track_running_stats]
         from .. import ops
+        # warm-up / capture frame: zeros with ONE plausible box, so that the target layers see a regular problem
+        self._fill_placeholder_gt(height, width)
         # every gradient buffer exists before the capture: the captured backward then ACCUMULATES in place
         params = [p for p in net.parameters() if p.requires_grad]
         for p in params:
@@ -82,6 +159,9 @@ class TrainStepRunner:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         saved = [p.grad.clone() for p in net.parameters() if p.requires_grad]
+        # the warm-up / capture steps run BatchNorm on batch statistics of a zero frame: keep the running statistics
+        stats = [(m, m.running_mean.clone(), m.running_var.clone(),
+                  m.num_batches_tracked.clone() if m.num_batches_tracked is not None else None) for m in self.bn_modules]
         with torch.cuda.stream(side):
             ops.set_conv_autotune(autotune)
             try:
@@ -97,49 +177,97 @@ class TrainStepRunner:
         # (autograd_ops._wgrad), never by autograd's AccumulateGrad nodes: those run on the stream the parameter was
         # created on (the default stream, outside the capture) and were measured to race with the captured backward
         # (up to 1 % gradient error); the side-stream form is exact and lets the filter gradients overlap the chain.
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True)
         prev = (autograd_ops.ASYNC_WGRAD, autograd_ops.WGRAD_ON_SIDE_STREAM, autograd_ops.GROUP_WGRAD)
         autograd_ops.ASYNC_WGRAD = True
         autograd_ops.WGRAD_ON_SIDE_STREAM = not inline
         # in line, the grouped filter gradients of a stage (autograd_ops.GROUP_WGRAD) cost nothing in overlap - there is no side
         # chain to trail - and save 1.3 ms of kernel time per step
-        autograd_ops.GROUP_WGRAD = bool(inline) or prev[2]
+        autograd_ops.GROUP_WGRAD = (bool(inline) or prev[2]) if group_wgrad is None else bool(group_wgrad)
+        if debug_dump:
+            self.graph.enable_debug_mode()
         self.inline = bool(inline)
         try:
             with torch.cuda.graph(self.graph):
                 self.loss, self.counts = self._step()
         finally:
             autograd_ops.ASYNC_WGRAD, autograd_ops.WGRAD_ON_SIDE_STREAM, autograd_ops.GROUP_WGRAD = prev
-        # the warm-up and capture passes ran on zero inputs: drop what they added to the gradients
+        if debug_dump:
+            self.graph.debug_dump(debug_dump)
+        self.node_kinds, self.nodes, self.edges = graph_node_kinds(self.graph)
+        # the warm-up and capture passes ran on a placeholder frame: drop what they added to the gradients and statistics
         with torch.no_grad():
             for p, g in zip(params, saved):
                 p.grad.copy_(g)
+            for m, mean, var, nbt in stats:
+                m.running_mean.copy_(mean)
+                m.running_var.copy_(var)
+                if nbt is not None:
+                    m.num_batches_tracked.copy_(nbt)
         for p, g in zip(params, own):
             p.grad = g
+        if self.inline and self.node_kinds.get('memset', 0) and not packet_capture_disabled():
+            raise InlineCaptureUnsafe("single-chain capture of the training step holds %d memset nodes (kinds %s): the runtime's "
+                                      "packet-captured replay is not trusted with them" % (self.node_kinds['memset'], self.node_kinds))
+        self.graph.instantiate()
+
+    def _fill_placeholder_gt(self, height, width):
+        box = torch.tensor([width * 0.25, height * 0.25, width * 0.6, height * 0.6, 1.0])
+        self.static_gt.zero_()
+        self.static_gt[0].copy_(box)
+        if self.lidar:
+            t = torch.tensor([width * 0.425, height * 0.425, 1.0, width * 0.35, height * 0.35, 2.0, 0.0, 1.0])
+            self.static_true_gt.zero_()
+            self.static_true_gt[0].copy_(t)
+        self.gt_count.fill_(1)
 
     def _step(self):
         net = self.net
-        net._seed_dev = self.seed_dev
+        net._seed_dev, net._gt_count_dev, net._uc_seed_dev = self.seed_dev, self.gt_count, self.uc_seed_dev
         try:
-            net.forward(self.static_in, self.info, self.static_gt, None, mode='TRAIN')
+            gt = (self.static_gt, self.static_true_gt) if self.lidar else self.static_gt
+            net.forward(self.static_in, self.info, gt, None, mode='TRAIN')
         finally:
-            net._seed_dev = None
+            net._seed_dev = net._gt_count_dev = net._uc_seed_dev = None
         loss = net._losses['total_loss']
         counts = net._proposal_targets.get('counts')
         net.backward(loss)
         self.losses = dict(net._losses)
         return loss, counts
 
+    def fits(self, blobs):
+        return len(blobs['gt_boxes']) <= self.gt_cap
+
     def run(self, blobs):
         data, gt = blobs['data'], blobs['gt_boxes']
         if isinstance(data, np.ndarray):
             data = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32))
-        if isinstance(gt, np.ndarray):
-            gt = torch.from_numpy(np.ascontiguousarray(gt, dtype=np.float32))
+        g = int(len(gt))
+        if g < 1 or g > self.gt_cap:
+            raise ValueError("TrainStepRunner: %d gt boxes, this runner holds 1..%d" % (g, self.gt_cap))
+        if self.lidar:
+            # blobs['gt_boxes'] rows [xc,yc,zc,l,w,h,ry,cls] (minibatch.py:147-167) -> the two forms the target layers take
+            # (Network.forward does the same split for the eager step)
+            from ..utils.bbox import bbaa_graphics_gems
+            gt_np = gt.detach().cpu().numpy() if isinstance(gt, torch.Tensor) else np.asarray(gt, dtype=np.float32)
+            if gt_np.ndim != 2 or gt_np.shape[1] != 8:
+                raise ValueError("LiDAR gt_boxes must be (G, 8) [xc,yc,zc,l,w,h,ry,cls], got %s" % (gt_np.shape,))
+            aabb = np.concatenate((bbaa_graphics_gems(gt_np[:, :7]), gt_np[:, 7:8]), 1).astype(np.float32)
+            self.static_true_gt[:g].copy_(torch.from_numpy(np.ascontiguousarray(gt_np, dtype=np.float32)), non_blocking=True)
+            self.static_gt[:g].copy_(torch.from_numpy(np.ascontiguousarray(aabb)), non_blocking=True)
+        else:
+            if isinstance(gt, np.ndarray):
+                gt = torch.from_numpy(np.ascontiguousarray(gt, dtype=np.float32))
+            self.static_gt[:g].copy_(gt[:, :5], non_blocking=True)
         self.static_in.copy_(data, non_blocking=True)
-        self.static_gt.copy_(gt[:, :5], non_blocking=True)
+        self.gt_count.fill_(g)
         self.seed_dev.copy_(torch.tensor([_draw_seed(), _draw_seed()], dtype=torch.int32))    # 8 bytes, host -> device
+        if self.uc_seed_dev is not None:
+            seed = self.net.next_uc_seed()
+            self.uc_seed_dev.fill_(seed - (1 << 32) if seed >= (1 << 31) else seed)
         self.graph.replay()
+        for m in self.bn_modules:      # the captured launches updated the running statistics in place
+            m.__dict__['_frcnn_stats_version'] = m.__dict__.get('_frcnn_stats_version', 0) + 1
         return self.loss, self.counts
 
 
@@ -204,19 +332,34 @@ class TrainPipeline:
             raise RuntimeError("TrainPipeline: slot %d still holds an uncollected frame (collect() before submitting more than "
                                "%d frames)" % (s, self.slots))
         data, info = blobs['data'], np.asarray(blobs['info'], dtype=np.float32)
-        key = (int(data.shape[1]), int(data.shape[2]), int(data.shape[3]), int(len(blobs['gt_boxes'])),
+        key = (int(data.shape[1]), int(data.shape[2]), int(data.shape[3]), gt_capacity(len(blobs['gt_boxes'])),
                tuple(float(v) for v in info))
         runner = self.runners[s].get(key)
         if runner is None:
             if len(self.runners[s]) >= self.max_graphs:
                 raise RuntimeError("TrainPipeline: more than %d distinct frame shapes" % self.max_graphs)
             torch.cuda.synchronize(self.dev)       # captures happen with the device idle
-            runner = TrainStepRunner(self.net, key[0], key[1], key[2], key[3], info, grads=self.grads[s],
-                                     autotune=not any(self.runners), inline=self.inline)
+            try:
+                runner = TrainStepRunner(self.net, key[0], key[1], key[2], key[3], info, grads=self.grads[s],
+                                         autotune=not any(self.runners), inline=self.inline)
+            except InlineCaptureUnsafe as e:
+                import warnings
+                warnings.warn("TrainPipeline: %s; capturing forked graphs instead (correct, but replays of different slots do "
+                              "not overlap)" % e)
+                self.inline = False
+                runner = TrainStepRunner(self.net, key[0], key[1], key[2], key[3], info, grads=self.grads[s],
+                                         autotune=False, inline=False)
             self.runners[s][key] = runner
-            if self.inline and not self._checked:
-                self._check_replays(runner, blobs, self.grads[s])
-                self._checked = True
+            if self.inline:
+                # every newly captured single-chain runner proves that its replays reproduce each other (3 replays)
+                try:
+                    self._check_replays(runner, blobs, self.grads[s])
+                except RuntimeError as e:
+                    import warnings
+                    warnings.warn(str(e) + "  Falling back to forked graphs.")
+                    self.inline = False
+                    runner = self.runners[s][key] = TrainStepRunner(self.net, key[0], key[1], key[2], key[3], info,
+                                                                    grads=self.grads[s], autotune=False, inline=False)
         st = self.streams[s]
         st.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(st):
@@ -233,23 +376,32 @@ class TrainPipeline:
         frame with the same sampling seeds and compare the increments.  Raises instead of training on wrong gradients."""
         torch.cuda.synchronize(self.dev)
         held = [g.clone() for g in grads]
+        stats = [(m, m.running_mean.clone(), m.running_var.clone(),
+                  m.num_batches_tracked.clone() if m.num_batches_tracked is not None else None) for m in runner.bn_modules]
+        uc_calls = getattr(self.net, '_uc_calls', 0)
         incs = []
         with torch.no_grad():
             for _ in range(3):
                 torch._foreach_zero_(grads)
                 state = torch.random.get_rng_state()
+                self.net._uc_calls = uc_calls                   # the same dropout masks / logit noise ...
                 runner.run(blobs)
-                torch.random.set_rng_state(state)               # the same two sampling seeds for every replay
+                torch.random.set_rng_state(state)               # ... and the same two sampling seeds for every replay
                 torch.cuda.synchronize(self.dev)
                 incs.append([g.clone() for g in grads])
             for g, h in zip(grads, held):
                 g.copy_(h)
+            self.net._uc_calls = uc_calls
+            for m, mean, var, nbt in stats:                     # the check must not count as three training steps
+                m.running_mean.copy_(mean)
+                m.running_var.copy_(var)
+                if nbt is not None:
+                    m.num_batches_tracked.copy_(nbt)
         scale = max(float(a.abs().max()) for a in incs[0]) or 1.0
         worst = max(float((a - b).abs().max()) for k in (1, 2) for a, b in zip(incs[0], incs[k])) / scale
         if not worst <= 1e-3:
             raise RuntimeError("TrainPipeline: a replayed single-chain training graph does not reproduce its own gradients "
-                               "(deviation %.3e of their scale).  Start the process with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, or "
-                               "build the pipeline with inline=False." % worst)
+                               "(deviation %.3e of their scale; node kinds %s)." % (worst, runner.node_kinds))
 
     def in_flight(self):
         return len(self.order)

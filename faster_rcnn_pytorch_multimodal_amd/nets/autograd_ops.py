@@ -278,6 +278,7 @@ class _BnTrainFn(torch.autograd.Function):
             bn.__dict__['_frcnn_stats_version'] = bn.__dict__.get('_frcnn_stats_version', 0) + 1
         ctx.relu = relu
         ctx.has_res = residual is not None
+        ctx.affine = (gamma, beta)
         ctx.save_for_backward(y, out if relu else None, gamma, mean, invstd)
         return out
 
@@ -287,6 +288,14 @@ class _BnTrainFn(torch.autograd.Function):
         dy, dres, dgamma, dbeta = ops.bn_train_bwd(dout.contiguous(), out, y, gamma.detach() if gamma is not None else None,
                                                    mean, invstd, relu=ctx.relu,
                                                    want_res=ctx.has_res and ctx.needs_input_grad[1])
+        if ASYNC_WGRAD:
+            # captured steps (model/train_graph.py) accumulate parameter gradients themselves, in place, on the step's stream:
+            # autograd's AccumulateGrad nodes run on the parameters' creation stream, outside the capture
+            with torch.no_grad():
+                for prm, g, need in ((ctx.affine[0], dgamma, ctx.needs_input_grad[2]), (ctx.affine[1], dbeta, ctx.needs_input_grad[3])):
+                    if need and prm is not None and g is not None:
+                        _accumulate(prm, g.view_as(prm))
+            dgamma = dbeta = None
         return (dy if ctx.needs_input_grad[0] else None, dres, dgamma if ctx.needs_input_grad[2] else None,
                 dbeta if ctx.needs_input_grad[3] else None, None, None)
 

@@ -518,8 +518,9 @@ class Network(nn.Module):
         ov = getattr(self, '_target_override', None) or {}
         # per-step sampling seeds: drawn on the host, or (model/train_graph.py) read on the device from self._seed_dev
         sd = getattr(self, '_seed_dev', None)
-        seed_a = dict(seed=0, seed_dev=sd[0:1]) if sd is not None else {}
-        seed_p = dict(seed=0, seed_dev=sd[1:2]) if sd is not None else {}
+        gc = getattr(self, '_gt_count_dev', None)          # live rows of a gt buffer padded to capacity (captured steps)
+        seed_a = dict(seed=0, seed_dev=sd[0:1], gt_count=gc) if sd is not None else {}
+        seed_p = dict(seed=0, seed_dev=sd[1:2], gt_count=gc) if sd is not None else {}
         with torch.no_grad():
             if 'anchor' in ov:
                 self._anchor_targets = dict(zip(('labels', 'targets', 'inside', 'outside'), ov['anchor']))
@@ -585,8 +586,13 @@ class Network(nn.Module):
         if mode == 'TEST':
             with torch.no_grad():
                 return self._predict()
-        gt = np.asarray(gt_boxes, dtype=np.float32) if not isinstance(gt_boxes, torch.Tensor) else gt_boxes
-        if cfg.NET_TYPE == 'lidar':
+        if isinstance(gt_boxes, tuple):
+            # (BEV rectangles (G,5), 3-D boxes (G,8)) already on the device: the captured LiDAR step (model/train_graph.py
+            # splits the blob's rows on the host before the replay)
+            gt, self._true_gt_boxes = gt_boxes
+        else:
+            gt = np.asarray(gt_boxes, dtype=np.float32) if not isinstance(gt_boxes, torch.Tensor) else gt_boxes
+        if cfg.NET_TYPE == 'lidar' and not isinstance(gt_boxes, tuple):
             # blobs['gt_boxes'] rows are [xc,yc,zc,l,w,h,ry,cls] in voxel-grid units (minibatch.py:147-167).  The target
             # layers take both forms (proposal_target_layer.py:174-175): the 3-D rows and their axis-aligned BEV
             # rectangles [x1,y1,x2,y2,cls]; the rectangle is the same bbaa_graphics_gems the 3-D anchors go through
@@ -683,18 +689,25 @@ class Network(nn.Module):
         if graphs is None:
             return None
         from ..model import train_graph
-        if train_graph.graphable(self, blobs) is not None:
-            return None
-        data, info = blobs['data'], np.asarray(blobs['info'], dtype=np.float32)
-        key = (int(data.shape[1]), int(data.shape[2]), int(data.shape[3]), int(len(blobs['gt_boxes'])),
-               tuple(float(v) for v in info))
-        runner = graphs.get(key)
-        if runner is None:
-            if len(graphs) >= self._train_graph_max:
-                return None                  # many distinct shapes: the remaining ones run eagerly
-            runner = train_graph.TrainStepRunner(self, key[0], key[1], key[2], key[3], info)
-            graphs[key] = runner
-        return runner
+        why = train_graph.graphable(self, blobs)
+        if why is None:
+            data, info = blobs['data'], np.asarray(blobs['info'], dtype=np.float32)
+            # one graph per frame geometry; the number of gt boxes only selects the capacity of its gt buffer (32, 64, ...)
+            key = (int(data.shape[1]), int(data.shape[2]), int(data.shape[3]), train_graph.gt_capacity(len(blobs['gt_boxes'])),
+                   tuple(float(v) for v in info))
+            runner = graphs.get(key)
+            if runner is not None:
+                return runner
+            if len(graphs) < self._train_graph_max:
+                runner = graphs[key] = train_graph.TrainStepRunner(self, key[0], key[1], key[2], len(blobs['gt_boxes']), info)
+                return runner
+            why = "more than %d distinct frame geometries are held as graphs (enable_train_graphs(max_graphs=...))" % self._train_graph_max
+        warned = self.__dict__.setdefault('_train_graph_warned', set())
+        if why not in warned:
+            warned.add(why)
+            import warnings
+            warnings.warn("train_step: this frame runs EAGERLY (host-bound, ~1.5x slower), not as a captured step: " + why)
+        return None
 
     def apply_update(self, optimizer, in_place=False):
         """The weight update that ends a pseudo batch (lib/model/train_val.py:379-382 inside the missing network.py's

@@ -173,6 +173,21 @@ def _branch(net, prefix, fc7, epistemic, samples, seed, seed_dev=None):
     return h, t
 
 
+def _norm_consts(net, key, k, device):
+    """(stds, means) of the box targets tiled per class, as device tensors cached on the net: a host->device copy is not
+    allowed inside a stream capture (model/frame_graph.py), and the values only change with cfg."""
+    vals = (tuple(float(v) for v in cfg.TRAIN[key].BBOX_NORMALIZE_STDS), tuple(float(v) for v in cfg.TRAIN[key].BBOX_NORMALIZE_MEANS))
+    tag = (key, k, str(device), vals)
+    cache = net.__dict__.get('_uc_norm_consts')
+    if cache is None or cache[0] != tag:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("uncertainty heads: normalisation constants are not on the device yet (run an eager frame first)")
+        cache = (tag, torch.tensor(vals[0], dtype=torch.float32, device=device).repeat(k),
+                 torch.tensor(vals[1], dtype=torch.float32, device=device).repeat(k))
+        net.__dict__['_uc_norm_consts'] = cache
+    return cache[1], cache[2]
+
+
 def classify_test(net, fc7, rois):
     """Test-time heads with cfg.UC.*: fills net._predictions (cls_score, cls_prob, bbox_pred, pred_boxes,
     uncertainties) and returns (cls_prob, bbox_pred)."""
@@ -204,9 +219,7 @@ def classify_test(net, fc7, rois):
     feat_b, tb = _branch(net, 'bbox', fc7, u.EN_BBOX_EPISTEMIC, t_req, seed, seed_dev)
     box_s = _linear(feat_b, net.bbox_pred_net).view(tb, r, k * e)
     bbox_pred = ops.mc_mean(box_s) if tb > 1 else box_s[0]
-    key = 'LIDAR' if lidar else 'IMAGE'
-    stds = torch.tensor(cfg.TRAIN[key].BBOX_NORMALIZE_STDS, dtype=torch.float32, device=fc7.device).repeat(k)
-    means = torch.tensor(cfg.TRAIN[key].BBOX_NORMALIZE_MEANS, dtype=torch.float32, device=fc7.device).repeat(k)
+    stds, means = _norm_consts(net, 'LIDAR' if lidar else 'IMAGE', k, fc7.device)
     if u.EN_BBOX_ALEATORIC:
         lv = _linear(feat_b, net.bbox_al_var_net).view(tb, r, k * e)
         a_var = ops.exp((ops.mc_mean(lv) if tb > 1 else lv[0]).contiguous())

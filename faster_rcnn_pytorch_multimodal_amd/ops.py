@@ -1060,8 +1060,18 @@ def lidar_bbox_transform(ex_rois, ex_anchors_3d, gt_rois):
     return out
 
 
-def anchor_target_layer(anchors, gt_boxes, info, rpn_batchsize, fg_fraction, neg_ov, pos_ov, seed, seed_dev=None):
-    """Returns labels (N,), targets/inside/outside (N,4) in anchor order and counts (2,) int32 [fg, bg candidates]."""
+def _gt_count(gt_count):
+    if gt_count is None:
+        return None
+    if not gt_count.is_cuda or gt_count.dtype != torch.int32 or gt_count.numel() != 1:
+        raise _hip.HipError("gt_count must be a one-element int32 device tensor")
+    return gt_count.data_ptr()
+
+
+def anchor_target_layer(anchors, gt_boxes, info, rpn_batchsize, fg_fraction, neg_ov, pos_ov, seed, seed_dev=None,
+                        gt_count=None):
+    """Returns labels (N,), targets/inside/outside (N,4) in anchor order and counts (2,) int32 [fg, bg candidates].
+    ``gt_count`` (int32 device tensor): live rows of a ``gt_boxes`` buffer padded to its row count."""
     lib = _hip.load()
     _dev_f32(anchors, "anchors"); _dev_f32(gt_boxes, "gt_boxes")
     n, g = anchors.shape[0], gt_boxes.shape[0]
@@ -1074,14 +1084,16 @@ def anchor_target_layer(anchors, gt_boxes, info, rpn_batchsize, fg_fraction, neg
     ws_bytes = lib.frcnn_anchor_target_layer_ws_bytes(n, g, int(rpn_batchsize))
     ws = _workspace(ws_bytes, dev)
     _hip.check(lib.frcnn_anchor_target_layer(
-        _ptr(anchors), n, _ptr(gt_boxes), g, _hip.float_array([float(v) for v in list(info)[:4]]), int(rpn_batchsize),
+        _ptr(anchors), n, _ptr(gt_boxes), g, _gt_count(gt_count), _hip.float_array([float(v) for v in list(info)[:4]]),
+        int(rpn_batchsize),
         float(fg_fraction), float(neg_ov), float(pos_ov), int(seed) & 0xFFFFFFFF, _ptr(seed_dev), _ptr(labels), _ptr(targets),
         _ptr(inside), _ptr(outside), _ptr(counts), _ptr(ws), ws_bytes, _stream()), "frcnn_anchor_target_layer")
     return labels, targets, inside, outside, counts
 
 
 def proposal_target_layer(rois, roi_scores, gt_boxes, num_classes, rois_per_frame, fg_fraction, fg_thresh, bg_hi, bg_lo,
-                          means, stds, seed, roi_count=None, anchors_3d=None, true_gt_boxes=None, skip_mask=None, seed_dev=None):
+                          means, stds, seed, roi_count=None, anchors_3d=None, true_gt_boxes=None, skip_mask=None, seed_dev=None,
+                          gt_count=None):
     """Returns dict(labels (R,), rois (R,5), scores (R,), targets/inside/outside (R,4K), assign int32 (R,), counts int32 (4,)).
     With ``anchors_3d`` (num_rois,7) and ``true_gt_boxes`` (G,8) the LiDAR form: 7K-wide targets and ``anchors_3d`` (R,7)."""
     lib = _hip.load()
@@ -1110,7 +1122,7 @@ def proposal_target_layer(rois, roi_scores, gt_boxes, num_classes, rois_per_fram
                "counts": torch.zeros((4,), dtype=torch.int32, device=dev)}
         _hip.check(lib.frcnn_proposal_target_layer_lidar(
             _ptr(rois), _ptr(roi_scores), _ptr(roi_count), rois.shape[0], _ptr(anchors_3d), _ptr(gt_boxes),
-            _ptr(true_gt_boxes), gt_boxes.shape[0], int(num_classes), r, float(fg_fraction), float(fg_thresh), float(bg_hi),
+            _ptr(true_gt_boxes), gt_boxes.shape[0], _gt_count(gt_count), int(num_classes), r, float(fg_fraction), float(fg_thresh), float(bg_hi),
             float(bg_lo), _hip.float_array(means), _hip.float_array(stds), int(seed) & 0xFFFFFFFF, _ptr(seed_dev), _ptr(out["labels"]),
             _ptr(out["rois"]), _ptr(out["scores"]), _ptr(out["anchors_3d"]), _ptr(out["targets"]), _ptr(out["inside"]),
             _ptr(out["outside"]), _ptr(out["assign"]), _ptr(out["counts"]), _ptr(skip_mask), _stream()),
@@ -1125,8 +1137,8 @@ def proposal_target_layer(rois, roi_scores, gt_boxes, num_classes, rois_per_fram
            "assign": torch.empty((r,), dtype=torch.int32, device=dev),
            "counts": torch.zeros((4,), dtype=torch.int32, device=dev)}
     _hip.check(lib.frcnn_proposal_target_layer(
-        _ptr(rois), _ptr(roi_scores), _ptr(roi_count), rois.shape[0], _ptr(gt_boxes), gt_boxes.shape[0], int(num_classes),
-        r, float(fg_fraction), float(fg_thresh), float(bg_hi), float(bg_lo), _hip.float_array(means),
+        _ptr(rois), _ptr(roi_scores), _ptr(roi_count), rois.shape[0], _ptr(gt_boxes), gt_boxes.shape[0], _gt_count(gt_count),
+        int(num_classes), r, float(fg_fraction), float(fg_thresh), float(bg_hi), float(bg_lo), _hip.float_array(means),
         _hip.float_array(stds), int(seed) & 0xFFFFFFFF, _ptr(seed_dev), _ptr(out["labels"]), _ptr(out["rois"]), _ptr(out["scores"]),
         _ptr(out["targets"]), _ptr(out["inside"]), _ptr(out["outside"]), _ptr(out["assign"]), _ptr(out["counts"]),
         _ptr(skip_mask), _stream()), "frcnn_proposal_target_layer")

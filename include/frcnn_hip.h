@@ -31,6 +31,11 @@ extern "C" {
 
 /* Library version (major*10000 + minor*100 + patch) and last error text of this thread. */
 int frcnn_version(void);
+/* How the library initialises / copies device memory inside its launch sequences: 0 (default) = its own fill / copy
+ * KERNELS, so that a stream capture of any entry point holds kernel nodes only; 1 = hipMemsetAsync / hipMemcpyAsync
+ * (memset / memcpy graph nodes).  See DESIGN.md section 4.8 for why the default is 0.  Process-wide, read at call time. */
+int frcnn_set_memops_mode(int mode);
+int frcnn_get_memops_mode(void);
 const char* frcnn_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -463,6 +468,8 @@ int frcnn_lidar_bbox_transform(const float* ex_rois, int roi_ld, const float* ex
  * device memory the caller rewrites before each replay; same for the proposal target layers below). */
 size_t frcnn_anchor_target_layer_ws_bytes(int num_anchors_total, int num_gt, int rpn_batchsize);
 int frcnn_anchor_target_layer(const float* anchors, int n, const float* gt_boxes, int num_gt,
+                              const int* num_gt_dev /* device int or NULL: live rows of a gt buffer padded to num_gt rows
+                              (one captured training step serves every number of gt boxes) */,
                               const float* info_host, int rpn_batchsize, float fg_fraction, float negative_overlap,
                               float positive_overlap, uint32_t seed, const uint32_t* seed_dev, float* labels,
                               float* targets, float* inside, float* outside, int* counts, void* ws, size_t ws_bytes,
@@ -476,7 +483,8 @@ int frcnn_anchor_target_layer(const float* anchors, int n, const float* gt_boxes
  * skip_mask (num_rois bytes, may be NULL): rows with a non-zero byte are no candidates (TRAIN.IGNORE_DC: proposals whose
  * overlap with a don't-care box reaches DC_THRESH, proposal_target_layer.py:180-191). */
 int frcnn_proposal_target_layer(const float* rois, const float* roi_scores, const int* roi_count, int num_rois,
-                                const float* gt_boxes, int num_gt, int num_classes, int rois_per_frame,
+                                const float* gt_boxes, int num_gt, const int* num_gt_dev /* as above */, int num_classes,
+                                int rois_per_frame,
                                 float fg_fraction, float fg_thresh, float bg_thresh_hi, float bg_thresh_lo,
                                 const float* means_host, const float* stds_host, uint32_t seed, const uint32_t* seed_dev,
                                 float* labels, float* out_rois, float* out_scores, float* targets, float* inside,
@@ -489,8 +497,9 @@ int frcnn_proposal_target_layer(const float* rois, const float* roi_scores, cons
  * follows the RoIs, out_anchors3d (rois_per_frame,7) the sampled rows; targets/inside/outside are (.,7*num_classes). */
 int frcnn_proposal_target_layer_lidar(const float* rois, const float* roi_scores, const int* roi_count, int num_rois,
                                       const float* anchors3d, const float* gt_boxes, const float* true_gt_boxes,
-                                      int num_gt, int num_classes, int rois_per_frame, float fg_fraction, float fg_thresh,
-                                      float bg_thresh_hi, float bg_thresh_lo, const float* means_host,
+                                      int num_gt, const int* num_gt_dev, int num_classes, int rois_per_frame,
+                                      float fg_fraction, float fg_thresh, float bg_thresh_hi, float bg_thresh_lo,
+                                      const float* means_host,
                                       const float* stds_host, uint32_t seed, const uint32_t* seed_dev, float* labels,
                                       float* out_rois, float* out_scores, float* out_anchors3d, float* targets, float* inside,
                                       float* outside, int* gt_assignment, int* counts, const unsigned char* skip_mask,

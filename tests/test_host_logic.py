@@ -283,20 +283,30 @@ def test_storage_stable_weight_caches_keep_addresses_and_refresh():
 
 
 def test_train_graph_refuses_what_it_cannot_capture():
+    """graphable(): what still runs eagerly (with a warning from Network.train_step) - don't-care boxes, frames without gt,
+    BatchNorm with a host-computed momentum.  The LiDAR detector, FIXED_BLOCKS = -1 and the uncertainty heads ARE capturable
+    since round 4 (device-side gt count / seeds, in-kernel running statistics)."""
+    import torch.nn as nn
     from faster_rcnn_pytorch_multimodal_amd.model import config as C
     from faster_rcnn_pytorch_multimodal_amd.model import train_graph
     C.reset_cfg()
     C.cfg.NET_TYPE = "image"
+    net = nn.Sequential(nn.Conv2d(4, 4, 1), nn.BatchNorm2d(4))
     blobs = {"gt_boxes": np.zeros((2, 5), np.float32), "gt_boxes_dc": np.zeros((0, 5), np.float32)}
-    assert train_graph.graphable(None, blobs) is None
-    assert "ground-truth" in train_graph.graphable(None, {"gt_boxes": np.zeros((0, 5), np.float32)})
-    C.cfg.RESNET.FIXED_BLOCKS = -1
-    assert "BatchNorm" in train_graph.graphable(None, blobs)
+    assert train_graph.graphable(net, blobs) is None
+    assert "ground-truth" in train_graph.graphable(net, {"gt_boxes": np.zeros((0, 5), np.float32)})
+    for key, val in (("RESNET.FIXED_BLOCKS", -1), ("NET_TYPE", "lidar")):
+        C.reset_cfg()
+        C.cfg_from_list([key, repr(val)])
+        assert train_graph.graphable(net, blobs) is None
     C.reset_cfg()
-    C.cfg.NET_TYPE = "lidar"
-    assert "LiDAR" in train_graph.graphable(None, blobs)
-    C.reset_cfg()
-    C.cfg.NET_TYPE = "image"
     C.cfg.UC.EN_BBOX_ALEATORIC = True
-    assert "uncertainty" in train_graph.graphable(None, blobs)
+    assert train_graph.graphable(net, blobs) is None
+    C.reset_cfg()
+    C.cfg.TRAIN.IGNORE_DC = True
+    assert "don't-care" in train_graph.graphable(net, dict(blobs, gt_boxes_dc=np.zeros((3, 5), np.float32)))
+    C.reset_cfg()
+    net[1].momentum = None
+    assert "momentum" in train_graph.graphable(net, blobs)
+    assert [train_graph.gt_capacity(n) for n in (1, 32, 33, 64, 65)] == [32, 32, 64, 64, 128]
     C.reset_cfg()

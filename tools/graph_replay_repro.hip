@@ -74,6 +74,38 @@ __global__ void touch_kernel(float* __restrict__ x, size_t n, float a) {   // di
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] = a;
 }
 
+// long dependent chain: node i computes dst = src * p.a + p.b with a 256-byte by-value parameter block
+struct Params {
+  float a, b;
+  float pad[62];
+};
+__global__ void axpb_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n, Params p) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = src[i] * p.a + p.b + p.pad[61];
+}
+
+static int g_memset_every = 0;   // long chains: every k-th node is preceded by a hipMemsetAsync of its destination
+__global__ void add_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+
+static void long_chain(float* const* ring, int nring, size_t n, float* grad, int nodes, hipStream_t s) {
+  for (int i = 0; i < nodes; ++i) {
+    if (g_memset_every && i % g_memset_every == g_memset_every - 1) {
+      // dst = 0 (runtime memset node), dst += src: a memset that is skipped or lands elsewhere leaves the ring's old contents
+      CHECK(hipMemsetAsync(ring[(i + 1) % nring], 0, n * sizeof(float), s));
+      hipLaunchKernelGGL(add_kernel, dim3(512), dim3(256), 0, s, ring[i % nring], ring[(i + 1) % nring], n);
+      continue;
+    }
+    Params p;
+    std::memset(&p, 0, sizeof(p));
+    p.a = (i % 3 == 0) ? 0.5f : ((i % 3 == 1) ? 1.5f : 1.25f);
+    p.b = 0.001f * (float)(i % 17);
+    hipLaunchKernelGGL(axpb_kernel, dim3(512), dim3(256), 0, s, ring[i % nring], ring[(i + 1) % nring], n, p);
+  }
+  hipLaunchKernelGGL(accumulate_kernel, dim3(512), dim3(256), 0, s, ring[nodes % nring], (const int*)nullptr, grad, n, 0.5f);
+}
+
 struct Bufs {
   float *src, *scratch, *grad, *tsrc, *tgrad;
   int *counters, *counts;
@@ -122,6 +154,20 @@ static void chain(const Bufs& b, int flags, hipStream_t s, int step) {
   hipLaunchKernelGGL(touch_kernel, grid, block, 0, s, b.scratch, b.n_scratch, 3.0f);   // leave the scratch dirty
 }
 
+// Eager traffic between instantiation and the replays, like a training loop's: thousands of kernel launches and runtime
+// memsets on another stream (they recycle whatever transient launch state the runtime keeps).
+static bool g_churn = false;
+static void churn(const Bufs& b) {
+  if (!g_churn) return;
+  static hipStream_t other = nullptr;
+  if (!other) CHECK(hipStreamCreateWithFlags(&other, hipStreamNonBlocking));
+  for (int i = 0; i < 4000; ++i) {
+    hipLaunchKernelGGL(touch_kernel, dim3(1), dim3(64), 0, other, b.tsrc + b.n_scratch - 64, (size_t)64, 0.25f);
+    if (i % 4 == 0) CHECK(hipMemsetAsync(b.counts + 8, 0, 16 + (i % 7), other));
+  }
+  CHECK(hipStreamSynchronize(other));
+}
+
 static double checksum(const float* dev, size_t n, hipStream_t s) {
   std::vector<float> h(n);
   CHECK(hipMemcpyAsync(h.data(), dev, n * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -133,6 +179,14 @@ static double checksum(const float* dev, size_t n, hipStream_t s) {
 
 int main(int argc, char** argv) {
   const int REPLAYS = 6;
+  for (int i = 1; i < argc; ++i)
+    if (std::strcmp(argv[i], "--churn") == 0) {
+      g_churn = true;
+      for (int j = i; j + 1 < argc; ++j) argv[j] = argv[j + 1];
+      --argc;
+      break;
+    }
+  std::printf("eager traffic between replays: %s\n", g_churn ? "yes (--churn)" : "no");
   const char* env = std::getenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE");
   std::printf("DEBUG_CLR_GRAPH_PACKET_CAPTURE=%s\n", env ? env : "(unset: runtime default)");
   Bufs b;
@@ -169,6 +223,7 @@ int main(int argc, char** argv) {
     CHECK(hipMemsetAsync(b.grad, 0, b.n_scratch * sizeof(float), s));
     CHECK(hipMemsetAsync(b.tgrad, 0, b.n_scratch * sizeof(float), s));
     CHECK(hipMemsetAsync(b.flags, 0, 2048, s));
+    churn(b);   // (its writes land before the reference pass, so both passes see the same operands)
     for (int r = 0; r < REPLAYS; ++r) {
       chain(b, v.flags, s, r);
       ref[r] = checksum(b.grad, b.n_scratch, s);
@@ -189,6 +244,7 @@ int main(int argc, char** argv) {
     CHECK(hipGraphGetNodes(graph, nullptr, &nodes));
     int first_bad = -1;
     for (int r = 0; r < REPLAYS; ++r) {
+      churn(b);
       CHECK(hipGraphLaunch(exec, s));
       got[r] = checksum(b.grad, b.n_scratch, s);
       gott[r] = checksum(b.tgrad, b.n_scratch, s);
@@ -210,6 +266,51 @@ int main(int argc, char** argv) {
     failures += (first_bad >= 0) + !b2b_ok;
     CHECK(hipGraphExecDestroy(exec));
     CHECK(hipGraphDestroy(graph));
+  }
+  // ---- long chains of dependent kernel nodes (the captured training step has ~1000 nodes, the inference frame ~170) ----
+  {
+    const int nring = 5;
+    const size_t n = (size_t)1 << 20;
+    float* ring[nring];
+    for (int i = 0; i < nring; ++i) CHECK(hipMalloc(&ring[i], n * sizeof(float)));
+    hipStream_t launch_stream;
+    CHECK(hipStreamCreateWithFlags(&launch_stream, hipStreamNonBlocking));
+    for (int pass = 0; pass < 2; ++pass)
+    for (int nodes : {64, 256, 512, 1024, 2048, 4096}) {
+      if (pass == 1 && nodes > 1024) continue;
+      g_memset_every = pass == 0 ? 0 : 100;
+      char name[32];
+      std::snprintf(name, sizeof(name), pass == 0 ? "long_chain_%d" : "long_memset_%d", nodes);
+      if (argc > 1 && std::strcmp(argv[1], name) != 0 && std::strcmp(argv[1], "long") != 0) continue;
+      std::vector<double> ref(REPLAYS);
+      CHECK(hipMemcpyAsync(ring[0], b.tsrc, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+      CHECK(hipMemsetAsync(b.grad, 0, n * sizeof(float), s));
+      for (int r = 0; r < REPLAYS; ++r) {
+        long_chain(ring, nring, n, b.grad, nodes, s);
+        ref[r] = checksum(b.grad, n, s);
+      }
+      CHECK(hipMemcpyAsync(ring[0], b.tsrc, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+      CHECK(hipMemsetAsync(b.grad, 0, n * sizeof(float), s));
+      CHECK(hipStreamSynchronize(s));
+      hipGraph_t graph;
+      hipGraphExec_t exec;
+      CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+      long_chain(ring, nring, n, b.grad, nodes, s);
+      CHECK(hipStreamEndCapture(s, &graph));
+      // like torch.cuda.CUDAGraph: instantiated with AutoFreeOnLaunch, replayed on ANOTHER stream than the capture's
+      CHECK(hipGraphInstantiateWithFlags(&exec, graph, hipGraphInstantiateFlagAutoFreeOnLaunch));
+      int first_bad = -1;
+      for (int r = 0; r < REPLAYS; ++r) {
+        churn(b);
+        CHECK(hipGraphLaunch(exec, launch_stream));
+        if (checksum(b.grad, n, launch_stream) != ref[r] && first_bad < 0) first_bad = r;
+      }
+      std::printf("%-20s replay-by-replay: %s", name, first_bad < 0 ? "equal to eager\n" : "DIVERGES");
+      if (first_bad >= 0) std::printf(" from replay %d\n", first_bad + 1);
+      failures += first_bad >= 0;
+      CHECK(hipGraphExecDestroy(exec));
+      CHECK(hipGraphDestroy(graph));
+    }
   }
   std::printf("%s\n", failures ? "FAULT REPRODUCED" : "no divergence in any variant");
   return failures ? 1 : 0;
