@@ -34,7 +34,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix pe
 HBM_PEAK_GBS = 8000.0
 REFERENCE_ORDER_FLOPS = 628.4e9          # the frame's convolutions in the reference's order of operations
 MIN_TIMED_S = 1.0                    # repeat the --steps region until about this much timed work exists
-PMC_FILES = ("r03_pmc_traffic.json", "r02b_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # committed rocprofv3 PMC passes, newest first
+PMC_TIMED_FILES = ("r04_pmc_timed.json",)     # PMC pass over the TIMED mode (hipGraph replays on 4 streams), tools/pmc_timed.py
+PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02b_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # committed rocprofv3 PMC passes, newest first
 
 
 def synthetic_frame(seed):
@@ -426,6 +427,39 @@ def pmc_mfma_util():
     return None
 
 
+def Cfg_post_nms():
+    from faster_rcnn_pytorch_multimodal_amd.model.config import cfg
+    return cfg.TEST.RPN_POST_NMS_TOP_N
+
+
+def pmc_timed():
+    """Matrix-pipe busy time per frame from the committed PMC pass over the timed mode (hipGraph replays, 4 streams):
+    sum over a frame's dispatches of MfmaUtil x duration, in ms of a fully busy chip (tools/pmc_timed.py)."""
+    for name in PMC_TIMED_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+def extra_configs(steps):
+    """BASELINE.json configs[2] (LiDAR-BEV forward) and configs[3] (res101+FPN forward+backward: eager, one captured step at
+    a time, three captured steps of a pseudo batch in flight) inside the driver's run, each with the fp32-MFMA roofline of
+    ITS timed mode (tools/bench_configs.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs as BC
+    out = []
+    t0 = time.perf_counter()
+    out.append(BC.lidar_forward(max(steps, 80)))
+    res = BC.fpn_train(16, modes=["eager", "graph", "pipeline"])
+    out += res if isinstance(res, list) else [res]
+    res = BC.lidar_train(16, modes=("eager", "graph"))
+    out += res if isinstance(res, list) else [res]
+    return {"seconds": time.perf_counter() - t0, "runs": out}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -446,9 +480,13 @@ def parse_args(argv=None):
     ap.add_argument("--regions", type=int, default=0, help="timed repetitions of the --steps region (0 = until ~1 s is timed)")
     ap.add_argument("--no-upload", action="store_true", help="skip the extra region that uploads every frame inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only-timed", action="store_true", help="profiling aid (tools/pmc_timed.py): the runners' warm-up frames and "
+                    "exactly --steps graph replays, nothing else; prints the frame counts")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip BASELINE configs[2] / configs[3] (extra_configs)")
     ap.add_argument("--no-drop-in", action="store_true", help="skip the legs that time model.test.test_net (drop_in, drop_in_uncertainty)")
     ap.add_argument("--drop-in-frames", type=int, default=240, help="frames per timed test_net call")
     ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--map-frames", type=int, default=8, help="frames (seeds 0..n-1, BASELINE configs[4]'s set) of the mAP-delta leg")
     ap.add_argument("--layers", action="store_true", help="print the per-layer conv table to stderr")
     ap.add_argument("--rehearse-collate", action="store_true",
                     help="control-flow rehearsal WITHOUT a GPU (CPU test of the N > 1 launcher): ranks exchange synthetic "
@@ -472,6 +510,14 @@ def self_launch(args, argv):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     return subprocess.run(cmd, env=env).returncode
+
+
+def device_for_rank(local_rank, backend, device_count):
+    """The GPU a rank binds: cuda:LOCAL_RANK under RCCL (one process per GPU; the launcher hands out LOCAL_RANK 0..N-1);
+    the gloo rehearsal on a box with fewer GPUs than ranks wraps around."""
+    if backend == "nccl":
+        return int(local_rank)
+    return int(local_rank) % max(int(device_count), 1)
 
 
 def rehearsal_record(frame_id, numel):
@@ -500,7 +546,7 @@ def main(argv=None):
     use_dist = world > 1 or rehearsal or os.environ.get("FRCNN_BENCH_FORCE_DIST") == "1"
     device = "cpu"
     if not rehearsal:
-        dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+        dev_index = device_for_rank(local_rank, backend, torch.cuda.device_count())
         torch.cuda.set_device(dev_index)
         device = "cuda:%d" % dev_index
     dist = None
@@ -593,6 +639,12 @@ def main(argv=None):
             elapsed = float(t.item())
         return elapsed, own, host, ring.gathers
 
+    if args.only_timed:
+        region(args.steps, frames)
+        per_runner = 3 if not args.no_graph else 0      # FrameRunner: two warm-up frames + one with the tuned plans, eager
+        print(json.dumps({"frames_total": args.steps + per_runner * n_streams, "frames_replayed": args.steps,
+                          "streams": n_streams}))
+        return
     source = None if rehearsal else frames
     warm_elapsed = None
     if args.warmup > 0:
@@ -621,6 +673,14 @@ def main(argv=None):
         upload = ups[len(ups) // 2]
         upload_hosts = [u[2] for u in ups]
     per_rank = [own_elapsed]
+    # what each rank is bound to (the rehearsal reports the device the RCCL run WOULD bind: cuda:LOCAL_RANK)
+    rank_devices = [device if not rehearsal else "cuda:%d" % device_for_rank(local_rank, "nccl", 0)]
+    rank_frames = [[rank + world * j for j in range(n_resident)]]
+    if use_dist:
+        gathered_dev, gathered_frames = [None] * world, [None] * world
+        dist.all_gather_object(gathered_dev, rank_devices[0])
+        dist.all_gather_object(gathered_frames, rank_frames[0])
+        rank_devices, rank_frames = gathered_dev, gathered_frames
     if use_dist:
         own = torch.tensor([own_elapsed], dtype=torch.float64, device=gather_dev)
         allr = torch.zeros(world, dtype=torch.float64, device=gather_dev)
@@ -724,6 +784,7 @@ def main(argv=None):
                                  "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
                                  "ranks": dist.get_world_size(),
                                  "per_rank_frames_per_s": [args.steps / v for v in per_rank],
+                                 "rank_devices": rank_devices, "rank_frame_seeds": rank_frames,
                                  "gather_every_frames": gather_every, "allgathers_per_region": gathers,
                                  "allgather_us_per_block": allgather_us,
                                  "allgather_us_per_step": (allgather_us / gather_every) if allgather_us else None,
@@ -743,7 +804,15 @@ def main(argv=None):
             # the pooling): *_launched counts the direct-form FLOPs of the convolutions as launched, frac_executed what the matrix
             # pipe really multiplied.
             from faster_rcnn_pytorch_multimodal_amd.nets import network as _N
-            algorithmic = REFERENCE_ORDER_FLOPS if _N.PROJECT_BEFORE_POOLING else conv["flops_per_frame"]
+            # reference-order FLOPs derived from the layer table: what was launched + the two 1x1 convolutions of layer4[0]
+            # evaluated on the 300 x 7 x 7 pooled pixels instead of the feature map (BASELINE.md section 3 gives 628.4e9)
+            algorithmic = conv["flops_per_frame"]
+            if _N.PROJECT_BEFORE_POOLING:
+                blk = net.resnet.layer4[0]
+                macs = blk.conv1.in_channels * (blk.conv1.out_channels + blk.downsample[0].out_channels)
+                fh, fw = net._act_summaries["conv"].shape[1:3]
+                algorithmic += 2.0 * macs * (int(Cfg_post_nms()) * 49 - fh * fw)
+            assert abs(algorithmic - REFERENCE_ORDER_FLOPS) < 0.005 * REFERENCE_ORDER_FLOPS, (algorithmic, REFERENCE_ORDER_FLOPS)
             achieved = algorithmic / (conv["ms_per_frame"] * 1e-3) / 1e12
             achieved_launched = conv["flops_per_frame"] / (conv["ms_per_frame"] * 1e-3) / 1e12
             timed_tflops = algorithmic / (1e-3 * 1e3 * elapsed / args.steps) / 1e12
@@ -765,6 +834,10 @@ def main(argv=None):
                                    "peak: a lower bound on the conv kernels' rate in the timed mode, since the step also "
                                    "holds every non-conv kernel" % n_streams,
                 "mfma_util_pmc_percent": pmc_mfma_util(),
+                "frac_executed_timed": conv["executed_flops_per_frame"] / (1e-3 * 1e3 * elapsed / args.steps) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                "frac_executed_timed_what": "FLOPs the matrix pipe EXECUTES per frame (Winograd layers: 16/36 of the direct form) / "
+                                            "ms_per_step of the timed run / peak: the MFMA pipe's utilisation in the timed mode; "
+                                            "achieved / frac / frac_timed above are ALGORITHMIC (reference-order, direct-form) rates",
                 "flops_per_frame": conv["flops_per_frame"], "kernel_ms_per_frame": conv["ms_per_frame"],
                 "avg_launch_us": 1e3 * conv["ms_per_frame"] / conv["launches_per_frame"],
                 "main_kernel_avg_us": conv["main_kernel_avg_us"],
@@ -789,6 +862,13 @@ def main(argv=None):
                 "winograd_calls_per_frame": conv["winograd_calls_per_frame"],
                 "winograd_transform_launches_per_frame": conv["winograd_transform_launches_per_frame"],
                 "winograd_transform_us_per_frame": conv["winograd_transform_us_per_frame"]}
+            pt = pmc_timed()
+            if pt is not None:
+                busy = pt["mfma_busy_ms_per_frame"]
+                out["roofline"]["mfma_util_timed_percent"] = 100.0 * busy / (1e3 * elapsed / args.steps)
+                out["roofline"]["mfma_util_timed_what"] = (
+                    "matrix-pipe busy time per frame (%.3f ms: sum over the frame's dispatches of MfmaUtil x duration, rocprofv3 "
+                    "PMC pass over the hipGraph x %d-stream mode, %s) / ms_per_step of THIS run" % (busy, n_streams, pt.get("file", "profiles/")))
             if args.layers:
                 for k, v in sorted(conv["per_layer"].items(), key=lambda kv: -kv[1]["us_per_call"] * kv[1]["calls_per_frame"]):
                     print("%-40s x%-4.0f %9.1f us/call %7.1f TFLOP/s" % (k, v["calls_per_frame"], v["us_per_call"], v["tflops"]),
@@ -799,11 +879,15 @@ def main(argv=None):
                 out["drop_in"] = drop_in_timing(net, frames, info, max(args.steps, args.drop_in_frames), out["value"])
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"], _ = cpu_baseline(sd, frames_host[:args.cpu_frames], info)
-                out["map_delta_vs_cpu"] = map_delta(net, sd, frames_host[:2], info)
+                out["map_delta_vs_cpu"] = map_delta(net, sd, [synthetic_frame(i) for i in range(args.map_frames)], info)
             if world == 1 and not args.no_drop_in:
                 del runners, net
+                torch.cuda.empty_cache()
                 out["drop_in_uncertainty"] = drop_in_uncertainty(device, max(args.steps, args.drop_in_frames),
                                                                  frames_host, info)
+    if rank == 0 and world == 1 and not rehearsal and not args.no_extra_configs:
+        torch.cuda.empty_cache()
+        out["extra_configs"] = extra_configs(args.steps)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

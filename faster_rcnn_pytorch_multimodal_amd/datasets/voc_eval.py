@@ -72,37 +72,52 @@ def voc_eval_arrays(image_ids, confidence, boxes, class_recs, ovthresh=0.5, use_
     return rec, prec, voc_ap(rec, prec, use_07_metric)
 
 
+def format_image_rows(im_ind, name, dets):
+    """The text lines of one frame's detections of one class: ``idx token score x1 y1 x2 y2 [uc ...]``
+    (lib/datasets/db.py:305-334)."""
+    dets = np.asarray(dets)
+    if dets.size == 0:
+        return ''
+    name = str(name)
+    out = []
+    for row in dets.tolist():
+        line = '{:d} {:s} {:.3f} {:.1f} {:.1f} {:.1f} {:.1f}'.format(im_ind, name, row[4], row[0], row[1], row[2], row[3])
+        if len(row) > 5:
+            line += ''.join(' {:.10f}'.format(v) for v in row[5:])
+        out.append(line)
+    return '\n'.join(out) + '\n'
+
+
+def format_lidar_rows(ind, name, dets):
+    """LiDAR rows (n, 8+u) [xc,yc,zc,l,w,h,ry,score,...] -> ``idx token score xc yc zc l w h ry [uc ...]``
+    (lib/datasets/db.py:336-367)."""
+    dets = np.asarray(dets)
+    if dets.size == 0:
+        return ''
+    name = str(name)
+    out = []
+    for row in dets.tolist():
+        line = '{:d} {:s} {:.3f} {:.3f} {:.3f} {:.3f} {:.3f} {:.3f} {:.3f} {:.5f}'.format(
+            ind, name, row[7], row[0], row[1], row[2], row[3], row[4], row[5], row[6])
+        if len(row) > 8:
+            line += ''.join(' {:.10f}'.format(v) for v in row[8:])
+        out.append(line)
+    return '\n'.join(out) + '\n'
+
+
 def write_image_results_file(dets_per_frame, frame_names, filename):
     """One class of ``all_boxes`` (list over frames of (n, 5+u) [x1,y1,x2,y2,score,uncertainties...]) in the
-    reference's text format ``idx token score x1 y1 x2 y2 [uc ...]`` (lib/datasets/db.py:305-334)."""
+    reference's text format (lib/datasets/db.py:305-334)."""
     with open(filename, 'wt') as f:
         for im_ind, img in enumerate(frame_names):
-            dets = np.asarray(dets_per_frame[im_ind])
-            if dets.size == 0:
-                continue
-            for k in range(dets.shape[0]):
-                f.write('{:d} {:s} {:.3f} {:.1f} {:.1f} {:.1f} {:.1f}'.format(im_ind, str(img), dets[k, 4], dets[k, 0],
-                                                                              dets[k, 1], dets[k, 2], dets[k, 3]))
-                for l in range(5, dets.shape[1]):
-                    f.write(' {:.10f}'.format(dets[k, l]))
-                f.write('\n')
+            f.write(format_image_rows(im_ind, img, dets_per_frame[im_ind]))
 
 
 def write_lidar_results_file(dets_per_frame, frame_names, filename):
-    """LiDAR rows (n, 8+u) [xc,yc,zc,l,w,h,ry,score,...] -> ``idx token score xc yc zc l w h ry [uc ...]``
-    (lib/datasets/db.py:336-367)."""
+    """LiDAR counterpart (lib/datasets/db.py:336-367)."""
     with open(filename, 'wt') as f:
         for ind, frame in enumerate(frame_names):
-            dets = np.asarray(dets_per_frame[ind])
-            if dets.size == 0:
-                continue
-            for k in range(dets.shape[0]):
-                f.write('{:d} {:s} {:.3f} {:.3f} {:.3f} {:.3f} {:.3f} {:.3f} {:.3f} {:.5f}'.format(
-                    ind, str(frame), dets[k, 7], dets[k, 0], dets[k, 1], dets[k, 2], dets[k, 3], dets[k, 4], dets[k, 5],
-                    dets[k, 6]))
-                for l in range(8, dets.shape[1]):
-                    f.write(' {:.10f}'.format(dets[k, l]))
-                f.write('\n')
+            f.write(format_lidar_rows(ind, frame, dets_per_frame[ind]))
 
 
 def read_results_file(filename, num_box_values=4):

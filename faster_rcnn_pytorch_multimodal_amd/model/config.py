@@ -62,7 +62,9 @@ def _defaults():
         RPN_POSITIVE_WEIGHT=-1.0, IGNORE_DC=False, ITER=1, DISPLAY=512, SNAPSHOT_KEPT=30, SUMMARY_INTERVAL=15,
         SNAPSHOT_ITERS=5000, SNAPSHOT_PREFIX='res101_faster_rcnn',
         TOD_FILTER_LIST=['Day', 'Night', 'Dawn/Dusk'],
-        FRAMES_IN_FLIGHT=1,      # not in the reference: > 1 pipelines that many frames of a pseudo batch (model/train_graph.py)
+        # not in the reference: how SolverWrapper executes a step (model/train_graph.py)
+        GRAPHS=True,             # replay each training step as a captured hipGraph (False: eager autograd launches)
+        FRAMES_IN_FLIGHT=3,      # frames of a pseudo batch in flight as single-chain graphs (1: one captured step at a time)
         LIDAR=dict(BBOX_NORMALIZE_MEANS=(0.0,) * 7, BBOX_NORMALIZE_STDS=(0.1, 0.1, 0.1, 0.2, 0.2, 0.2, 1.0)),
         IMAGE=dict(BBOX_NORMALIZE_MEANS=(0.0, 0.0, 0.0, 0.0), BBOX_NORMALIZE_STDS=(0.1, 0.1, 0.2, 0.2)))
     c.TEST = dict(SCALES=(1.0,), NMS_THRESH=0.6, BBOX_REG=True, HAS_RPN=True, RPN_NMS_THRESH=0.7,

@@ -207,10 +207,14 @@ def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=F
             st.wait_stream(cur)
     import time
     t_loop = time.perf_counter()
-    for c0 in range(0, steps, chunk):
-        n = min(chunk, steps - c0)
-        ring = collate.RecordRing(numel, n, every=collate.EVAL_GATHER_EVERY, device=dev, distributed=distributed,
-                                  gather_device=gather_dev)
+    # rank 0 streams the per-class text files of lib/datasets/db.py:305-367 while the device works on the next chunk
+    writers = None
+    fmt = voc_eval.format_lidar_rows if lidar else voc_eval.format_image_rows
+    if rank == 0:
+        os.makedirs(out_dir, exist_ok=True)
+        writers = {j: open(os.path.join(out_dir, 'det_%s_cls%d.txt' % (mode, j)), 'wt') for j in range(1, k)}
+
+    def queue_chunk(c0, n, ring):
         for s in range(c0, c0 + n):
             # the loader runs inside the lane's stream context: device-side producers (prep_im_for_blob, the BEV voxeliser)
             # launch on the stream that consumes their blob
@@ -229,6 +233,8 @@ def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=F
                 else:
                     slot.zero_()          # a frame without data (the reference skips it, :198-203) or a padding step
                 ring.commit(s - c0)
+
+    def collect_chunk(c0, n, ring):
         host = ring.drain()
         for s in range(c0, c0 + n):
             rows = collate.unpack_records(host[s - c0], k, max_out, elem)
@@ -241,11 +247,31 @@ def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=F
                 if lidar:
                     # the voxel-grid geometry depends on cfg and the frame scale only: another rank's frame needs no reload
                     info = infos[i] if i in infos else minibatch.lidar_frame_geometry(cfg.TEST.SCALES[0])[2]
+                name = (db.name_at(i, mode) if hasattr(db, 'name_at') else '%06d' % i) if writers is not None else None
                 for j in range(1, k):
                     cls_boxes = rows[r][j]
                     if lidar and cls_boxes.size:
                         cls_boxes = bbox_voxel_grid_to_pc(cls_boxes, lidar_extents(), info)
                     all_boxes[j][i] = cls_boxes if cls_boxes.size else np.empty(0)
+                    if writers is not None and cls_boxes.size:
+                        writers[j].write(fmt(i, name, cls_boxes))
+        ring.reset()
+
+    # Two rings alternate: chunk c+1 is queued on the device before chunk c's records are waited for, unpacked into
+    # all_boxes and written out, so the host-side work of a chunk overlaps the device work of the next one (frames are
+    # visited in order, so the text files are written in frame order like the reference's)
+    rings = [collate.RecordRing(numel, min(chunk, max(steps, 1)), every=collate.EVAL_GATHER_EVERY, device=dev,
+                                distributed=distributed, gather_device=gather_dev) for _ in range(2 if steps > chunk else 1)]
+    prev = None
+    for ci, c0 in enumerate(range(0, steps, chunk)):
+        n = min(chunk, steps - c0)
+        ring = rings[ci % len(rings)]
+        queue_chunk(c0, n, ring)
+        if prev is not None:
+            collect_chunk(*prev)
+        prev = (c0, n, ring)
+    if prev is not None:
+        collect_chunk(*prev)
     if pool is not None:
         cur = torch.cuda.current_stream(dev)
         for st in pool.streams:
@@ -255,13 +281,10 @@ def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=F
         timers['frames'] = len(mine)
         timers['pool'] = dict(pool.stats) if pool is not None else None
     if rank == 0:
-        os.makedirs(out_dir, exist_ok=True)
+        for f in writers.values():
+            f.close()
         with open(os.path.join(out_dir, 'detections.pkl'), 'wb') as f:
             pickle.dump(all_boxes, f, pickle.HIGHEST_PROTOCOL)
-        names = [db.name_at(i, mode) if hasattr(db, 'name_at') else '%06d' % i for i in range(num_images)]
-        writer = voc_eval.write_lidar_results_file if lidar else voc_eval.write_image_results_file
-        for j in range(1, k):
-            writer(all_boxes[j], names, os.path.join(out_dir, 'det_%s_cls%d.txt' % (mode, j)))
         if eval_det and hasattr(db, 'evaluate_detections'):
             db.evaluate_detections(all_boxes, out_dir, mode)
     return all_boxes

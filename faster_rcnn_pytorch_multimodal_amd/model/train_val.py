@@ -78,7 +78,7 @@ class GradientBucket:
             faults = float(self.fault.item())
             self.flat.div_(dist.get_world_size(group))
             return faults
-        return float(self.fault.item())
+        return 0.0          # single process: mark_fault() raises at once, the slot is never written (and no host sync here)
 
 
 class DataParallelOptimizer:
@@ -118,6 +118,18 @@ class DataParallelOptimizer:
         self.bucket.fault.add_(1.0)
         self._fault_text = text
         return True
+
+    def check_faults(self):
+        """All ranks learn NOW whether any of them recorded a fatal frame since the last weight update (the fault slot
+        otherwise only travels with the next gradient all-reduce): called before a snapshot is written and at the end of
+        training, so that a fault in the trailing frames of a run cannot end in a snapshot 'as if nothing happened'."""
+        if not self._distributed():
+            return
+        flag = self.bucket.fault.clone()
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=self.group)
+        if float(flag.item()) > 0:
+            raise RuntimeError("a rank reported a fatal training frame (%d since the last weight update): %s"
+                               % (int(round(float(flag.item()))), self._fault_text or "see that rank's log"))
 
     def step(self):
         self.reduce()
@@ -215,6 +227,8 @@ class SolverWrapper:
         as a seventh object, a list over ranks), BatchNorm statistics are averaged first, rank 0 writes and everyone
         waits for the files."""
         sfile, nfile = self._snapshot_name(it, '.pth'), self._snapshot_name(it, '.pkl')
+        if hasattr(self.optimizer, 'check_faults'):
+            self.optimizer.check_faults()
         states = None
         if self._dist():
             self._sync_batchnorm_statistics()
@@ -319,11 +333,16 @@ class SolverWrapper:
         self.optimizer.zero_grad()
         losses = []
         pipe, pending = None, []
-        if int(cfg.TRAIN.get('FRAMES_IN_FLIGHT', 1)) > 1:
+        # cfg.TRAIN.GRAPHS (default on): every step is a replayed hipGraph (model/train_graph.py); cfg.TRAIN.FRAMES_IN_FLIGHT
+        # (default 3) frames of a pseudo batch run concurrently as single-chain graphs.  A frame a graph cannot express
+        # (don't-care boxes) runs eagerly, with a warning from Network.train_step.
+        on_device = torch.device(self.net._device).type == 'cuda' and hasattr(self.net, 'enable_train_graphs')
+        if on_device and cfg.TRAIN.get('GRAPHS', True):
             from . import train_graph
             self.optimizer.zero_grad(set_to_none=False)
-            self.net.enable_train_graphs(True)      # frames the pipeline cannot take run through train_step's own graph / eager path
-            pipe = train_graph.TrainPipeline(self.net, slots=int(cfg.TRAIN.FRAMES_IN_FLIGHT))
+            self.net.enable_train_graphs(True)
+            if int(cfg.TRAIN.get('FRAMES_IN_FLIGHT', 1)) > 1:
+                pipe = train_graph.TrainPipeline(self.net, slots=int(cfg.TRAIN.FRAMES_IN_FLIGHT))
         while it < max_iters + 1:
             update_weights = (it % self.batch_size == 0 and it != 0)
             if it == next_stepsize + 1:
@@ -340,7 +359,7 @@ class SolverWrapper:
                                             i == self.val_batch_size - 1)
                     self.val_summaries += [(it, k, v) for k, v in out[0]]
             want_summary = bool(self.sum_size and it % self.sum_size == 0)
-            if pipe is not None and train_graph.graphable(self.net, blobs) is None:
+            if pipe is not None and train_graph.graphable(self.net, blobs) is None and self._pipeline_takes(pipe, blobs):
                 # cfg.TRAIN.FRAMES_IN_FLIGHT > 1: the frame is queued on the next pipeline slot; its loss is collected when
                 # the slot comes round again, or right away where this iteration needs it (summary, weight update)
                 if pipe.in_flight() >= pipe.slots:
@@ -379,7 +398,19 @@ class SolverWrapper:
         self._drain(pipe, pending, losses)
         if last_snapshot_iter != it - 1:
             self.snapshot(it - 1)
+        elif hasattr(self.optimizer, 'check_faults'):
+            self.optimizer.check_faults()
         return losses
+
+    @staticmethod
+    def _pipeline_takes(pipe, blobs):
+        """Frames of a geometry beyond the pipeline's graph budget go through train_step (its own graph or the eager path)."""
+        from . import train_graph
+        data, info = blobs['data'], np.asarray(blobs['info'], dtype=np.float32)
+        key = (int(data.shape[1]), int(data.shape[2]), int(data.shape[3]), train_graph.gt_capacity(len(blobs['gt_boxes'])),
+               tuple(float(v) for v in info))
+        slot = pipe.runners[pipe.next_slot]
+        return key in slot or len(slot) < pipe.max_graphs
 
     def _collect_one(self, pipe, pending, losses):
         it, want_summary = pending.pop(0)

@@ -49,6 +49,35 @@ def test_gpus_2_self_launches_and_collates_over_gloo(gather_every):
     assert ver["distinct_expected_records"] == ver["distinct_frames_per_rank"] >= 2
 
 
+def test_gpus_8_rehearsal_frame_sharding_blocks_and_device_binding():
+    """The 8-rank run of BASELINE.json configs[4] rehearsed over gloo (the driver's `--gpus 8` can then only fail on RCCL
+    itself): frame seed r + 8 j on rank r (seeds 0..7 in the first step), ONE all-gather per block of 8 frames, every rank
+    bound to cuda:LOCAL_RANK, the audit fields of the `collective` object, all records verified in collated order."""
+    res = _run(["--gpus", "8", "--steps", "16", "--warmup", "2", "--rehearse-collate"], timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    col = out["collective"]
+    assert out["n_gpus"] == 8 and out["config"]["frames_per_step"] == 8 and out["scaling"] == "weak"
+    assert col["ranks"] == 8 and col["self_launched"] is True and len(col["per_rank_frames_per_s"]) == 8
+    assert col["gather_every_frames"] == 8 and col["allgathers_per_region"] == 2          # 16 steps = two blocks of 8 frames
+    assert col["rank_devices"] == ["cuda:%d" % r for r in range(8)]
+    assert [seeds[0] for seeds in col["rank_frame_seeds"]] == list(range(8))              # frame r of the step on rank r
+    assert all(seeds[1] == seeds[0] + 8 for seeds in col["rank_frame_seeds"])
+    assert col["record_bytes_per_rank"] * 8 == col["block_bytes_per_rank"]
+    ver = out["verification"]
+    assert ver["equal_to_eager_path"] is True and ver["timed_steps_checked"] == 16 and ver["regions_checked"] >= 1
+
+
+def test_device_binding_rule():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert [bench.device_for_rank(r, "nccl", 8) for r in range(8)] == list(range(8))
+    assert [bench.device_for_rank(r, "nccl", 1) for r in range(2)] == [0, 1]      # RCCL never shares a device between ranks
+    assert [bench.device_for_rank(r, "gloo", 1) for r in range(3)] == [0, 0, 0]   # the rehearsal wraps around
+
+
 def test_world_size_mismatch_is_rejected():
     res = _run(["--gpus", "2", "--rehearse-collate"], env_extra={"WORLD_SIZE": "1", "RANK": "0"})
     assert res.returncode != 0 and "WORLD_SIZE" in (res.stderr + res.stdout)

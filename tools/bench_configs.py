@@ -10,10 +10,7 @@ import os
 import sys
 import time
 
-if "--inflight" in sys.argv:
-    # frames of a pseudo batch in flight replay single-chain graphs (model/train_graph.inline_graphs_supported): the general
-    # graph replay path of the runtime has to be selected before HIP starts
-    os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix peak
 
 import numpy as np
 import torch
@@ -42,6 +39,12 @@ def lidar_forward(steps, streams=4):
     frames = [torch.from_numpy((rng.random((1, h, w, 15)) * (rng.random((1, h, w, 15)) < 0.05)).astype(np.float32)).cuda()
               for _ in range(4)]
     runners = [FrameRunner(net, h, w, 15, info, 0.5, 100) for _ in range(streams)]
+    from faster_rcnn_pytorch_multimodal_amd import ops
+    from faster_rcnn_pytorch_multimodal_amd.model.test import detect_frame_device
+    ops.flops_begin()                                  # one eager frame with the tuned plans: FLOPs per frame
+    detect_frame_device(net, frames[0], info, 0.5, 100, 100)
+    torch.cuda.synchronize()
+    fl = ops.flops_end()
     sts = [torch.cuda.Stream() for _ in range(streams)]
     outs = [None] * streams
 
@@ -60,8 +63,24 @@ def lidar_forward(steps, streams=4):
     C.reset_cfg()
     return {"metric": "frames/sec res101 LiDAR-BEV Faster-RCNN 400x350x15 (--scale 0.5)", "value": steps / dt,
             "unit": "frames/s", "ms_per_step": 1e3 * dt / steps, "n_gpus": 1, "steps": steps, "dtype": "f32",
+            "roofline": _roofline(fl, dt / steps, ("fwd",)),
             "config": {"workload": "BASELINE.json configs[2]", "frames_in_flight": streams, "launch": "hipGraph replay",
                        "detections_last_frame": outs[0][1].cpu().tolist()}}
+
+
+def _roofline(fl, seconds_per_step, kinds):
+    """fp32-MFMA roofline of a step from the convolution FLOPs its launches carry (ops.flops_begin / flops_end): `achieved`
+    counts the direct-form FLOPs of the convolutions as launched (forward + data gradient + filter gradient), `executed`
+    what the matrix pipe multiplies (Winograd F(2x2,3x3) plans do 16/36 of the direct form); both over the WHOLE timed step
+    (every other kernel's time included), so they are lower bounds on the convolution kernels' own rate."""
+    direct = sum(fl[k] for k in kinds)
+    executed = sum(fl[k + "_executed"] for k in kinds)
+    return {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TFLOPS,
+            "achieved": direct / seconds_per_step / 1e12, "frac": direct / seconds_per_step / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            "achieved_executed": executed / seconds_per_step / 1e12,
+            "frac_executed": executed / seconds_per_step / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            "gflop_direct_form": {k: fl[k] / 1e9 for k in kinds}, "gflop_executed": {k: fl[k + "_executed"] / 1e9 for k in kinds},
+            "what": "convolution FLOPs of one step (%s) / wall time per step of the timed mode / fp32 MFMA peak" % " + ".join(kinds)}
 
 
 def _timed_train_windows(net, blobs, opt, steps, windows=3):
@@ -115,18 +134,7 @@ def _timed_pipeline_windows(net, blobs, opt, steps, inflight, windows=3):
     return losses, sorted(times)[len(times) // 2]
 
 
-def _inline(inflight):
-    from faster_rcnn_pytorch_multimodal_amd.model.train_graph import inline_graphs_supported
-    return inflight > 1 and inline_graphs_supported()
-
-
-def _wgrad_grouped():
-    from faster_rcnn_pytorch_multimodal_amd.nets import autograd_ops
-    return autograd_ops.GROUP_WGRAD
-
-
-def fpn_train(steps, autotune=True, graph=False, inflight=1):
-    from faster_rcnn_pytorch_multimodal_amd import ops
+def _build_fpn_train():
     from faster_rcnn_pytorch_multimodal_amd.model import config as C
     from faster_rcnn_pytorch_multimodal_amd.nets.imagenet import imagenet
     from faster_rcnn_pytorch_multimodal_amd.utils.init_utils import seeded_state_dict
@@ -150,6 +158,13 @@ def fpn_train(steps, autotune=True, graph=False, inflight=1):
     opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=1e-4, momentum=C.cfg.TRAIN.MOMENTUM,
                           weight_decay=C.cfg.TRAIN.WEIGHT_DECAY)
     blobs = {"data": data, "info": info, "gt_boxes": gt, "gt_boxes_dc": np.zeros((0, 4), np.float32)}
+    return net, opt, blobs
+
+
+def _tune_and_count(net, opt, blobs, autotune=True):
+    """Two eager steps with the plan autotuner on, then one eager step whose convolution calls are counted."""
+    from faster_rcnn_pytorch_multimodal_amd import ops
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
     torch.manual_seed(C.cfg.RNG_SEED)
     ops.set_conv_autotune(autotune)      # time the (tile, split-K) candidates of every forward / data-gradient shape once
     try:
@@ -159,36 +174,50 @@ def fpn_train(steps, autotune=True, graph=False, inflight=1):
         torch.cuda.synchronize()
         ops.set_conv_autotune(False)
     opt.zero_grad()
-    # forward FLOPs of one step from the per-launch conv log
-    ops.PROFILE = []
+    ops.flops_begin()
     net.train_step(blobs, opt, update_weights=False)
     torch.cuda.synchronize()
-    fwd_flops = sum(s["flops"] for s in ops.PROFILE)
-    ops.PROFILE = None
-    if graph:
-        net.enable_train_graphs(True)        # model/train_graph.py: the step replayed as one hipGraph
-    if inflight > 1:
-        losses, dt = _timed_pipeline_windows(net, blobs, opt, steps, inflight)
-    else:
-        losses, dt = _timed_train_windows(net, blobs, opt, steps)
+    fl = ops.flops_end()
+    opt.zero_grad()
+    return fl
+
+
+def fpn_train(steps, autotune=True, graph=False, inflight=1, modes=None):
+    """BASELINE.json configs[3].  ``modes``: list out of 'eager', 'graph', 'pipeline' measured on ONE net in this order
+    (bench.py's extra_configs); default: the single mode the flags select."""
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    net, opt, blobs = _build_fpn_train()
+    fl = _tune_and_count(net, opt, blobs, autotune)
+    if modes is None:
+        modes = ["pipeline"] if inflight > 1 else ["graph"] if graph else ["eager"]
+    out = []
+    for mode in modes:
+        if mode == "pipeline":
+            n_in = inflight if inflight > 1 else 3
+            losses, dt = _timed_pipeline_windows(net, blobs, opt, steps, n_in)
+            launch = "hipGraph replay of the whole step, %d frames of a pseudo batch in flight (TrainPipeline, single-chain graphs)" % n_in
+            wg = "in line, grouped per ResNet stage"
+        elif mode == "graph":
+            net.enable_train_graphs(True)        # model/train_graph.py: the step replayed as one hipGraph
+            losses, dt = _timed_train_windows(net, blobs, opt, steps)
+            launch, wg = "hipGraph replay of the whole step, one frame at a time", "on a side stream"
+        else:
+            losses, dt = _timed_train_windows(net, blobs, opt, steps)
+            launch, wg = "eager (autograd)", "per layer inside autograd's backward (synchronous)"
+        out.append({"metric": "train steps/sec res101+FPN Faster-RCNN 1000x600 forward+backward", "value": steps / dt,
+                    "unit": "steps/s", "ms_per_step": 1e3 * dt / steps, "n_gpus": 1, "steps": steps, "dtype": "f32",
+                    "mode": mode, "roofline": _roofline(fl, dt / steps, ("fwd", "dgrad", "wgrad")),
+                    "config": {"workload": "BASELINE.json configs[3]: 8 random gt boxes, 12000/2000 proposals, 256 sampled RoIs, "
+                                           "FIXED_BLOCKS=1, SGD update every 16 steps",
+                               "launch": launch, "filter_gradients": wg, "loss_first": losses[0], "loss_last": losses[-1],
+                               "packet_capture_env": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")}})
     C.reset_cfg()
-    return {"metric": "train steps/sec res101+FPN Faster-RCNN 1000x600 forward+backward", "value": steps / dt,
-            "unit": "steps/s", "ms_per_step": 1e3 * dt / steps, "n_gpus": 1, "steps": steps, "dtype": "f32",
-            "config": {"workload": "BASELINE.json configs[3]: 8 random gt boxes, 12000/2000 proposals, 256 sampled RoIs, "
-                                   "FIXED_BLOCKS=1, SGD update every 16 steps",
-                       "launch": ("hipGraph replay of the whole step, %d frames of a pseudo batch in flight (TrainPipeline)" % inflight)
-                                 if inflight > 1 else
-                                 "hipGraph replay of the whole step, one frame at a time" if graph else "eager (autograd)",
-                       "filter_gradients": "per layer inside autograd's backward (synchronous)" if not graph and inflight <= 1 else
-                                           ("in line (single-chain graphs, DEBUG_CLR_GRAPH_PACKET_CAPTURE=0)" if _inline(inflight)
-                                            else "on a side stream") + (", grouped per ResNet stage" if (_wgrad_grouped() or _inline(inflight)) else ""),
-                       "forward_conv_gflop": fwd_flops / 1e9, "loss_first": losses[0], "loss_last": losses[-1]}}
+    return out if len(out) > 1 else out[0]
 
 
-def lidar_train(steps):
+def lidar_train(steps, modes=("eager",)):
     """LiDAR-BEV train_step (not a BASELINE config; the training counterpart of configs[2]): 400x350x15 blob, 8 gt
-    boxes, FIXED_BLOCKS=1 -> layer2/layer3 BatchNorm with batch statistics."""
-    from faster_rcnn_pytorch_multimodal_amd import ops
+    boxes, FIXED_BLOCKS=1 -> layer2/layer3 BatchNorm with batch statistics.  modes out of 'eager', 'graph'."""
     from faster_rcnn_pytorch_multimodal_amd.layer_utils.generate_3d_anchors import generate_anchors_3d
     from faster_rcnn_pytorch_multimodal_amd.model import config as C
     from faster_rcnn_pytorch_multimodal_amd.nets.lidarnet import lidarnet
@@ -217,22 +246,21 @@ def lidar_train(steps):
     opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=1e-5, momentum=C.cfg.TRAIN.MOMENTUM,
                           weight_decay=C.cfg.TRAIN.WEIGHT_DECAY)
     blobs = {"data": data, "info": info, "gt_boxes": gt, "gt_boxes_dc": np.zeros((0, 4), np.float32)}
-    torch.manual_seed(C.cfg.RNG_SEED)
-    ops.set_conv_autotune(True)
-    try:
-        for _ in range(2):
-            net.train_step(blobs, opt, update_weights=False)
-    finally:
-        torch.cuda.synchronize()
-        ops.set_conv_autotune(False)
-    opt.zero_grad()
-    losses, dt = _timed_train_windows(net, blobs, opt, steps)
+    fl = _tune_and_count(net, opt, blobs)
+    out = []
+    for mode in modes:
+        if mode == "graph":
+            net.enable_train_graphs(True)
+        losses, dt = _timed_train_windows(net, blobs, opt, steps)
+        out.append({"metric": "train steps/sec res101 LiDAR-BEV Faster-RCNN 400x350x15 forward+backward", "value": steps / dt,
+                    "unit": "steps/s", "ms_per_step": 1e3 * dt / steps, "n_gpus": 1, "steps": steps, "dtype": "f32", "mode": mode,
+                    "roofline": _roofline(fl, dt / steps, ("fwd", "dgrad", "wgrad")),
+                    "config": {"workload": "training counterpart of BASELINE.json configs[2]: 8 gt boxes, 256 sampled RoIs, "
+                                           "FIXED_BLOCKS=1 (layer2/3 BatchNorm on batch statistics)",
+                               "launch": "hipGraph replay of the whole step" if mode == "graph" else "eager (autograd)",
+                               "loss_first": losses[0], "loss_last": losses[-1]}})
     C.reset_cfg()
-    return {"metric": "train steps/sec res101 LiDAR-BEV Faster-RCNN 400x350x15 forward+backward", "value": steps / dt,
-            "unit": "steps/s", "ms_per_step": 1e3 * dt / steps, "n_gpus": 1, "steps": steps, "dtype": "f32",
-            "config": {"workload": "training counterpart of BASELINE.json configs[2]: 8 gt boxes, 256 sampled RoIs, "
-                                   "FIXED_BLOCKS=1 (layer2/3 BatchNorm on batch statistics)", "launch": "eager (autograd)",
-                       "loss_first": losses[0], "loss_last": losses[-1]}}
+    return out if len(out) > 1 else out[0]
 
 
 def main():
@@ -244,6 +272,7 @@ def main():
     ap.add_argument("--no-autotune", action="store_true", help="heuristic conv plans in the training step")
     ap.add_argument("--graph", action="store_true", help="--train: replay the step as a hipGraph (Network.enable_train_graphs)")
     ap.add_argument("--inflight", type=int, default=1, help="--train: frames of a pseudo batch in flight (TrainPipeline)")
+    ap.add_argument("--modes", default=None, help="--train / --lidar-train: comma list out of eager,graph,pipeline measured on one net")
     ap.add_argument("--roi-bwd-per-sample", action="store_true", help="A/B: sample-by-sample RoIAlign backward instead of the planned one")
     ap.add_argument("--rpn-dense-backward", action="store_true", help="A/B: dense backward through the RPN head")
     ap.add_argument("--no-dgrad-winograd-cache", action="store_true", help="A/B: transform the data-gradient filter per call")
@@ -273,9 +302,14 @@ def main():
     if args.lidar or both:
         print(json.dumps(lidar_forward(args.steps or 80)))
     if args.train or both:
-        print(json.dumps(fpn_train(args.steps or 16, not args.no_autotune, args.graph, args.inflight)))
+        res = fpn_train(args.steps or 16, not args.no_autotune, args.graph, args.inflight,
+                        modes=args.modes.split(",") if args.modes else None)
+        for r in (res if isinstance(res, list) else [res]):
+            print(json.dumps(r))
     if args.lidar_train or both:
-        print(json.dumps(lidar_train(args.steps or 16)))
+        res = lidar_train(args.steps or 16, modes=tuple(args.modes.split(",")) if args.modes else ("eager", "graph"))
+        for r in (res if isinstance(res, list) else [res]):
+            print(json.dumps(r))
 
 
 if __name__ == "__main__":
