@@ -134,27 +134,44 @@ def roi_align_timing(net, steps):
            "us_per_launch": us,
            "algorithmic_bytes": bytes_,
            "what": "the reference's operation: RoIAlign of the %d-channel feature map (Network._crop_pool_layer)" % c}
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return 1e3 * e0.elapsed_time(e1) / steps
+
+    # a second, trained-like RoI set: 300 seeded boxes with sides of 32..320 px inside the frame (an untrained RPN proposes
+    # frame-wide strips, the heaviest windows the op can get)
+    g = torch.Generator().manual_seed(11)
+    wh = torch.rand(rois.shape[0], 2, generator=g) * 288 + 32
+    xy = torch.rand(rois.shape[0], 2, generator=g) * (torch.tensor([float(W), float(H)]) - wh - 1)
+    typical = torch.cat((torch.zeros(rois.shape[0], 1), xy, xy + wh), 1).to(feat.device)
+    u_typ = timed(lambda: ops.roi_align_nhwc(feat, typical, 7, 1.0 / 16.0, 0))
+    out["typical_boxes"] = {"what": "300 seeded boxes with sides 32..320 px", "us_per_launch": u_typ,
+                            "achieved": bytes_ / u_typ / 1e3, "frac": bytes_ / u_typ / 1e3 / HBM_PEAK_GBS}
+    out["bound_note"] = ("every RoI reads its whole window through the vector L1 (the bench's RoIs: ~326 MB per launch against "
+                         "70 MB algorithmic); measured L2->L1 rate for this access pattern 31-33 TB/s L2-resident, 15 TB/s from "
+                         "the Infinity Cache (tools/l2_bw.hip): a per-RoI kernel bottoms out at 11-13 us + the plan launch "
+                         "(profiles/r03_roi_align.md), i.e. below the 0.60 target whatever the schedule")
     from faster_rcnn_pytorch_multimodal_amd.nets import network as N
     if N.PROJECT_BEFORE_POOLING:
-        # the timed frame pools the two projected maps instead (Network._layer4_projected): same kernels, other channel counts
-        calls = []
-        for ck, relu in ((512, True), (2048, False)):
-            g = torch.randn((1, h, w, ck), device=feat.device)
-            sc, sh = torch.rand(ck, device=feat.device) + 0.5, torch.randn(ck, device=feat.device)
-            ops.roi_align_nhwc(g, rois, 7, 1.0 / 16.0, 0, scale=sc, shift=sh, relu=relu)
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(steps):
-                ops.roi_align_nhwc(g, rois, 7, 1.0 / 16.0, 0, scale=sc, shift=sh, relu=relu)
-            e1.record()
-            torch.cuda.synchronize()
-            u = 1e3 * e0.elapsed_time(e1) / steps
-            b = h * w * ck * 4 + rois.shape[0] * 7 * 7 * ck * 4 + rois.numel() * 4 + 8 * ck
-            calls.append({"channels": ck, "us_per_launch": u, "algorithmic_bytes": b, "achieved": b / u / 1e3,
-                          "frac": b / u / 1e3 / HBM_PEAK_GBS})
-        out["in_timed_frame"] = {"what": "frcnn_roi_align_fwd_affine on layer4[0].conv1(F) (512 channels, BatchNorm + ReLU "
-                                         "epilogue) and layer4[0].downsample[0](F) (2048 channels, BatchNorm epilogue)",
-                                 "calls": calls}
+        # the timed frame pools the projected map instead (Network._layer4_projected): layer4[0].conv1 | downsample[0] as ONE
+        # 1024 -> 2560 convolution, its 512 + 2048 channels pooled through one plan (frcnn_roi_align_fwd_split)
+        ck = 2560
+        gmap = torch.randn((1, h, w, ck), device=feat.device)
+        sc, sh = torch.rand(ck, device=feat.device) + 0.5, torch.randn(ck, device=feat.device)
+        b = h * w * ck * 4 + rois.shape[0] * 7 * 7 * ck * 4 + rois.numel() * 4 + 8 * ck
+        calls = {}
+        for name, rset in (("bench_rois", rois), ("typical_boxes", typical)):
+            u = timed(lambda: ops.roi_align_split(gmap, rset, 7, 1.0 / 16.0, 512, 0, scale=sc, shift=sh, relu1=True))
+            calls[name] = {"us_per_call": u, "achieved": b / u / 1e3, "frac": b / u / 1e3 / HBM_PEAK_GBS}
+        out["in_timed_frame"] = {"what": "frcnn_roi_align_fwd_split on the 2560-channel map conv1|downsample[0](F): one plan "
+                                         "launch + two pooling launches (512 channels BatchNorm + ReLU, 2048 channels BatchNorm)",
+                                 "algorithmic_bytes": b, "calls": calls}
     return out
 
 

@@ -108,6 +108,8 @@ PROTOTYPES = {
     "frcnn_mc_bbox_var": (c_int, [_P, c_int, c_int64, _P, _P]),
     "frcnn_mc_cls_stats": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "frcnn_mc_mean": (c_int, [_P, c_int, c_int64, _P, _P]),
+    "frcnn_roi_align_fwd_split": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_float, c_int, c_int, _P, _P, _P, _P,
+                                           c_int, c_int, _P, c_size_t, _P]),
     "frcnn_set_memops_mode": (c_int, [c_int]),
     "frcnn_get_memops_mode": (c_int, []),
     "frcnn_dropout_fwd": (c_int, [_P, c_int64, c_int, c_float, c_uint32, _P, c_uint32, _P, _P]),

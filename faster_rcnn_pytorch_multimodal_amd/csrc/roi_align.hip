@@ -324,6 +324,7 @@ __global__ __launch_bounds__(64 * 2 * PLAN_P) void roi_plan_kernel(int H, int W,
 
 template <int G, bool EPI>
 __global__ __launch_bounds__(256) void roi_align_fwd_planned(const float* __restrict__ feat, int H, int W, int C4,
+                                                             int S4, int off4, int plan_slices,
                                                              int nslices, const RoiPlanHead* __restrict__ head,
                                                              const RoiItem* __restrict__ items,
                                                              const float* __restrict__ wxt, const float* __restrict__ wyt,
@@ -332,8 +333,11 @@ __global__ __launch_bounds__(256) void roi_align_fwd_planned(const float* __rest
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wpad = plan_pad(W), hpad = plan_pad(H);
+  // C4 = float4 channel groups this launch pools and writes; the map has S4 groups per pixel and the launch reads groups
+  // [off4, off4 + C4) of it (S4 == C4, off4 == 0: the whole map).  plan_slices: item descriptors per piece in the plan
+  // (== nslices when the plan was built for this launch alone, 1 for a plan shared by launches over channel sub-ranges)
   const int slice = blockIdx.x % nslices;              // this workgroup's channel slice
-  const int n_slice = head->total_items / nslices;     // items of one slice
+  const int n_slice = head->total_items / plan_slices; // items of one slice
   const int nt = n_slice * P;                          // wave-items of the slice: t -> (item t / P, column bin t % P)
   const int stride = (gridDim.x / nslices) * 4;        // waves working on the slice
   const int c4 = slice * 64 + lane;
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_planned(const float* __rest
     if (t < nt) {
       const int e = t / P;
       d.pw = t - e * P;
-      const RoiItem* it = items + (size_t)e * nslices + slice;
+      const RoiItem* it = items + (size_t)e * plan_slices + (plan_slices == 1 ? 0 : slice);
       d.r = it->r; d.sp = it->sp; d.flag = it->flag; d.y0 = it->y0; d.y1 = it->y1; d.bimg = it->bimg;
       d.inv_count = it->inv_count;
       d.xlo = it->xlo[d.pw]; d.xhi = it->xhi[d.pw];
@@ -406,11 +410,11 @@ __global__ __launch_bounds__(256) void roi_align_fwd_planned(const float* __rest
         for (int ph = 0; ph < P; ++ph) acc[ph][0] = acc[ph][1] = f32x2{0.f, 0.f};
         const int ncols_all = d.xhi - d.xlo + 1;
         if (ncols_all > 0 && d.y1 >= d.y0) {
-          const float4* fbu = reinterpret_cast<const float4*>(feat) + (size_t)d.bimg * H * W * C4;   // wave-uniform
+          const float4* fbu = reinterpret_cast<const float4*>(feat) + (size_t)d.bimg * H * W * S4 + off4;   // wave-uniform
           for (int xc = 0; xc < ncols_all; xc += 64) {           // column chunks of 64 (one weight per lane)
             const int ncols = min(64, ncols_all - xc), xlo = d.xlo + xc;
             const float wx = xc == 0 ? t_cur.wx : wxt[((size_t)d.r * P + pw) * wpad + xc + lane];
-            const int row_skip = (W - ncols) * C4;  // float4 units from the end of a window row to the next row's start
+            const int row_skip = (W - ncols) * S4;  // float4 units from the end of a window row to the next row's start
             for (int yc = d.y0 & ~63; yc <= d.y1; yc += 64) {   // aligned row chunks of 64 (one weight per lane)
               const int ys = max(yc, d.y0), ye = min(yc + 63, d.y1);
               float wy[P];
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_planned(const float* __rest
               const int total = (ye - ys + 1) * ncols;
               f32x2 T0 = {0.f, 0.f}, T1 = {0.f, 0.f};
               int cy = ys - yc, cx = 0;                 // consume cursor: row relative to yc, column relative to xlo
-              int lx = 0, loff = (ys * W + xlo) * C4;   // load cursor: column and float4 offset (wave-uniform)
+              int lx = 0, loff = (ys * W + xlo) * S4;   // load cursor: column and float4 offset (wave-uniform)
               auto consume = [&](const float4& v) {
                 const float wgt = lane_bcast(wx, cx);
                 const f32x2 w2 = {wgt, wgt};
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_planned(const float* __rest
 #pragma unroll
                 for (int k = 0; k < G; ++k) {
                   v[k] = (fbu + loff)[cl];
-                  loff += C4;
+                  loff += S4;
                   if (++lx == ncols) { lx = 0; loff += row_skip; }
                 }
 #pragma unroll
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_planned(const float* __rest
                   v[k] = zero4;
                   if (k < n) {
                     v[k] = (fbu + loff)[cl];
-                    loff += C4;
+                    loff += S4;
                     if (++lx == ncols) { lx = 0; loff += row_skip; }
                   }
                 }
@@ -970,16 +974,16 @@ extern "C" int frcnn_roi_align_fwd_affine(const float* feat, int n, int h, int w
     nwg = std::min(nwg, (max_wave_items + 3) / 4);
     nwg = std::max<long>(nslices, nwg / nslices * nslices);
     if (!g8 && !has_epi)
-      hipLaunchKernelGGL((roi_align_fwd_planned<4, false>), dim3((unsigned)nwg), dim3(256), 0, stream, feat, h, w, c4, nslices,
+      hipLaunchKernelGGL((roi_align_fwd_planned<4, false>), dim3((unsigned)nwg), dim3(256), 0, stream, feat, h, w, c4, c4, 0, nslices, nslices,
                          head, items, wxt, wyt, out, epi);
     else if (!g8)
-      hipLaunchKernelGGL((roi_align_fwd_planned<4, true>), dim3((unsigned)nwg), dim3(256), 0, stream, feat, h, w, c4, nslices,
+      hipLaunchKernelGGL((roi_align_fwd_planned<4, true>), dim3((unsigned)nwg), dim3(256), 0, stream, feat, h, w, c4, c4, 0, nslices, nslices,
                          head, items, wxt, wyt, out, epi);
     else if (!has_epi)
-      hipLaunchKernelGGL((roi_align_fwd_planned<8, false>), dim3((unsigned)nwg), dim3(256), 0, stream, feat, h, w, c4, nslices,
+      hipLaunchKernelGGL((roi_align_fwd_planned<8, false>), dim3((unsigned)nwg), dim3(256), 0, stream, feat, h, w, c4, c4, 0, nslices, nslices,
                          head, items, wxt, wyt, out, epi);
     else
-      hipLaunchKernelGGL((roi_align_fwd_planned<8, true>), dim3((unsigned)nwg), dim3(256), 0, stream, feat, h, w, c4, nslices,
+      hipLaunchKernelGGL((roi_align_fwd_planned<8, true>), dim3((unsigned)nwg), dim3(256), 0, stream, feat, h, w, c4, c4, 0, nslices, nslices,
                          head, items, wxt, wyt, out, epi);
     return frcnn::check_launch("roi_align_fwd_planned");
   }
@@ -1002,6 +1006,47 @@ extern "C" int frcnn_roi_align_fwd(const float* feat, int n, int h, int w, int c
                                    void* stream_) {
   return frcnn_roi_align_fwd_affine(feat, n, h, w, c, rois, roi_count, num_rois, rois_per_image, pooled, spatial_scale,
                                     sampling_ratio, level_of_roi, level, out, nullptr, nullptr, 0, ws, ws_bytes, stream_);
+}
+
+// RoIAlign of ONE map into TWO outputs over channel ranges, through ONE plan: out1 = act1(pool(feat[..., :split_c]) *
+// scale + shift), out2 = act2(pool(feat[..., split_c:]) * scale + shift) (scale / shift index the map's channels).  The
+// inference path pools layer4[0]'s two projections this way (Network._layer4_projected: conv1 and downsample[0] run as one
+// 1024 -> 512 + 2048 convolution; 512 channels with BatchNorm + ReLU, 2048 with BatchNorm).  One plan launch instead of two;
+// the pooling stays two launches because a workgroup's channel slice is bound to its XCD (blockIdx % 8): 2 and 8 slices of
+// 256 channels keep each XCD on one slice of the map (L2-resident), 10 slices in one launch would put the whole 24.5 MB
+// map through every 4 MB L2.  ws: frcnn_roi_align_fwd_ws_bytes(h, w, 4, num_rois, 7) (one descriptor per piece).
+extern "C" int frcnn_roi_align_fwd_split(const float* feat, int h, int w, int c, const float* rois, const int* roi_count,
+                                         int num_rois, int pooled, float spatial_scale, int sampling_ratio, int split_c,
+                                         float* out1, float* out2, const float* scale, const float* shift, int relu1,
+                                         int relu2, void* ws, size_t ws_bytes, void* stream_) {
+  FRCNN_REQUIRE(feat && rois && out1 && out2 && h > 0 && w > 0 && c > 0 && num_rois > 0 && planned_ok(pooled) &&
+                    split_c > 0 && split_c < c && split_c % 256 == 0 && (c - split_c) % 4 == 0,
+                "roi_align_fwd_split: bad arguments (pooled 7, 0 < split_c < c, split_c %% 256 == 0, c %% 4 == 0)");
+  if (!ws || ws_bytes < plan_bytes(h, w, 4, num_rois))
+    return frcnn::fail(FRCNN_ERR_WS, "roi_align_fwd_split: workspace %zu < %zu bytes", ws_bytes, plan_bytes(h, w, 4, num_rois));
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  RoiPlanHead* head = static_cast<RoiPlanHead*>(ws);
+  RoiItem* items = reinterpret_cast<RoiItem*>(head + 1);
+  float* wxt = reinterpret_cast<float*>(items + (size_t)num_rois * PLAN_P);
+  float* wyt = wxt + (size_t)num_rois * PLAN_P * plan_pad(w);
+  hipLaunchKernelGGL(roi_plan_kernel, dim3((unsigned)num_rois), dim3(64 * 2 * PLAN_P), 0, stream, h, w, rois, roi_count,
+                     num_rois, spatial_scale, sampling_ratio, (const int*)nullptr, -1, 1, g_roi_heavy_loads, head, items, wxt, wyt);
+  int rc = frcnn::check_launch("roi_plan_kernel");
+  if (rc != FRCNN_OK) return rc;
+  const int s4 = c / 4;
+  for (int part = 0; part < 2; ++part) {
+    const int off4 = part == 0 ? 0 : split_c / 4, c4 = part == 0 ? split_c / 4 : s4 - split_c / 4;
+    const int nslices = (c4 + 63) / 64;
+    const RoiEpilogue epi{scale ? scale + 4 * off4 : nullptr, shift ? shift + 4 * off4 : nullptr, part == 0 ? relu1 : relu2};
+    const long max_wave_items = (long)num_rois * nslices * PLAN_P * PLAN_P;
+    long nwg = std::min<long>(256 * 4, (max_wave_items + 3) / 4);
+    nwg = std::max<long>(nslices, nwg / nslices * nslices);
+    hipLaunchKernelGGL((roi_align_fwd_planned<4, true>), dim3((unsigned)nwg), dim3(256), 0, stream, feat, h, w, c4, s4, off4, 1,
+                       nslices, head, items, wxt, wyt, part == 0 ? out1 : out2, epi);
+    rc = frcnn::check_launch("roi_align_fwd_planned");
+    if (rc != FRCNN_OK) return rc;
+  }
+  return FRCNN_OK;
 }
 
 // Backward through the plan (see roi_align_bwd_planned): dfeat (n,H,W,C) += scatter(dout (R,P,P,C)); dfeat is zero-filled

@@ -102,6 +102,23 @@ def prepared_conv(conv, bn=None, use_bn=True):
                         refresh=lambda: prepared_conv(conv, bn, use_bn))
 
 
+def prepared_conv_concat(owner, cache_name, parts):
+    """Several convolutions that read the SAME input with the same geometry as ONE: ``parts`` = [(conv, bn, use_bn), ...] ->
+    (w_krsc (K1 + K2 + .., R, S, C), scale (K,), shift (K,)) with the folded BatchNorm terms concatenated (1 / 0 where a
+    part has none).  Cached on ``owner`` in storage-stable tensors like every derived weight (captured frames read them by
+    address); the entry's name must contain '_fused_cache' so that refresh_derived_weights visits it after the parts."""
+    prepared = [prepared_conv(c, b, u) for c, b, u in parts]
+    key = tuple((t.data_ptr(), t._version) if t is not None else None for p in prepared for t in p)
+    cache = owner.__dict__.get(cache_name)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    with torch.no_grad():
+        w = torch.cat([p[0] for p in prepared], 0).contiguous()
+        scale = torch.cat([p[1] if p[1] is not None else torch.ones(p[0].shape[0], device=w.device) for p in prepared]).contiguous()
+        shift = torch.cat([p[2] if p[2] is not None else torch.zeros(p[0].shape[0], device=w.device) for p in prepared]).contiguous()
+    return stable_store(owner, cache_name, key, (w, scale, shift), refresh=lambda: prepared_conv_concat(owner, cache_name, parts))
+
+
 def conv_bn_act(x, conv, bn=None, relu=False, residual=None, use_bn=True):
     """NHWC in, NHWC out: act(bn(conv(x)) + residual) on the fp32 matrix cores."""
     if bn is not None and use_bn and bn.training:

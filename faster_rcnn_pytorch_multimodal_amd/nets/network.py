@@ -37,12 +37,15 @@ from . import autograd_ops
 from . import uncertainty
 from .autograd_ops import (_Holder, conv_bn_act_train, conv_on_patches_train, det_loss_train, fused_head_train, fused_head_weights, linear_train,
                            roi_align_train, rpn_loss_train, spatial_mean_train)
-from .hip_modules import conv_bn_act, pad4, prepared_conv, to_nchw_view, to_nhwc
+from .hip_modules import conv_bn_act, pad4, prepared_conv, prepared_conv_concat, to_nchw_view, to_nhwc
 
 ROI_ALIGN_SAMPLING_RATIO = 0
 # inference runs layer4[0]'s input-side 1x1 convolutions on the feature map, before the RoIAlign (Network._layer4_projected);
 # False: the reference's order of operations (pool, then convolve 300 x 7 x 7 pixels)
 PROJECT_BEFORE_POOLING = True
+# ... as ONE 1x1 convolution with concatenated filters, pooled through ONE RoIAlign plan (frcnn_roi_align_fwd_split);
+# False: two convolutions and two complete RoIAlign calls (round 3)
+FUSE_PROJECTIONS = True
 # training runs the RPN's differentiable pass on the pixels that carry a labelled anchor only (Network._rpn_losses_on_labelled_pixels);
 # False: dense backward through the whole RPN head
 RPN_BACKWARD_ON_LABELLED_PIXELS = True
@@ -461,10 +464,17 @@ class Network(nn.Module):
         rois = rois.contiguous()
         count = self._predictions.get('rois_count')
         scale = 1.0 / self._feat_stride
-        a1 = ops.roi_align_nhwc(ops.conv2d_nhwc(x, w1), rois, cfg.POOLING_SIZE, scale, ROI_ALIGN_SAMPLING_RATIO,
-                                roi_count=count, scale=s1, shift=b1, relu=True)
-        identity = ops.roi_align_nhwc(ops.conv2d_nhwc(x, wd), rois, cfg.POOLING_SIZE, scale, ROI_ALIGN_SAMPLING_RATIO,
-                                      roi_count=count, scale=sd, shift=bd, relu=False)
+        if FUSE_PROJECTIONS and w1.shape[0] % 256 == 0 and cfg.POOLING_SIZE == 7:
+            wc, sc, bc = prepared_conv_concat(blk, '_fused_cache_l4proj', [(blk.conv1, blk.bn1, bn),
+                                                                           (blk.downsample[0], blk.downsample[1], True)])
+            a1, identity = ops.roi_align_split(ops.conv2d_nhwc(x, wc), rois, cfg.POOLING_SIZE, scale, w1.shape[0],
+                                               ROI_ALIGN_SAMPLING_RATIO, roi_count=count, scale=sc, shift=bc, relu1=True,
+                                               relu2=False)
+        else:
+            a1 = ops.roi_align_nhwc(ops.conv2d_nhwc(x, w1), rois, cfg.POOLING_SIZE, scale, ROI_ALIGN_SAMPLING_RATIO,
+                                    roi_count=count, scale=s1, shift=b1, relu=True)
+            identity = ops.roi_align_nhwc(ops.conv2d_nhwc(x, wd), rois, cfg.POOLING_SIZE, scale, ROI_ALIGN_SAMPLING_RATIO,
+                                          roi_count=count, scale=sd, shift=bd, relu=False)
         out = conv_bn_act(a1, blk.conv2, blk.bn2, relu=True, use_bn=bn)
         y = conv_bn_act(out, blk.conv3, blk.bn3, relu=True, residual=identity, use_bn=bn)
         for later in list(self.resnet.layer4)[1:]:

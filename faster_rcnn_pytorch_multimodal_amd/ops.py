@@ -579,6 +579,32 @@ def roi_align_nhwc(feat, rois, pooled, spatial_scale, sampling_ratio=0, roi_coun
     return out
 
 
+def roi_align_split(feat, rois, pooled, spatial_scale, split_c, sampling_ratio=0, roi_count=None, scale=None, shift=None,
+                    relu1=False, relu2=False):
+    """(out1 (R,P,P,split_c), out2 (R,P,P,C - split_c)) = RoIAlign of feat (1,H,W,C) over the two channel ranges with one
+    plan (frcnn_roi_align_fwd_split); ``scale`` / ``shift`` (C,) are applied after the pooling, ReLU per output."""
+    lib = _hip.load()
+    _dev_f32(feat, "feat"); _dev_f32(rois, "rois")
+    n, h, w, c = feat.shape
+    if n != 1 or rois.shape[1] != 5:
+        raise _hip.HipError("roi_align_split: one image, rois (R,5)")
+    for nm, t in (("scale", scale), ("shift", shift)):
+        if t is not None:
+            _dev_f32(t, nm)
+            if t.numel() != c:
+                raise _hip.HipError("roi_align_split: %s has %d elements, expected %d" % (nm, t.numel(), c))
+    r = rois.shape[0]
+    out1 = torch.empty((r, pooled, pooled, split_c), dtype=torch.float32, device=feat.device)
+    out2 = torch.empty((r, pooled, pooled, c - split_c), dtype=torch.float32, device=feat.device)
+    ws_bytes = lib.frcnn_roi_align_fwd_ws_bytes(h, w, 4, r, pooled)
+    ws = _workspace(ws_bytes, feat.device)
+    _hip.check(lib.frcnn_roi_align_fwd_split(_ptr(feat), h, w, c, _ptr(rois), _ptr(roi_count), r, pooled, float(spatial_scale),
+                                             int(sampling_ratio), int(split_c), _ptr(out1), _ptr(out2), _ptr(scale), _ptr(shift),
+                                             int(bool(relu1)), int(bool(relu2)), _ptr(ws), ws_bytes, _stream()),
+               "frcnn_roi_align_fwd_split")
+    return out1, out2
+
+
 def head_fc_softmax_decode(x, w_cls, b_cls, w_box, b_box, rois, stds, means, scale, roi_anchors_3d=None):
     """x (R,P,P,C) -> dict(fc7, cls_score, cls_prob, bbox_pred, pred_boxes).  With ``roi_anchors_3d`` (R,7) the
     boxes are the 7-DoF LiDAR boxes (frcnn_head_fc_softmax_decode_lidar), otherwise 4-DoF image boxes."""

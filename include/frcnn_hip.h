@@ -294,6 +294,15 @@ int frcnn_roi_align_fwd_affine(const float* feat, int n, int h, int w, int c, co
                                int num_rois, int rois_per_image, int pooled, float spatial_scale, int sampling_ratio,
                                const int* level_of_roi, int level, float* out, const float* scale, const float* shift,
                                int relu, void* ws, size_t ws_bytes, void* stream);
+/* One map, two outputs over the channel ranges [0, split_c) and [split_c, c), ONE plan launch: out1 (num_rois,7,7,split_c) =
+ * act1(pooled * scale + shift), out2 (num_rois,7,7,c - split_c) likewise (scale / shift: device float[c] or NULL, indexed by
+ * the MAP's channel; relu1 / relu2 0/1).  The inference path runs layer4[0].conv1 and layer4[0].downsample[0]
+ * (lib/nets/resnet.py:98-127) as one 1x1 convolution with concatenated filters and pools its 512 + 2048 channels here.
+ * split_c % 256 == 0; pooled == 7; ws: frcnn_roi_align_fwd_ws_bytes(h, w, 4, num_rois, 7). */
+int frcnn_roi_align_fwd_split(const float* feat, int h, int w, int c, const float* rois, const int* roi_count, int num_rois,
+                              int pooled, float spatial_scale, int sampling_ratio, int split_c, float* out1, float* out2,
+                              const float* scale, const float* shift, int relu1, int relu2, void* ws, size_t ws_bytes,
+                              void* stream);
 
 /* LevelMapper (lib/utils/torchpoolers.py:20-51) of MultiScaleRoIAlign: levels[i] = clamp(floor(canonical_level +
  * log2(sqrt(area_i) / canonical_scale) + eps), k_min, k_max) - k_min for rois (n,5); area without +1. */

@@ -345,3 +345,32 @@ def test_subclass_tail_is_called_in_test_mode(hip):
         assert (outs[0][1] - outs[1][1]).abs().max().item() <= 2e-5                  # class probabilities
     finally:
         C.reset_cfg()
+
+
+@pytest.mark.gpu
+def test_roi_align_split_equals_two_calls_bit_for_bit(hip):
+    """frcnn_roi_align_fwd_split (one plan, channel ranges of one map, per-range epilogue) against two complete
+    frcnn_roi_align_fwd_affine calls on the two halves: identical bits (same kernel arithmetic per channel), for the bench's
+    frame-wide RoIs, typical boxes, a live-row count below the row count, and a map whose first range is 256 channels."""
+    import torch
+    from faster_rcnn_pytorch_multimodal_amd import ops
+    g = torch.Generator().manual_seed(4)
+    for (h, w, c, split) in ((38, 63, 2560, 512), (25, 22, 768, 256)):
+        feat = torch.randn((1, h, w, c), generator=g).to(DEV)
+        sc, sh = (torch.rand(c, generator=g) + 0.5).to(DEV), torch.randn(c, generator=g).to(DEV)
+        n = 300
+        wh = torch.rand(n, 2, generator=g) * torch.tensor([w * 16.0, h * 16.0]) * 0.9 + 8
+        xy = torch.rand(n, 2, generator=g) * (torch.tensor([w * 16.0, h * 16.0]) - wh).clamp(min=0)
+        rois = torch.cat((torch.zeros(n, 1), xy, xy + wh), 1)
+        rois[::7, 1] = 0.0
+        rois[::7, 3] = w * 16.0 - 1            # frame-wide strips like an untrained RPN's
+        rois = rois.to(DEV)
+        for count in (None, torch.tensor([217], dtype=torch.int32, device=DEV)):
+            o1, o2 = ops.roi_align_split(feat, rois, 7, 1.0 / 16.0, split, 0, roi_count=count, scale=sc, shift=sh, relu1=True)
+            r1 = ops.roi_align_nhwc(feat[..., :split].contiguous(), rois, 7, 1.0 / 16.0, 0, roi_count=count, scale=sc[:split].contiguous(),
+                                    shift=sh[:split].contiguous(), relu=True)
+            r2 = ops.roi_align_nhwc(feat[..., split:].contiguous(), rois, 7, 1.0 / 16.0, 0, roi_count=count, scale=sc[split:].contiguous(),
+                                    shift=sh[split:].contiguous(), relu=False)
+            torch.cuda.synchronize()
+            assert torch.equal(o1, r1) and torch.equal(o2, r2), (h, w, c, split, count)
+            assert float(o1.min()) >= 0.0 and float(o2.min()) < 0.0
