@@ -396,6 +396,8 @@ class SolverWrapper:
                     self.remove_snapshot(np_paths, ss_paths)
             it += 1
         self._drain(pipe, pending, losses)
+        if pipe is not None:
+            pipe.flush()          # frames since the last update: their gradients leave the slots' buffers for param.grad
         if last_snapshot_iter != it - 1:
             self.snapshot(it - 1)
         elif hasattr(self.optimizer, 'check_faults'):

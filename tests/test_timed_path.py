@@ -253,22 +253,24 @@ def test_full_size_frame_on_the_nets_own_rpn_output(hip):
     away: (1) every rank whose gaps to both neighbours exceed 2 x noise holds the IDENTICAL anchor index; (2) at EVERY rank k
     the device's k-th anchor has an oracle score within 2 x noise of the oracle's k-th score (the device ranking is the
     oracle ranking up to permutations inside noise-wide score clusters); (3) the two top-6000 SETS differ only in anchors
-    whose oracle score lies within 2 x noise of the cut score.  The RPN class head is scaled x16 so that the scores spread
-    (a random-init head scores every anchor 0.5 +- 1e-3); the scaling is part of the weights both paths load.
+    whose oracle score lies within 2 x noise of the cut score.  Run twice: with the bench weights as they are (score noise must
+    meet north_star's 1e-4) and with the RPN class head scaled x16 so that the scores spread like a trained head's (a
+    random-init head scores every anchor 0.5 +- 1e-3; the scaling is part of the weights both paths load and multiplies the
+    noise of the logits with them, so the bar there is 16 x 1e-4).
     Printed: the noise, the fraction of ranks inside noise-wide clusters and the number of ranks that actually differ.  With
     6000 ranks drawn from 59 850 anchors the mean gap between neighbouring scores (~1e-5) is BELOW the fp32 noise of the
     backbone (~3e-5 on these scores), so most ranks sit in such clusters for ANY pair of fp32 implementations; exact index
     parity of the proposal stage is therefore pinned on injected logits (test_timed_path_against_cpu_oracle_structured_rpn)."""
     from faster_rcnn_pytorch_multimodal_amd.model.test import detect_frame_device
-    net, sd = bench.build_net(DEV)
-    sd = dict(sd)
-    sd["rpn_cls_score_net.weight"] = sd["rpn_cls_score_net.weight"] * 16.0
-    net.load_state_dict(sd, strict=True)
+    net, sd0 = bench.build_net(DEV)
     cpu = O.ImageNetOracle(num_classes=bench.NUM_CLASSES)
-    cpu.load_state_dict(sd, strict=True)
     top = 6000
     report = []
-    for seed in (0, 1):
+    for head_scale, seed in ((1.0, 0), (16.0, 0), (16.0, 1)):
+        sd = dict(sd0)
+        sd["rpn_cls_score_net.weight"] = sd0["rpn_cls_score_net.weight"] * head_scale
+        net.load_state_dict(sd, strict=True)
+        cpu.load_state_dict(sd, strict=True)
         f = bench.synthetic_frame(seed)
         O.frame_detect(cpu, f, INFO, bench.NUM_CLASSES, bench.THRESH, bench.MAX_DETS)
         d = cpu._dbg
@@ -282,7 +284,7 @@ def test_full_size_frame_on_the_nets_own_rpn_output(hip):
         dev_scores, dev_order = p["rpn_scores"].cpu(), p["rpn_order"].cpu()
         assert dev_scores.shape == ref_scores.shape == (59850,)
         noise = float((dev_scores - ref_scores).abs().max())
-        assert noise <= 1e-4, noise                                   # north_star: scores within 1e-4 abs
+        assert noise <= 1e-4 * head_scale, (head_scale, noise)        # north_star: scores within 1e-4 abs (bench weights)
         tau = 2.0 * noise
         s = ref_scores[full_order[:top + 1]].double()
         gap = (s[:-1] - s[1:]).numpy()                                 # gap[k] = score(rank k) - score(rank k+1) >= 0
@@ -302,9 +304,9 @@ def test_full_size_frame_on_the_nets_own_rpn_output(hip):
             assert abs(float(ref_scores[i]) - cut) <= tau, (seed, i, float(ref_scores[i]), cut, tau)
         # the device's own order is the canonical (score desc, index asc) order of ITS scores
         assert torch.equal(dev_order, O.stable_desc_order(dev_scores)[:top])
-        report.append((seed, noise, float(amb.mean()), int((~same).sum()), float(s[0] - s[top - 1]), float(gap[:top - 1].mean()),
+        report.append((head_scale, seed, noise, float(amb.mean()), int((~same).sum()), float(s[0] - s[top - 1]), float(gap[:top - 1].mean()),
                        len(ref_set ^ dev_set) // 2))
-    for seed, noise, frac, diff, spread, mean_gap, swapped in report:
-        print("own-RPN ranking, frame %d: score noise %.2e, top-%d spread %.3f (mean gap %.1e), ranks inside noise-wide "
+    for head_scale, seed, noise, frac, diff, spread, mean_gap, swapped in report:
+        print("own-RPN ranking, head x%g, frame %d: score noise %.2e, top-%d spread %.3f (mean gap %.1e), ranks inside noise-wide "
               "clusters %.1f %%, ranks that differ %d, anchors swapped across the cut %d"
-              % (seed, noise, top, spread, mean_gap, 100 * frac, diff, swapped))
+              % (head_scale, seed, noise, top, spread, mean_gap, 100 * frac, diff, swapped))
