@@ -472,7 +472,7 @@ def extra_configs(steps):
     out.append(BC.lidar_forward(max(steps, 80)))
     res = BC.fpn_train(16, modes=["eager", "graph", "pipeline"])
     out += res if isinstance(res, list) else [res]
-    res = BC.lidar_train(16, modes=("eager", "graph"))
+    res = BC.lidar_train(16, modes=("eager", "graph", "pipeline"))
     out += res if isinstance(res, list) else [res]
     return {"seconds": time.perf_counter() - t0, "runs": out}
 
@@ -855,6 +855,7 @@ def main(argv=None):
                 "frac_executed_timed_what": "FLOPs the matrix pipe EXECUTES per frame (Winograd layers: 16/36 of the direct form) / "
                                             "ms_per_step of the timed run / peak: the MFMA pipe's utilisation in the timed mode; "
                                             "achieved / frac / frac_timed above are ALGORITHMIC (reference-order, direct-form) rates",
+                "conv_calls_per_frame": int(round(conv["launches_per_frame"])),
                 "flops_per_frame": conv["flops_per_frame"], "kernel_ms_per_frame": conv["ms_per_frame"],
                 "avg_launch_us": 1e3 * conv["ms_per_frame"] / conv["launches_per_frame"],
                 "main_kernel_avg_us": conv["main_kernel_avg_us"],

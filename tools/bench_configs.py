@@ -251,13 +251,18 @@ def lidar_train(steps, modes=("eager",)):
     for mode in modes:
         if mode == "graph":
             net.enable_train_graphs(True)
-        losses, dt = _timed_train_windows(net, blobs, opt, steps)
+        if mode == "pipeline":
+            losses, dt = _timed_pipeline_windows(net, blobs, opt, steps, 3)
+        else:
+            losses, dt = _timed_train_windows(net, blobs, opt, steps)
         out.append({"metric": "train steps/sec res101 LiDAR-BEV Faster-RCNN 400x350x15 forward+backward", "value": steps / dt,
                     "unit": "steps/s", "ms_per_step": 1e3 * dt / steps, "n_gpus": 1, "steps": steps, "dtype": "f32", "mode": mode,
                     "roofline": _roofline(fl, dt / steps, ("fwd", "dgrad", "wgrad")),
                     "config": {"workload": "training counterpart of BASELINE.json configs[2]: 8 gt boxes, 256 sampled RoIs, "
                                            "FIXED_BLOCKS=1 (layer2/3 BatchNorm on batch statistics)",
-                               "launch": "hipGraph replay of the whole step" if mode == "graph" else "eager (autograd)",
+                               "launch": {"graph": "hipGraph replay of the whole step, one frame at a time",
+                                          "pipeline": "hipGraph replay, 3 frames of a pseudo batch in flight (TrainPipeline, single-chain graphs)",
+                                          "eager": "eager (autograd)"}[mode],
                                "loss_first": losses[0], "loss_last": losses[-1]}})
     C.reset_cfg()
     return out if len(out) > 1 else out[0]
@@ -307,7 +312,7 @@ def main():
         for r in (res if isinstance(res, list) else [res]):
             print(json.dumps(r))
     if args.lidar_train or both:
-        res = lidar_train(args.steps or 16, modes=tuple(args.modes.split(",")) if args.modes else ("eager", "graph"))
+        res = lidar_train(args.steps or 16, modes=tuple(args.modes.split(",")) if args.modes else ("eager", "graph", "pipeline"))
         for r in (res if isinstance(res, list) else [res]):
             print(json.dumps(r))
 

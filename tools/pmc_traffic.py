@@ -31,7 +31,7 @@ COMPANIONS = {"conv_splitk_epilogue": "conv_igemm", "wino_": "conv_igemm"}
 
 # bench.py tunes its conv plans during the first frames (extra candidate launches); its roofline is timed over the
 # LAST 5 eager frames x 106 conv launches, so the conv traffic is averaged over exactly those dispatches.
-LAST = {"conv_igemm": 5 * 106}
+LAST = {"conv_igemm": 5 * 105}      # overridden by --conv-calls=N (bench.py roofline.conv_calls_per_frame)
 
 
 def per_kernel(directory, counter):
@@ -125,6 +125,10 @@ def main(fetch_dir, write_dir, command="", mfma_dir=None):
 
 
 if __name__ == "__main__":
+    for a in sys.argv[1:]:
+        if a.startswith("--conv-calls="):
+            LAST["conv_igemm"] = 5 * int(a.split("=", 1)[1])
+    sys.argv = [a for a in sys.argv if not a.startswith("--conv-calls=")]
     args = [a for a in sys.argv[1:] if not a.startswith("--mfma=")]
     mfma = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--mfma=")]
     main(args[0], args[1], " ".join(args[2:]), mfma[0] if mfma else None)

@@ -25,7 +25,7 @@ def main(path, title=""):
         print("| `%s` | %d | %.1f | %.2f | %.2f |" % (short, calls, tot, avg, pct))
 
 
-def conv_cross_check(path, frames=5, launches_per_frame=106, flops_per_frame=563.85e9):
+def conv_cross_check(path, frames=5, launches_per_frame=105, flops_per_frame=563.85e9):
     """bench.py measures its `roofline` over its LAST `frames` eager frames (after the timed region): sum the
     conv_igemm* dispatches of exactly those frames (plus the split-K second passes that follow them) from the
     per-dispatch table, for comparison with bench.py's kernel_ms_per_frame / avg_launch_us."""
@@ -58,4 +58,8 @@ if __name__ == "__main__":
     main(args[0], " ".join(args[1:]))
     if "--conv-cross-check" in sys.argv:
         flops = [float(a.split("=", 1)[1]) for a in sys.argv[1:] if a.startswith("--flops-per-frame=")]
-        conv_cross_check(args[0], **({"flops_per_frame": flops[0]} if flops else {}))
+        calls = [int(a.split("=", 1)[1]) for a in sys.argv[1:] if a.startswith("--conv-calls=")]
+        kw = {"flops_per_frame": flops[0]} if flops else {}
+        if calls:
+            kw["launches_per_frame"] = calls[0]
+        conv_cross_check(args[0], **kw)
