@@ -172,6 +172,7 @@ class FramePool:
         self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_streams)]
         self.runners = {}             # key -> [runner or None] * streams
         self.sightings = {}           # key -> frames seen
+        self.uncapturable = set()     # problems whose capture failed: eager from then on
         self.clock = 0
         self.last_use = {}
         self.stats = {'replays': 0, 'eager': 0, 'captures': 0, 'refreshes': 0, 'invalidations': 0}
@@ -225,6 +226,9 @@ class FramePool:
         self.clock += 1
         seen = self.sightings.get(key, 0) + 1
         self.sightings[key] = seen
+        if key in self.uncapturable:
+            self.stats['eager'] += 1
+            return None
         lanes = self.runners.get(key)
         if lanes is None:
             # the very first problem of this pool is captured at first sight
@@ -243,10 +247,21 @@ class FramePool:
         if r is None:
             torch.cuda.synchronize(self.dev)      # captures happen with the device idle (no replay of another lane in flight)
             tuned = any(x is not None for ls in self.runners.values() for x in ls)
-            r = lanes[lane] = FrameRunner(self.net, key[0], key[1], key[2], np.asarray(key[3], np.float32), thresh, max_dets,
-                                          use_graph=self.use_graph, warmup=self.warmup if not tuned else 1,
-                                          autotune=self.autotune and not any(x is not None for x in lanes),
-                                          max_out=max_out, with_filter=with_filter, e_num_sample=key[8])
+            try:
+                r = lanes[lane] = FrameRunner(self.net, key[0], key[1], key[2], np.asarray(key[3], np.float32), thresh, max_dets,
+                                              use_graph=self.use_graph, warmup=self.warmup if not tuned else 1,
+                                              autotune=self.autotune and not any(x is not None for x in lanes),
+                                              max_out=max_out, with_filter=with_filter, e_num_sample=key[8])
+            except Exception as e:      # a forward that cannot be captured (a host read-back inside): this problem runs eagerly
+                import warnings
+                warnings.warn("FramePool: frames of shape %s run EAGERLY, their forward pass could not be captured: %s: %s"
+                              % (key[:3], type(e).__name__, e))
+                torch.cuda.synchronize(self.dev)
+                self.uncapturable.add(key)
+                if not any(x is not None for x in lanes):
+                    self.runners.pop(key, None)
+                self.stats['eager'] += 1
+                return None
             self.stats['captures'] += 1
             self._stamp = self._weights_stamp()   # the warm-up may have created derived tensors; versions are unchanged
         self.stats['replays'] += 1

@@ -337,6 +337,10 @@ class SolverWrapper:
         # (default 3) frames of a pseudo batch run concurrently as single-chain graphs.  A frame a graph cannot express
         # (don't-care boxes) runs eagerly, with a warning from Network.train_step.
         on_device = torch.device(self.net._device).type == 'cuda' and hasattr(self.net, 'enable_train_graphs')
+        if on_device and cfg.TEST.get('FRAME_GRAPHS', True) and self.data_gen_val is not None and self.val_sum_size:
+            # validation frames (run_eval -> test_frame, train_val.py:411-412) replay the captured forward pass too; the pool
+            # notices every weight update through the parameters' version counters and re-derives the cached filters in place
+            self.net.enable_frame_graphs(True)
         if on_device and cfg.TRAIN.get('GRAPHS', True):
             from . import train_graph
             self.optimizer.zero_grad(set_to_none=False)

@@ -165,3 +165,34 @@ def test_single_chain_capture_with_memset_nodes_is_refused(hip):
     finally:
         _hip.check(lib.frcnn_set_memops_mode(0), "frcnn_set_memops_mode")
     C.reset_cfg()
+
+
+def test_solver_validation_replays_captured_frames(hip, tmp_path):
+    """SolverWrapper with validation frames (lib/model/train_val.py:402-445): ``run_eval`` goes through the captured forward
+    pass of the frame pool, which follows the weight updates in between (refreshes > 0, no re-capture), and after training
+    the replayed forward equals the eager one at the final weights."""
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.model import train_val
+    net, _ = T._build_fpn_pair(seed=23)
+    data, info, gt, _, _ = T._fpn_case()
+    C.cfg.TRAIN.SNAPSHOT_ITERS = 1000
+    C.cfg.TRAIN.LEARNING_RATE = 1e-4
+
+    class Frames:
+        def next(self):
+            return {"data": data, "info": info, "gt_boxes": gt, "gt_boxes_dc": np.zeros((0, 4), np.float32)}
+
+    solver = train_val.SolverWrapper(net, 2, Frames(), val_frames=Frames(), output_dir=str(tmp_path), batch_size=2, sum_size=0,
+                                     val_sum_size=2, val_batch_size=2, log=lambda *_: None)
+    losses = solver.train_model(5)
+    assert len(losses) == 5 and all(np.isfinite(l) for l in losses)
+    st = net.frame_pool().stats
+    assert st["replays"] >= 4 and st["captures"] == 1 and st["refreshes"] >= 1 and st["invalidations"] == 0, st
+    assert [v for it, k, v in solver.val_summaries if k == "val_num_rois"]
+    blobs = Frames().next()
+    out_g = net.run_eval(blobs, 1, update_summaries=False)
+    net.enable_frame_graphs(False)
+    out_e = net.run_eval(blobs, 1, update_summaries=False)
+    assert torch.equal(out_g[1], out_e[1]) and torch.equal(out_g[3], out_e[3]) and torch.equal(out_g[4], out_e[4])
+    assert net.training                                             # run_eval put the module back into train() mode
+    C.reset_cfg()
