@@ -70,6 +70,10 @@ struct ConvParams {
   const float* mask;
   const float* mscale;
   const float* u_pre;   // host side: Winograd-transformed filter supplied by the caller (frcnn_conv2d_fwd_pre) or nullptr
+  // Winograd grouped GEMM with the INPUT TRANSFORM fused into the A-tile load (conv_igemm_f32<..., WINO = true>): x is the
+  // layer's NHWC input (wiH x wiW pixels, C channels), GEMM row m is the 2x2-output tile (n, ty, tx) of a wth x wtw grid and
+  // blockIdx.y the transform component
+  int wiH, wiW, wth, wtw;
 };
 
 // XCD-aware bijective remap (guide T1): blocks b and b+8 share an XCD; give each XCD a contiguous
@@ -183,8 +187,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 // every load of a tile is issued unconditionally (and the compiler can count them: partial vmcnt waits)
 __device__ float g_zero_page[64];
 
-template <int WM, int WN, int TM, int TN, bool ALIGNED>
+template <int WM, int WN, int TM, int TN, bool ALIGNED, bool WINO = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvParams p) {
+  static_assert(!WINO || ALIGNED, "the fused Winograd input transform needs C % 32 == 0");
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr int RPP = NT / 8;                // tile rows staged per pass (8 threads x 16 B cover one row)
@@ -212,10 +217,37 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
   // ---- per-thread staging geometry: thread t moves chunk kc of rows (t>>3) + RPP*i ---------------
   const int kc = t & 7, row0 = t >> 3;
   int a_base[PA], a_hi0[PA], a_wi0[PA];
+  // WINO: V[xi][tile][c] = (B^T d B)[ci][cj] of the tile's 4x4 input patch d (rows 2ty-1.., cols 2tx-1.., zero outside the
+  // map) is a signed sum of FOUR patch pixels: with B^T's rows (1,0,-1,0), (0,1,1,0), (0,-1,1,0), (0,1,0,-1) row ci combines
+  // patch rows ra, rb as d[ra] + sr d[rb] and column cj likewise, in the order wino_input_kernel evaluates them
+  // (rows first, then columns), so the fused GEMM is bit-identical to the two-launch form.
+  constexpr int WPA = WINO ? PA : 1, WQ = WINO ? 4 : 1;
+  int w_off[WPA][WQ];      // element offsets of the four pixels (-1: outside the map -> zero page)
+  float w_sr = 1.f, w_sc = 1.f;
+  if constexpr (WINO) {
+    const int xi = blockIdx.y, ci = xi >> 2, cj = xi & 3;
+    const int ra = ci == 0 ? 0 : (ci == 2 ? 2 : 1), rb = ci == 2 ? 1 : (ci == 3 ? 3 : 2);
+    const int ca = cj == 0 ? 0 : (cj == 2 ? 2 : 1), cb = cj == 2 ? 1 : (cj == 3 ? 3 : 2);
+    w_sr = ci == 1 ? 1.f : -1.f;
+    w_sc = cj == 1 ? 1.f : -1.f;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int m = m0 + i * RPP + row0;
+      const int tx = m % p.wtw, t2 = m / p.wtw;
+      const int ty = t2 % p.wth, img = t2 / p.wth;
+      const int hr[2] = {2 * ty - 1 + ra, 2 * ty - 1 + rb}, wc[2] = {2 * tx - 1 + ca, 2 * tx - 1 + cb};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {      // q = 0: (ra, ca), 1: (rb, ca), 2: (ra, cb), 3: (rb, cb)
+        const int hi = hr[q & 1], wi = wc[q >> 1];
+        const bool ok = m < p.M && (unsigned)hi < (unsigned)p.wiH && (unsigned)wi < (unsigned)p.wiW;
+        w_off[i][q] = ok ? ((img * p.wiH + hi) * p.wiW + wi) * p.C : -1;
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     const int m = m0 + i * RPP + row0;
-    if (m < p.M) {
+    if (!WINO && m < p.M) {
       const int img = m / (p.Ho * p.Wo);
       const int rem = m - img * p.Ho * p.Wo;
       const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
@@ -231,6 +263,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
 
   // two register sets: the tiles of steps s+1 and s+2 are in flight while step s computes
   f32x4 ra[2][PA], rb[2][PB];
+  f32x4 rw[2][WPA][WQ];    // WINO: the four raw pixels per A chunk stay in flight; they are combined when the tile is stored
   typedef std::integral_constant<int, 0> Set0;
   typedef std::integral_constant<int, 1> Set1;
   // tap state for the ALIGNED path (C % 32 == 0: a K-step never straddles a tap)
@@ -247,7 +280,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
   auto load_tiles = [&](int step, auto set) {
     constexpr int SL = decltype(set)::value;
     const int kflat = step * BK + kc * 4;
-    if (ALIGNED) {
+    if constexpr (WINO) {
+      const int koff = tc + kc * 4;          // R = S = 1: a K-step is a channel block
+#pragma unroll
+      for (int i = 0; i < PA; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          rw[SL][i][q] = *reinterpret_cast<const f32x4*>(w_off[i][q] >= 0 ? px + w_off[i][q] + koff : g_zero_page);
+      tc += BK;
+    } else if (ALIGNED) {
       const int koff = (tr * p.W + ts) * p.C + tc + kc * 4;
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
@@ -285,7 +326,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
     float* a = As + buf * BM * LDS_PITCH + row0 * LDS_PITCH + kc * 4;
     float* b = Bs + buf * BN * LDS_PITCH + row0 * LDS_PITCH + kc * 4;
 #pragma unroll
-    for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4*>(a + i * RPP * LDS_PITCH) = ra[SL][i];
+    for (int i = 0; i < PA; ++i) {
+      if constexpr (WINO) {
+        const f32x4 lo = rw[SL][i][0] + w_sr * rw[SL][i][1];      // r[ci][ca] = d[ra][ca] +- d[rb][ca]
+        const f32x4 hi = rw[SL][i][2] + w_sr * rw[SL][i][3];      // r[ci][cb]
+        *reinterpret_cast<f32x4*>(a + i * RPP * LDS_PITCH) = lo + w_sc * hi;
+      } else {
+        *reinterpret_cast<f32x4*>(a + i * RPP * LDS_PITCH) = ra[SL][i];
+      }
+    }
 #pragma unroll
     for (int j = 0; j < PB; ++j) *reinterpret_cast<f32x4*>(b + j * RPP * LDS_PITCH) = rb[SL][j];
   };
@@ -747,11 +796,14 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 struct Plan {
   int cfg, splits, steps_per_split;
   int algo = 0;   // 0 = implicit GEMM; 1 = Winograd F(2x2, 3x3) around a grouped GEMM that uses tile `cfg` (splits = 1)
+  int fuse_in = 0;   // algo 1 only: the input transform runs inside the 64x64 GEMM's A-tile load (cfg 5, C % 32 == 0)
 };
 bool winograd_ok(int r, int s, int stride, int pad, int c, int k, int out_stride);
 size_t winograd_ws_bytes(int n, int h, int w, int c, int k);
 // test / tuning hook: 0 = the autotuner may pick either form, 1 = implicit GEMM only, 2 = Winograd wherever it applies
 std::atomic<int> g_algo_mode{0};   // atomic: set from one thread while another may launch
+// test / tuning hook (frcnn_conv2d_set_algo bit 4): may the tuner try / forced Winograd use the fused input transform?
+std::atomic<int> g_wino_fuse{1};
 
 // test / tuning hook: force the block tile (0 = automatic choice)
 std::atomic<int> g_force_tm{0}, g_force_tn{0};
@@ -868,13 +920,13 @@ bool prof_events(int kind, hipEvent_t* e0, hipEvent_t* e1, hipStream_t stream) {
   return true;
 }
 
-template <int WM, int WN, int TM, int TN, bool ALIGNED>
+template <int WM, int WN, int TM, int TN, bool ALIGNED, bool WINO = false>
 int launch_conv(const ConvParams& p, int splits, int groups, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_PITCH * sizeof(float);
   static std::atomic<bool> configured{false};   // idempotent attribute call: a race only repeats it
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, TM, TN, ALIGNED>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, TM, TN, ALIGNED, WINO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return frcnn::fail(FRCNN_ERR_LAUNCH, "conv: set LDS size: %s", hipGetErrorString(e));
     configured = true;
@@ -882,10 +934,10 @@ int launch_conv(const ConvParams& p, int splits, int groups, hipStream_t stream)
   dim3 grid(p.tiles_m * p.tiles_n, groups, splits);
   hipEvent_t e0, e1;
   if (prof_events(0, &e0, &e1, stream))
-    hipExtLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, ALIGNED>), grid, dim3(64 * WM * WN), (uint32_t)lds, stream, e0, e1,
-                          0, p);
+    hipExtLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, ALIGNED, WINO>), grid, dim3(64 * WM * WN), (uint32_t)lds, stream, e0,
+                          e1, 0, p);
   else
-    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, ALIGNED>), grid, dim3(64 * WM * WN), lds, stream, p);
+    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, ALIGNED, WINO>), grid, dim3(64 * WM * WN), lds, stream, p);
   return frcnn::check_launch("conv_igemm_f32");
 }
 
@@ -948,8 +1000,11 @@ extern "C" int frcnn_conv2d_set_tile(int tm, int tn) {
 }
 
 extern "C" int frcnn_conv2d_set_algo(int mode) {
-  FRCNN_REQUIRE(mode >= 0 && mode <= 2, "conv2d_set_algo: mode %d (0 auto, 1 implicit GEMM only, 2 Winograd where it applies)", mode);
-  g_algo_mode = mode;
+  FRCNN_REQUIRE(mode >= 0 && (mode & 3) <= 2 && (mode & ~(3 | 16 | 32)) == 0,
+                "conv2d_set_algo: mode %d (0 auto, 1 implicit GEMM only, 2 Winograd where it applies; +16: never fuse the "
+                "Winograd input transform into the GEMM, +32: forced Winograd uses the 64x64 GEMM with the fused transform)", mode);
+  g_algo_mode = mode & 3;
+  g_wino_fuse = (mode & 16) ? 0 : ((mode & 32) ? 2 : 1);
   return FRCNN_OK;
 }
 
@@ -1031,7 +1086,7 @@ extern "C" int frcnn_conv2d_export_plans(int* out, int capacity_entries) {
   for (const auto& kv : g_plan_cache) {
     if (out && n < capacity_entries) {
       for (int i = 0; i < 10; ++i) out[n * 13 + i] = kv.first[i];
-      out[n * 13 + 10] = kv.second.cfg + 16 * kv.second.algo;
+      out[n * 13 + 10] = kv.second.cfg + 16 * (kv.second.algo + kv.second.fuse_in);   // 2 = Winograd with the fused input transform
       out[n * 13 + 11] = kv.second.splits;
       out[n * 13 + 12] = kv.second.steps_per_split;
     }
@@ -1045,14 +1100,16 @@ extern "C" int frcnn_conv2d_import_plans(const int* in, int entries) {
   std::lock_guard<std::mutex> lock(g_plan_mutex);
   for (int e = 0; e < entries; ++e) {
     const int* row = in + e * 13;
-    const int algo = row[10] >> 4, cfg = row[10] & 15;
-    FRCNN_REQUIRE(row[10] >= 0 && cfg < kNumTiles && algo <= 1 && row[11] >= 1 && row[11] <= 64 && row[12] >= 1 &&
+    const int code = row[10] >> 4, cfg = row[10] & 15;
+    const int algo = code >= 1 ? 1 : 0, fuse_in = code == 2 ? 1 : 0;
+    FRCNN_REQUIRE(row[10] >= 0 && cfg < kNumTiles && code <= 2 && (!fuse_in || (cfg == 5 && row[3] % BK == 0)) && row[11] >= 1 && row[11] <= 64 && row[12] >= 1 &&
                       (algo == 0 || (row[11] == 1 && winograd_ok(row[5], row[6], row[7], row[8], row[3], row[4], row[9]))),   // a residual key (row[9] >= 256) fails winograd_ok: no Winograd plan for it
                   "conv2d_import_plans: entry %d is not a valid plan (tile %d, splits %d)", e, row[10], row[11]);
     ShapeKey key;
     for (int i = 0; i < 10; ++i) key[i] = row[i];
     Plan pl{cfg, row[11], row[12]};
     pl.algo = algo;
+    pl.fuse_in = fuse_in;
     g_plan_cache[key] = pl;
   }
   return FRCNN_OK;
@@ -1232,6 +1289,10 @@ int launch_gemm(ConvParams p, const Plan& pl, long M, int k, int groups, hipStre
   p.tiles_n = (k + bn - 1) / bn;
   const bool aligned = (p.C % BK) == 0;
   int rc;
+  if (pl.fuse_in) {
+    if (pl.cfg != 5 || !aligned) return frcnn::fail(FRCNN_ERR_ARG, "conv2d: fused Winograd input needs the 64x64 tile and C %% 32 == 0");
+    return launch_conv<2, 2, 1, 1, true, true>(p, 1, groups, stream);
+  }
 #define FRCNN_CONV_CASE(WM_, WN_, TM_, TN_)                                           \
   rc = aligned ? launch_conv<WM_, WN_, TM_, TN_, true>(p, pl.splits, groups, stream) \
                : launch_conv<WM_, WN_, TM_, TN_, false>(p, pl.splits, groups, stream)
@@ -1282,8 +1343,9 @@ int launch_winograd(const ConvParams& p, const Plan& pl, const float* scale, con
   if (p.u_pre) U = const_cast<float*>(p.u_pre);   // read-only from here on
   else rc = launch_1d("wino_filter_kernel", wino_filter_kernel, (size_t)p.K * (p.C / 4), stream, p.w, U, p.K, p.C / 4);
   if (rc != FRCNN_OK) return rc;
-  rc = launch_1d("wino_input_kernel", wino_input_kernel, (size_t)g.T * (p.C / 4), stream, p.x, V, p.H, p.W, p.C / 4, g.th,
-                 g.tw, g.T);
+  if (!pl.fuse_in)
+    rc = launch_1d("wino_input_kernel", wino_input_kernel, (size_t)g.T * (p.C / 4), stream, p.x, V, p.H, p.W, p.C / 4, g.th,
+                   g.tw, g.T);
   if (rc != FRCNN_OK) return rc;
   // 16 GEMMs  Mo[xi] (T x K) = V[xi] (T x C) . U[xi]^T (K x C)  as ONE grouped 1x1 convolution over a 1 x T "image"
   ConvParams q;
@@ -1297,7 +1359,14 @@ int launch_winograd(const ConvParams& p, const Plan& pl, const float* scale, con
   q.gx = (size_t)g.T * p.C; q.gw = (size_t)p.K * p.C; q.gy = (size_t)g.T * p.K;
   q.u_pre = nullptr;
   q.mask = q.mscale = nullptr;
+  q.wiH = q.wiW = q.wth = q.wtw = 0;
   Plan gp{pl.cfg, 1, q.ksteps};
+  if (pl.fuse_in) {          // the GEMM reads the layer's input itself: no V tensor
+    q.x = p.x;
+    q.gx = 0;
+    q.wiH = p.H; q.wiW = p.W; q.wth = g.th; q.wtw = g.tw;
+    gp.fuse_in = 1;
+  }
   rc = launch_gemm(q, gp, g.T, p.K, 16, stream);
   if (rc != FRCNN_OK) return rc;
   return launch_1d("wino_output_kernel", wino_output_kernel, (size_t)g.T * (p.K / 4), stream, (const float*)Mo, scale, shift, y,
@@ -1347,6 +1416,12 @@ bool tune_plan(const ConvParams& p, long M, int k, const float* scale, const flo
     for (int cfg = 0; cfg < kNumTiles; ++cfg) {
       Plan pl{cfg, 1, (p.C + BK - 1) / BK};
       pl.algo = 1;
+      cands.push_back(pl);
+    }
+    if ((p.C % BK) == 0 && g_wino_fuse) {   // the 64x64 GEMM with the input transform in its A-tile load
+      Plan pl{5, 1, p.C / BK};
+      pl.algo = 1;
+      pl.fuse_in = 1;
       cands.push_back(pl);
     }
   }
@@ -1401,6 +1476,7 @@ int run_conv(const float* x, const float* wgt, const float* scale, const float* 
   p.ys = out_stride; p.Hy = hy; p.Wy = wy;
   p.steps_per_split = p.ksteps; p.tiles_m = p.tiles_n = 0;
   p.gx = p.gw = p.gy = 0;
+  p.wiH = p.wiW = p.wth = p.wtw = 0;
   const bool allow_split = out_stride == 1;
   Plan pl;
   bool have = false;
@@ -1427,6 +1503,7 @@ int run_conv(const float* x, const float* wgt, const float* scale, const float* 
         winograd_ok(r, s, stride, pad, c, k, out_stride)) {
       pl = Plan{M >= 2048 ? 2 : 5, 1, (c + BK - 1) / BK};   // forced Winograd without tuning: a mid-size GEMM tile
       pl.algo = 1;
+      if (g_wino_fuse == 2 && (c % BK) == 0) { pl.cfg = 5; pl.fuse_in = 1; }
     }
   }
   if (!have && split_k <= 0 && pl.splits > 1 && (!ws || ws_bytes < plan_ws_bytes(pl, p, M, k))) {

@@ -144,7 +144,7 @@ def cfg_fingerprint(net):
     return (cfg.NET_TYPE, int(t.RPN_PRE_NMS_TOP_N), int(t.RPN_POST_NMS_TOP_N), float(t.RPN_NMS_THRESH), float(t.NMS_THRESH),
             str(t.get('MODE', 'nms')), int(t.get('RPN_TOP_N', 0)), str(cfg.POOLING_MODE), int(cfg.POOLING_SIZE),
             bool(cfg.ENABLE_CUSTOM_TAIL), uc, int(u.E_NUM_SAMPLE), int(u.A_NUM_CE_SAMPLE), ops.nms_suppress_at_equal(),
-            ops._CONV_ALGO_MODE, bool(N.PROJECT_BEFORE_POOLING), hash(modes))
+            ops._CONV_ALGO_MODE, ops._CONV_ALGO_FLAGS, bool(N.PROJECT_BEFORE_POOLING), hash(modes))
 
 
 class FramePool:

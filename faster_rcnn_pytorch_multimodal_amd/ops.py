@@ -71,13 +71,16 @@ def set_conv_autotune(enable):
 
 def set_conv_algo(mode):
     """0 = the autotuner may choose Winograd F(2x2, 3x3) for the eligible 3x3 layers, 1 = implicit GEMM only,
-    2 = Winograd wherever it applies (frcnn_conv2d_set_algo)."""
-    global _CONV_ALGO_MODE
+    2 = Winograd wherever it applies (frcnn_conv2d_set_algo).  Flags: +16 never fuse the Winograd input transform into the
+    64x64 GEMM's tile load, +32 forced Winograd (2) uses that fused form wherever C % 32 == 0 (tests)."""
+    global _CONV_ALGO_MODE, _CONV_ALGO_FLAGS
     _hip.check(_hip.load().frcnn_conv2d_set_algo(int(mode)), "frcnn_conv2d_set_algo")
-    _CONV_ALGO_MODE = int(mode)
+    _CONV_ALGO_MODE = int(mode) & 3
+    _CONV_ALGO_FLAGS = int(mode) & ~3
 
 
 _CONV_ALGO_MODE = 0
+_CONV_ALGO_FLAGS = 0
 _CONV_AUTOTUNE = False
 
 

@@ -374,3 +374,33 @@ def test_roi_align_split_equals_two_calls_bit_for_bit(hip):
             torch.cuda.synchronize()
             assert torch.equal(o1, r1) and torch.equal(o2, r2), (h, w, c, split, count)
             assert float(o1.min()) >= 0.0 and float(o2.min()) < 0.0
+
+
+@pytest.mark.gpu
+def test_lidar_test_net_replays_graphs(hip, tmp_path):
+    """The LiDAR-BEV detector (BASELINE configs[2] geometry at a small grid) through ``test_net``: captured frames, 4 in flight,
+    records equal to the eager path row for row after the voxel-grid -> metres conversion of lib/model/test.py:223-224, result
+    text file in the LiDAR format of lib/datasets/db.py:336-367."""
+    import torch
+    import test_gpu_parity as T
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.model.test import bbox_voxel_grid_to_pc, lidar_extents, test_net
+    net, _ = T._build_lidar_pair(seed=9)
+    try:
+        info = np.array([0, 176, 0, 208, 0, 12, 0.5], np.float32)
+        blobs = [torch.from_numpy(T._bev_blob(208, 176, 40 + i)).to(DEV) for i in range(6)]
+        timers = {}
+        all_boxes = test_net(net, _Frames(blobs, info), str(tmp_path / "eval"), max_dets=100, thresh=0.05, timers=timers)
+        assert timers["pool"]["replays"] == 6 and timers["pool"]["eager"] == 0 and timers["pool"]["captures"] == 4
+        eager = _eager_records(net, blobs, [info] * 6, 0.05, 100, 300)
+        total = 0
+        for i, (dets, counts) in enumerate(eager):
+            n = int(counts[1])
+            total += n
+            want = bbox_voxel_grid_to_pc(dets[1, :n].copy(), lidar_extents(), info) if n else dets[1, :0]
+            np.testing.assert_array_equal(all_boxes[1][i].reshape(-1, 8), want)
+        assert total > 0
+        lines = open(tmp_path / "eval" / "det_test_cls1.txt").read().splitlines()
+        assert len(lines) == total and len(lines[0].split(" ")) == 10
+    finally:
+        C.reset_cfg()

@@ -185,6 +185,33 @@ def test_conv2d_winograd_matches_direct_and_float64(hip, shape):
     assert float((wino - direct).abs().max()) <= 1e-5 * scale
 
 
+@pytest.mark.parametrize("shape", [(1, 38, 63, 256, 256), (1, 75, 125, 128, 128), (3, 7, 7, 512, 512), (2, 9, 12, 64, 96), (1, 5, 6, 32, 64)])
+def test_conv2d_winograd_fused_input_transform_is_bit_identical(hip, shape):
+    """The 64x64 grouped GEMM with the Winograd INPUT transform inside its A-tile load (frcnn_conv2d_set_algo(2 | 32);
+    conv_igemm_f32<2,2,1,1,true,WINO>) against the two-launch form with the same GEMM tile (2 | 16 + set_conv_tile(1, 1)):
+    the four patch pixels are combined in the order wino_input_kernel combines them, so every output bit is equal - odd map
+    sizes (partial tiles, zero padding on every side), several images, M not a multiple of the tile."""
+    ops = _ops()
+    n, h, w, c, k = shape
+    g = torch.Generator().manual_seed(h * 17 + w)
+    x = torch.randn(n, h, w, c, generator=g).to(DEV)
+    wt = (torch.randn(k, 3, 3, c, generator=g) / (3.0 * c ** 0.5)).to(DEV)
+    sc, sh = (torch.rand(k, generator=g) + 0.5).to(DEV), torch.randn(k, generator=g).to(DEV)
+    try:
+        ops.set_conv_algo(2 | 32)
+        fused = ops.conv2d_nhwc(x, wt, sc, sh, stride=1, pad=1, relu=True)
+        fused2 = ops.conv2d_nhwc(x, wt, sc, sh, stride=1, pad=1, relu=True, w_winograd=ops.winograd_filter(wt))
+        # the two-launch reference: forced Winograd takes the 64x64 GEMM for < 2048 tiles and the 128x128 one above; results
+        # are tile independent (exact k-ordered fma chains, test_conv2d_is_deterministic_and_tile_independent)
+        ops.set_conv_algo(2 | 16)
+        ref = ops.conv2d_nhwc(x, wt, sc, sh, stride=1, pad=1, relu=True)
+    finally:
+        ops.set_conv_algo(0)
+    torch.cuda.synchronize()
+    assert torch.equal(fused, fused2)
+    assert torch.equal(fused, ref), "fused input transform differs: max %.3e" % float((fused - ref).abs().max())
+
+
 def test_conv2d_autotune_may_pick_winograd_and_plans_round_trip(hip):
     """With the autotuner on, an eligible layer is timed in both forms; whatever wins is exported with the algorithm in the
     tile index (+16) and imports back."""
