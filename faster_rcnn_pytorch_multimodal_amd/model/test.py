@@ -198,7 +198,9 @@ def test_net(net, db, out_dir, max_dets=100, thresh=0.1, mode='test', draw_det=F
     # EVAL_GATHER_EVERY frames is collated (one all-gather over the ranks) and copied to the host on the ring's own stream
     # (collate.RecordRing); the host unpacks a chunk of blocks at a time.
     chunk = collate.EVAL_GATHER_EVERY * 8
-    pool = net.frame_pool() if (cfg.TEST.FRAME_GRAPHS and dev.type == 'cuda' and hasattr(net, 'frame_pool')) else None
+    # (an injected RPN output - the evaluation hook Network._rpn_override - is a per-call host decision: eager path)
+    pool = net.frame_pool() if (cfg.TEST.FRAME_GRAPHS and dev.type == 'cuda' and hasattr(net, 'frame_pool')
+                                and getattr(net, '_rpn_override', None) is None) else None
     lanes = pool.n_streams if pool is not None else 1
     if pool is not None:
         pool.sync_weights()
