@@ -409,7 +409,8 @@ def drop_in_uncertainty(device, n_frames, frames_host, info, calls=3):
                        if not np.array_equal(np.asarray(boxes[j][i]).reshape(-1, width), exp[j]))
         runs.sort(key=lambda r: r[0])
         fps = n_frames / runs[len(runs) // 2][0]
-        return {"frames_s": fps, "runner_frames_s": runner_fps, "ratio_to_runner": fps / runner_fps, "frames": n_frames,
+        return {"frames_s": fps, "ms_per_frame": 1e3 / fps, "runner_frames_s": runner_fps, "ratio_to_runner": fps / runner_fps,
+                "frames": n_frames,
                 "e_num_sample": int(cfg.UC.E_NUM_SAMPLE), "a_num_ce_sample": int(cfg.UC.A_NUM_CE_SAMPLE),
                 "row_width": width, "records_equal_to_eager_path": bad == 0, "frames_checked_against_eager": checked,
                 "what": "cfg.UC.EN_BBOX/CLS_ALEATORIC + EN_BBOX/CLS_EPISTEMIC: 10 Monte-Carlo passes of the heads per frame as "
