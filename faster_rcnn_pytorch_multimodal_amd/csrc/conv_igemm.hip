@@ -74,6 +74,7 @@ struct ConvParams {
   // layer's NHWC input (wiH x wiW pixels, C channels), GEMM row m is the 2x2-output tile (n, ty, tx) of a wth x wtw grid and
   // blockIdx.y the transform component
   int wiH, wiW, wth, wtw;
+  int epi_lds;   // 1: the register-staged kernels transpose their accumulator tiles through LDS before storing (conv_epilogue_lds)
 };
 
 // XCD-aware bijective remap (guide T1): blocks b and b+8 share an XCD; give each XCD a contiguous
@@ -178,6 +179,75 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
           if (p.mask) t = p.mask[orow + n] > 0.f ? t * (p.mscale ? p.mscale[n] : 1.f) : 0.f;
           p.y[orow + n] = t;
         }
+      }
+    }
+  }
+}
+
+// The same epilogue with the accumulator tiles TRANSPOSED through LDS first.  In the MFMA layout a lane holds 4 consecutive
+// channels of ITS pixel, so a store instruction of conv_epilogue writes 64 pieces of 16 bytes (32 pixels x 2 halves), each in
+// a different row of the output - and reads the residual the same way.  Here a wave writes its 32 x 32 tile to a private LDS
+// patch (the K loop is over: the staging buffers are free) and reads it back with 8 lanes per pixel: every global access of
+// the wave is then 8 rows x 128 contiguous bytes.  Same per-element arithmetic -> bit-identical results.  K % 4 == 0 only.
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_lds(const ConvParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc,
+                                                  int lane, float* __restrict__ patch) {
+  const size_t goff = (size_t)blockIdx.y * p.gy;
+  float* const slab = p.partial ? p.partial + (size_t)blockIdx.z * p.M * p.K : nullptr;
+  const int wpix = lane & 31, whalf = 4 * (lane >> 5);       // write phase: MFMA layout
+  const int rrow = lane >> 3, rcol = 4 * (lane & 7);         // read phase: 8 lanes x 16 B per pixel row
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(patch + wpix * LDS_PITCH + 8 * g + whalf) =
+            f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+      const int n = n0 + (wc * TN + j) * 32 + rcol;
+      const bool nok = n < p.K;
+      f32x4 v[4], rv[4], mv[4];
+      size_t at[4];
+      bool ok[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = rrow + 8 * it;
+        const int m = m0 + (wr * TM + i) * 32 + row;
+        v[it] = *reinterpret_cast<const f32x4*>(patch + row * LDS_PITCH + rcol);
+        ok[it] = nok && m < p.M;
+        size_t orow = (size_t)m * p.K + goff;
+        if (p.ys != 1 && ok[it]) {
+          const int img = m / (p.Ho * p.Wo);
+          const int rem = m - img * p.Ho * p.Wo;
+          const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+          orow = ((size_t)(img * p.Hy + ho * p.ys) * p.Wy + wo * p.ys) * p.K + goff;
+        }
+        at[it] = slab ? (size_t)m * p.K + n : orow + n;
+        rv[it] = (!slab && p.res && ok[it]) ? *reinterpret_cast<const f32x4*>(p.res + at[it]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        mv[it] = (!slab && p.mask && ok[it]) ? *reinterpret_cast<const f32x4*>(p.mask + at[it]) : f32x4{1.f, 1.f, 1.f, 1.f};
+      }
+      if (slab) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          if (ok[it]) *reinterpret_cast<f32x4*>(slab + at[it]) = v[it];
+        continue;
+      }
+      const f32x4 sc = (p.scale && nok) ? *reinterpret_cast<const f32x4*>(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+      const f32x4 sh = (p.shift && nok) ? *reinterpret_cast<const f32x4*>(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 ms = (p.mask && p.mscale && nok) ? *reinterpret_cast<const f32x4*>(p.mscale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        if (!ok[it]) continue;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = v[it][e] * sc[e] + sh[e];
+          t += rv[it][e];
+          t = p.relu ? fmaxf(t, 0.f) : t;
+          if (p.mask) t = mv[it][e] > 0.f ? t * ms[e] : 0.f;
+          o[e] = t;
+        }
+        *reinterpret_cast<f32x4*>(p.y + at[it]) = o;
       }
     }
   }
@@ -411,7 +481,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvPara
     if (it + 1 < nsteps) kstep(it + 1, Set1{}, std::false_type{});
   }
 
-  conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
+  if (p.epi_lds && (p.K & 3) == 0)   // (uniform branch; every wave is past the K loop's last barrier and reads no LDS any more)
+    conv_epilogue_lds<TM, TN>(p, acc, m0, n0, wr, wc, lane, smem + wave * 32 * LDS_PITCH);
+  else
+    conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -804,6 +877,8 @@ size_t winograd_ws_bytes(int n, int h, int w, int c, int k);
 std::atomic<int> g_algo_mode{0};   // atomic: set from one thread while another may launch
 // test / tuning hook (frcnn_conv2d_set_algo bit 4): may the tuner try / forced Winograd use the fused input transform?
 std::atomic<int> g_wino_fuse{1};
+// test / tuning hook (frcnn_conv2d_set_algo bit 6): 1 = the register-staged kernels store through the LDS transpose
+std::atomic<int> g_epi_lds{1};
 
 // test / tuning hook: force the block tile (0 = automatic choice)
 std::atomic<int> g_force_tm{0}, g_force_tn{0};
@@ -1000,11 +1075,13 @@ extern "C" int frcnn_conv2d_set_tile(int tm, int tn) {
 }
 
 extern "C" int frcnn_conv2d_set_algo(int mode) {
-  FRCNN_REQUIRE(mode >= 0 && (mode & 3) <= 2 && (mode & ~(3 | 16 | 32)) == 0,
+  FRCNN_REQUIRE(mode >= 0 && (mode & 3) <= 2 && (mode & ~(3 | 16 | 32 | 64)) == 0,
                 "conv2d_set_algo: mode %d (0 auto, 1 implicit GEMM only, 2 Winograd where it applies; +16: never fuse the "
-                "Winograd input transform into the GEMM, +32: forced Winograd uses the 64x64 GEMM with the fused transform)", mode);
+                "Winograd input transform into the GEMM, +32: forced Winograd uses the 64x64 GEMM with the fused transform, +64: the "
+                "register-staged kernels store straight from the MFMA layout instead of through the LDS transpose)", mode);
   g_algo_mode = mode & 3;
   g_wino_fuse = (mode & 16) ? 0 : ((mode & 32) ? 2 : 1);
+  g_epi_lds = (mode & 64) ? 0 : 1;
   return FRCNN_OK;
 }
 
@@ -1360,6 +1437,7 @@ int launch_winograd(const ConvParams& p, const Plan& pl, const float* scale, con
   q.u_pre = nullptr;
   q.mask = q.mscale = nullptr;
   q.wiH = q.wiW = q.wth = q.wtw = 0;
+  q.epi_lds = p.epi_lds;
   Plan gp{pl.cfg, 1, q.ksteps};
   if (pl.fuse_in) {          // the GEMM reads the layer's input itself: no V tensor
     q.x = p.x;
@@ -1477,6 +1555,7 @@ int run_conv(const float* x, const float* wgt, const float* scale, const float* 
   p.steps_per_split = p.ksteps; p.tiles_m = p.tiles_n = 0;
   p.gx = p.gw = p.gy = 0;
   p.wiH = p.wiW = p.wth = p.wtw = 0;
+  p.epi_lds = g_epi_lds;
   const bool allow_split = out_stride == 1;
   Plan pl;
   bool have = false;

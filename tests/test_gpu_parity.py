@@ -212,6 +212,53 @@ def test_conv2d_winograd_fused_input_transform_is_bit_identical(hip, shape):
     assert torch.equal(fused, ref), "fused input transform differs: max %.3e" % float((fused - ref).abs().max())
 
 
+@pytest.mark.parametrize("case", [(1, 38, 63, 256, 1024, 1, 1, 0), (1, 38, 63, 1024, 256, 1, 1, 0), (1, 75, 125, 128, 128, 3, 1, 1),
+                                  (2, 9, 11, 64, 2048, 1, 1, 0), (1, 19, 32, 512, 512, 3, 2, 1), (1, 13, 17, 32, 100, 3, 1, 1),
+                                  (300, 7, 7, 512, 512, 1, 1, 0)])
+def test_conv2d_lds_transposed_epilogue_is_bit_identical(hip, case):
+    """The register-staged kernels' store path (conv_epilogue_lds: accumulator tiles transposed through LDS so that a wave
+    writes 8 rows x 128 contiguous bytes) against the direct MFMA-layout stores (frcnn_conv2d_set_algo flag 64): same
+    arithmetic per element -> identical bits, with scale / shift / residual / ReLU, for every register-staged tile, split-K
+    slabs, K not a multiple of 32 and the data-gradient forms (stride-2 scatter, activation mask)."""
+    ops = _ops()
+    from faster_rcnn_pytorch_multimodal_amd import _hip
+    lib = _hip.load()
+    n, h, w, c, k, r, stride, pad = case
+    g = torch.Generator().manual_seed(c + k)
+    x = torch.randn(n, h, w, c, generator=g).to(DEV)
+    wt = (torch.randn(k, r, r, c, generator=g) / (r * c ** 0.5)).to(DEV)
+    sc, sh = (torch.rand(k, generator=g) + 0.5).to(DEV), torch.randn(k, generator=g).to(DEV)
+    ho, wo = (h + 2 * pad - r) // stride + 1, (w + 2 * pad - r) // stride + 1
+    res = torch.randn(n, ho, wo, k, generator=g).to(DEV)
+    outs = {}
+    try:
+        _hip.check(lib.frcnn_conv2d_set_staging(0), "set_staging")        # register-staged kernels for every tile
+        for flag in (1, 1 | 64):                                             # implicit GEMM only; with / without the transpose
+            ops.set_conv_algo(flag)
+            got = []
+            for tm, tn in ((1, 1), (1, 2), (2, 1), (2, 2), (4, 2)):
+                _hip.check(lib.frcnn_conv2d_set_tile(tm, tn), "set_tile")
+                got.append(ops.conv2d_nhwc(x, wt, sc, sh, res, stride=stride, pad=pad, relu=True))
+                got.append(ops.conv2d_nhwc(x, wt, None, None, None, stride=stride, pad=pad, relu=False, split_k=2))
+            _hip.check(lib.frcnn_conv2d_set_tile(0, 0), "set_tile")
+            # data gradient of the same layer (dy = res): strided 3x3 dilates, strided 1x1 scatters; with the activation mask
+            wt_t = ops.conv2d_transpose_filter(wt)
+            got.append(ops.conv2d_bwd_data(res, wt_t, (n, h, w, c), stride=stride, pad=pad))
+            got.append(ops.conv2d_bwd_data(res, wt_t, (n, h, w, c), stride=stride, pad=pad, act_y=x,
+                                           act_scale=torch.rand(c, generator=torch.Generator().manual_seed(1)).to(DEV))
+                       if stride == 1 or r > 1 else got[-1])
+            outs[flag] = got
+    finally:
+        _hip.check(lib.frcnn_conv2d_set_tile(0, 0), "set_tile")
+        _hip.check(lib.frcnn_conv2d_set_staging(1), "set_staging")
+        ops.set_conv_algo(0)
+    torch.cuda.synchronize()
+    for a, b in zip(outs[1], outs[1 | 64]):
+        assert torch.equal(a, b)
+    for t in outs[1][0:10:2]:
+        assert torch.equal(t, outs[1][0])                                    # and tile independent, as before
+
+
 def test_conv2d_autotune_may_pick_winograd_and_plans_round_trip(hip):
     """With the autotuner on, an eligible layer is timed in both forms; whatever wins is exported with the algorithm in the
     tile index (+16) and imports back."""
