@@ -238,7 +238,7 @@ def test_conv2d_lds_transposed_epilogue_is_bit_identical(hip, case):
             got = []
             for tm, tn in ((1, 1), (1, 2), (2, 1), (2, 2), (4, 2)):
                 _hip.check(lib.frcnn_conv2d_set_tile(tm, tn), "set_tile")
-                got.append(ops.conv2d_nhwc(x, wt, sc, sh, res, stride=stride, pad=pad, relu=True))
+                got.append(ops.conv2d_nhwc(x, wt, sc, sh, res, stride=stride, pad=pad, relu=True, split_k=1))
                 got.append(ops.conv2d_nhwc(x, wt, None, None, None, stride=stride, pad=pad, relu=False, split_k=2))
             _hip.check(lib.frcnn_conv2d_set_tile(0, 0), "set_tile")
             # data gradient of the same layer (dy = res): strided 3x3 dilates, strided 1x1 scatters; with the activation mask
