@@ -661,7 +661,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_f32(const ConvParams p)
     mma(fa1, fb1);
     stage = next;
   }
-  conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
+  if (p.epi_lds && (p.K & 3) == 0) {
+    __syncthreads();   // the last step has no barrier behind its fragment reads: every wave must be done with the stages
+    conv_epilogue_lds<TM, TN>(p, acc, m0, n0, wr, wc, lane, smem + wave * 32 * LDS_PITCH);
+  } else {
+    conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -829,7 +834,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma2_f32(const ConvParams p
     }
     mma(fa1, fb1);
   }
-  conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
+  if (p.epi_lds && (p.K & 3) == 0) {
+    __syncthreads();
+    conv_epilogue_lds<TM, TN>(p, acc, m0, n0, wr, wc, lane, smem + wave * 32 * LDS_PITCH);
+  } else {
+    conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
+  }
 }
 
 
@@ -877,7 +887,7 @@ size_t winograd_ws_bytes(int n, int h, int w, int c, int k);
 std::atomic<int> g_algo_mode{0};   // atomic: set from one thread while another may launch
 // test / tuning hook (frcnn_conv2d_set_algo bit 4): may the tuner try / forced Winograd use the fused input transform?
 std::atomic<int> g_wino_fuse{1};
-// test / tuning hook (frcnn_conv2d_set_algo bit 6): 1 = the register-staged kernels store through the LDS transpose
+// test / tuning hook (frcnn_conv2d_set_algo bit 6): 1 = the convolution kernels store through the LDS transpose
 std::atomic<int> g_epi_lds{1};
 
 // test / tuning hook: force the block tile (0 = automatic choice)

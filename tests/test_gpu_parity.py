@@ -216,7 +216,7 @@ def test_conv2d_winograd_fused_input_transform_is_bit_identical(hip, shape):
                                   (2, 9, 11, 64, 2048, 1, 1, 0), (1, 19, 32, 512, 512, 3, 2, 1), (1, 13, 17, 32, 100, 3, 1, 1),
                                   (300, 7, 7, 512, 512, 1, 1, 0)])
 def test_conv2d_lds_transposed_epilogue_is_bit_identical(hip, case):
-    """The register-staged kernels' store path (conv_epilogue_lds: accumulator tiles transposed through LDS so that a wave
+    """The convolution kernels' store path (conv_epilogue_lds: accumulator tiles transposed through LDS so that a wave
     writes 8 rows x 128 contiguous bytes) against the direct MFMA-layout stores (frcnn_conv2d_set_algo flag 64): same
     arithmetic per element -> identical bits, with scale / shift / residual / ReLU, for every register-staged tile, split-K
     slabs, K not a multiple of 32 and the data-gradient forms (stride-2 scatter, activation mask)."""
@@ -232,14 +232,18 @@ def test_conv2d_lds_transposed_epilogue_is_bit_identical(hip, case):
     res = torch.randn(n, ho, wo, k, generator=g).to(DEV)
     outs = {}
     try:
-        _hip.check(lib.frcnn_conv2d_set_staging(0), "set_staging")        # register-staged kernels for every tile
         for flag in (1, 1 | 64):                                             # implicit GEMM only; with / without the transpose
             ops.set_conv_algo(flag)
             got = []
-            for tm, tn in ((1, 1), (1, 2), (2, 1), (2, 2), (4, 2)):
-                _hip.check(lib.frcnn_conv2d_set_tile(tm, tn), "set_tile")
-                got.append(ops.conv2d_nhwc(x, wt, sc, sh, res, stride=stride, pad=pad, relu=True, split_k=1))
-                got.append(ops.conv2d_nhwc(x, wt, None, None, None, stride=stride, pad=pad, relu=False, split_k=2))
+            # staging 0: register-staged kernels for every tile; 1: LDS-DMA kernels for the 8-wave tiles; 2: also the
+            # two-stage LDS-DMA kernel for the 128x128 tile (C % 32 == 0, else the register-staged kernels again)
+            for staging, tiles in ((0, ((1, 1), (1, 2), (2, 1), (2, 2), (4, 2))), (1, ((4, 2), (2, 4))), (2, ((2, 2),))):
+                _hip.check(lib.frcnn_conv2d_set_staging(staging), "set_staging")
+                for tm, tn in tiles:
+                    _hip.check(lib.frcnn_conv2d_set_tile(tm, tn), "set_tile")
+                    got.append(ops.conv2d_nhwc(x, wt, sc, sh, res, stride=stride, pad=pad, relu=True, split_k=1))
+                    got.append(ops.conv2d_nhwc(x, wt, None, None, None, stride=stride, pad=pad, relu=False, split_k=2))
+            _hip.check(lib.frcnn_conv2d_set_staging(0), "set_staging")
             _hip.check(lib.frcnn_conv2d_set_tile(0, 0), "set_tile")
             # data gradient of the same layer (dy = res): strided 3x3 dilates, strided 1x1 scatters; with the activation mask
             wt_t = ops.conv2d_transpose_filter(wt)
@@ -255,8 +259,8 @@ def test_conv2d_lds_transposed_epilogue_is_bit_identical(hip, case):
     torch.cuda.synchronize()
     for a, b in zip(outs[1], outs[1 | 64]):
         assert torch.equal(a, b)
-    for t in outs[1][0:10:2]:
-        assert torch.equal(t, outs[1][0])                                    # and tile independent, as before
+    for t in outs[1][0:16:2]:
+        assert torch.equal(t, outs[1][0])                                    # and tile / staging independent, as before
 
 
 def test_conv2d_autotune_may_pick_winograd_and_plans_round_trip(hip):
