@@ -214,7 +214,7 @@ def test_conv2d_winograd_fused_input_transform_is_bit_identical(hip, shape):
 
 @pytest.mark.parametrize("case", [(1, 38, 63, 256, 1024, 1, 1, 0), (1, 38, 63, 1024, 256, 1, 1, 0), (1, 75, 125, 128, 128, 3, 1, 1),
                                   (2, 9, 11, 64, 2048, 1, 1, 0), (1, 19, 32, 512, 512, 3, 2, 1), (1, 13, 17, 32, 100, 3, 1, 1),
-                                  (300, 7, 7, 512, 512, 1, 1, 0)])
+                                  (300, 7, 7, 512, 512, 1, 1, 0), (1, 38, 62, 256, 512, 1, 2, 0)])
 def test_conv2d_lds_transposed_epilogue_is_bit_identical(hip, case):
     """The convolution kernels' store path (conv_epilogue_lds: accumulator tiles transposed through LDS so that a wave
     writes 8 rows x 128 contiguous bytes) against the direct MFMA-layout stores (frcnn_conv2d_set_algo flag 64): same
