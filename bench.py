@@ -498,6 +498,9 @@ def parse_args(argv=None):
     ap.add_argument("--regions", type=int, default=0, help="timed repetitions of the --steps region (0 = until ~1 s is timed)")
     ap.add_argument("--no-upload", action="store_true", help="skip the extra region that uploads every frame inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cu-mask", default="none", choices=["none", "xcd", "rows", "xcd2"],
+                    help="experiment: give every frame stream its own share of the CUs (hipExtStreamCreateWithCUMask): 'xcd' = "
+                         "whole XCDs per stream (mask bit i = CU i / 8 of XCD i %% 8), 'rows' = the same CU rows of every XCD")
     ap.add_argument("--only-timed", action="store_true", help="profiling aid (tools/pmc_timed.py): the runners' warm-up frames and "
                     "exactly --steps graph replays, nothing else; prints the frame counts")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip BASELINE configs[2] / configs[3] (extra_configs)")
@@ -536,6 +539,35 @@ def device_for_rank(local_rank, backend, device_count):
     if backend == "nccl":
         return int(local_rank)
     return int(local_rank) % max(int(device_count), 1)
+
+
+_MASKED_STREAMS = []
+
+
+def masked_stream(device, k, n, mode, num_cu=256, num_xcd=8):
+    """A HIP stream whose kernels only run on share k of n of the CUs (hipExtStreamCreateWithCUMask), as a torch stream."""
+    if mode == "none":
+        return torch.cuda.Stream(device=device)
+    import ctypes
+    from faster_rcnn_pytorch_multimodal_amd.model.train_graph import _hip_runtime
+    hip = _hip_runtime()
+    words = (num_cu + 31) // 32
+    mask = [0] * words
+    for i in range(num_cu):
+        xcd, row = i % num_xcd, i // num_xcd          # mask bit i = CU `row` of XCD `xcd` (bits interleave the XCDs)
+        if mode == "xcd2":                              # two halves of the chip, streams alternate between them
+            mine = (xcd * 2 // num_xcd) == (k % 2)
+        else:
+            mine = (xcd * n // num_xcd == k) if mode == "xcd" else (row % n == k)
+        if mine:
+            mask[i // 32] |= 1 << (i % 32)
+    arr = (ctypes.c_uint32 * words)(*mask)
+    handle = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(words), arr)
+    if rc != 0:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
+    _MASKED_STREAMS.append(handle)
+    return torch.cuda.ExternalStream(handle.value, device=device)
 
 
 def rehearsal_record(frame_id, numel):
@@ -606,7 +638,7 @@ def main(argv=None):
                 _ops.import_conv_plans(json.load(f))
             plans_loaded = True
         runners = [FrameRunner(net, H, W, C, info, THRESH, MAX_DETS, use_graph=not args.no_graph) for _ in range(n_streams)]
-        streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+        streams = [masked_stream(device, k, n_streams, args.cu_mask) for k in range(n_streams)]
         for st in streams:
             st.wait_stream(torch.cuda.current_stream())
 
