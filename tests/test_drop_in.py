@@ -404,3 +404,27 @@ def test_lidar_test_net_replays_graphs(hip, tmp_path):
         assert len(lines) == total and len(lines[0].split(" ")) == 10
     finally:
         C.reset_cfg()
+
+
+@pytest.mark.gpu
+def test_fpn_detector_test_net_replays_graphs(hip, tmp_path):
+    """The res101+FPN detector (cfg.USE_FPN, 'multiscale' pooling over p2..p5, custom tail: tools/trainval_net.py:326-330)
+    through ``test_net``: the pyramid, the FPN level map and the multi-level RoIAlign are captured like the plain detector's
+    frame; records equal the eager path."""
+    import torch
+    import test_gpu_parity as T
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.model.test import test_net
+    net, _ = T._build_fpn_pair(seed=23)
+    try:
+        net.eval()
+        rng = np.random.default_rng(17)
+        info = np.array([0, 320, 0, 256, 0, 0, 1.0], np.float32)
+        blobs = [torch.from_numpy((rng.standard_normal((1, 256, 320, 3)) * 50).astype(np.float32)).to(DEV) for _ in range(6)]
+        timers = {}
+        all_boxes = test_net(net, _Frames(blobs, info), str(tmp_path / "eval"), max_dets=100, thresh=0.05, timers=timers)
+        assert timers["pool"]["replays"] == 6 and timers["pool"]["eager"] == 0, timers
+        eager = _eager_records(net, blobs, [info] * 6, 0.05, 100, 300)
+        assert _assert_boxes_equal(all_boxes, eager) > 0
+    finally:
+        C.reset_cfg()
