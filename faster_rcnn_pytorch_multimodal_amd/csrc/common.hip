@@ -68,12 +68,18 @@ hipError_t copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t stre
 
 }  // namespace frcnn
 
+namespace frcnn {
+static std::atomic<unsigned> g_settings_epoch{0};
+void bump_settings_epoch() { g_settings_epoch.fetch_add(1); }
+}  // namespace frcnn
+extern "C" unsigned frcnn_settings_epoch(void) { return frcnn::g_settings_epoch.load(); }
+
 extern "C" int frcnn_set_memops_mode(int mode) {
   if (mode != 0 && mode != 1) return frcnn::fail(FRCNN_ERR_ARG, "set_memops_mode: 0 (kernels) or 1 (hipMemsetAsync / hipMemcpyAsync)");
-  frcnn::g_memops_mode.store(mode);
+  if (frcnn::g_memops_mode.exchange(mode) != mode) frcnn::bump_settings_epoch();
   return FRCNN_OK;
 }
 extern "C" int frcnn_get_memops_mode(void) { return frcnn::g_memops_mode.load(); }
 
-extern "C" int frcnn_version(void) { return 107; }
+extern "C" int frcnn_version(void) { return 108; }
 extern "C" const char* frcnn_last_error(void) { return frcnn::error_buffer(); }

@@ -1079,8 +1079,8 @@ extern "C" int frcnn_conv2d_set_tile(int tm, int tn) {
   for (int i = 0; i < kNumTiles; ++i) known = known || (kTiles[i].tm == tm && kTiles[i].tn == tn);
   FRCNN_REQUIRE(known, "conv2d_set_tile: tiles are 64*tm x 64*tn with (tm,tn) in "
                        "{(4,2),(2,4),(2,2),(2,1),(1,2),(1,1)} ((0,0) = automatic)");
-  g_force_tm = tm;
-  g_force_tn = tn;
+  if (g_force_tm.exchange(tm) != tm) frcnn::bump_settings_epoch();
+  if (g_force_tn.exchange(tn) != tn) frcnn::bump_settings_epoch();
   return FRCNN_OK;
 }
 
@@ -1089,15 +1089,16 @@ extern "C" int frcnn_conv2d_set_algo(int mode) {
                 "conv2d_set_algo: mode %d (0 auto, 1 implicit GEMM only, 2 Winograd where it applies; +16: never fuse the "
                 "Winograd input transform into the GEMM, +32: forced Winograd uses the 64x64 GEMM with the fused transform, +64: the "
                 "register-staged kernels store straight from the MFMA layout instead of through the LDS transpose)", mode);
-  g_algo_mode = mode & 3;
-  g_wino_fuse = (mode & 16) ? 0 : ((mode & 32) ? 2 : 1);
-  g_epi_lds = (mode & 64) ? 0 : 1;
+  const int fuse = (mode & 16) ? 0 : ((mode & 32) ? 2 : 1), epi = (mode & 64) ? 0 : 1;
+  const bool same = g_algo_mode.exchange(mode & 3) == (mode & 3);
+  const bool same_f = g_wino_fuse.exchange(fuse) == fuse, same_e = g_epi_lds.exchange(epi) == epi;
+  if (!(same && same_f && same_e)) frcnn::bump_settings_epoch();
   return FRCNN_OK;
 }
 
 extern "C" int frcnn_conv2d_set_staging(int use_lds_dma) {
   FRCNN_REQUIRE(use_lds_dma >= 0 && use_lds_dma <= 2, "conv2d_set_staging: mode %d (0, 1 or 2)", use_lds_dma);
-  g_use_dma = use_lds_dma;
+  if (g_use_dma.exchange(use_lds_dma) != use_lds_dma) frcnn::bump_settings_epoch();
   return FRCNN_OK;
 }
 

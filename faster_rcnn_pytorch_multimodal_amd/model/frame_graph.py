@@ -134,8 +134,10 @@ class FrameRunner:
 # ---------------------------------------------------------------------------------------------------------------------
 def cfg_fingerprint(net):
     """Everything outside the frame's shape that a captured frame bakes in: proposal / NMS / pooling settings, the
-    uncertainty flags and sample counts, the process-wide kernel switches, the modules' train / eval state."""
-    from .. import ops
+    uncertainty flags and sample counts, the process-wide kernel switches (the Python-level ones by value, the library's -
+    forced tile, convolution algorithm / staging, RoIAlign and filter variants, memops mode, NMS tie rule - through
+    ``frcnn_settings_epoch``, which advances whenever one of them changes value), the modules' train / eval state."""
+    from .. import _hip, ops
     from ..nets import network as N
     t, u = cfg.TEST, cfg.UC
     uc = tuple(bool(u.get(k, False)) for k in ('EN_BBOX_ALEATORIC', 'EN_CLS_ALEATORIC', 'EN_BBOX_EPISTEMIC', 'EN_CLS_EPISTEMIC',
@@ -144,7 +146,8 @@ def cfg_fingerprint(net):
     return (cfg.NET_TYPE, int(t.RPN_PRE_NMS_TOP_N), int(t.RPN_POST_NMS_TOP_N), float(t.RPN_NMS_THRESH), float(t.NMS_THRESH),
             str(t.get('MODE', 'nms')), int(t.get('RPN_TOP_N', 0)), str(cfg.POOLING_MODE), int(cfg.POOLING_SIZE),
             bool(cfg.ENABLE_CUSTOM_TAIL), uc, int(u.E_NUM_SAMPLE), int(u.A_NUM_CE_SAMPLE), ops.nms_suppress_at_equal(),
-            ops._CONV_ALGO_MODE, ops._CONV_ALGO_FLAGS, bool(N.PROJECT_BEFORE_POOLING), hash(modes))
+            ops._CONV_ALGO_MODE, ops._CONV_ALGO_FLAGS, bool(N.PROJECT_BEFORE_POOLING), bool(N.FUSE_PROJECTIONS),
+            int(N.ROI_ALIGN_SAMPLING_RATIO), int(_hip.load().frcnn_settings_epoch()), hash(modes))
 
 
 class FramePool:

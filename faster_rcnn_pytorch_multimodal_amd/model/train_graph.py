@@ -53,7 +53,11 @@ def inline_graphs_supported():
     same initialisations as kernel launches (csrc/common.hip fill_bytes / copy_bytes, the default since library version
     107) it replays correctly on the default runtime path.  ``TrainStepRunner`` additionally refuses an in-line capture
     that still contains a memset node (``InlineCaptureUnsafe``: e.g. a torch reduction's semaphore memset) and
-    ``TrainPipeline`` checks every captured runner's replays against each other."""
+    ``TrainPipeline`` checks every captured runner's replays against each other.
+    The root cause is EMPIRICAL (an in-situ A/B, profiles/r04_graph_replay_root_cause.md; the stand-alone reproducer
+    tools/graph_replay_repro.hip does not trigger, and torch's own memcpy nodes remain in the chain): what protects a run is
+    the per-runner replay check.  ``TrainPipeline(inline=False)`` / ``DEBUG_CLR_GRAPH_PACKET_CAPTURE=0`` are the
+    conservative settings (forked graphs / the runtime's general replay path)."""
     return True
 
 
@@ -67,14 +71,25 @@ _NODE_KINDS = {0: 'kernel', 1: 'memcpy', 2: 'memset', 3: 'host', 4: 'graph', 5: 
 
 
 def _hip_runtime():
-    """The libamdhip64 instance THIS process already runs on (torch ships its own copy: opening another one by name would
-    hand its entry points graph handles of a different runtime)."""
+    """The libamdhip64 instance THIS process's torch runs on (torch ships its own copy: opening another one by name, or
+    picking another mapped copy, would hand its entry points graph handles of a different runtime)."""
     import ctypes
+    import os
     with open('/proc/self/maps') as f:
-        paths = {line.split()[-1] for line in f if 'libamdhip64' in line}
+        paths = sorted({line.split()[-1] for line in f if 'libamdhip64' in line})
     if not paths:
         raise RuntimeError("libamdhip64 is not loaded in this process")
-    return ctypes.CDLL(sorted(paths)[0])
+    torch_lib = os.path.join(os.path.dirname(os.path.abspath(torch.__file__)), 'lib')
+    own = [p for p in paths if os.path.dirname(os.path.realpath(p)) == os.path.realpath(torch_lib)]
+    if len(paths) > 1 and not own:
+        raise RuntimeError("several libamdhip64 copies are mapped (%s) and none is torch's: cannot tell which runtime owns "
+                           "torch's graphs" % ", ".join(paths))
+    return ctypes.CDLL((own or paths)[0])
+
+
+def _hip_ok(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed with hipError %d" % (what, rc))
 
 
 def graph_node_kinds(graph):
@@ -85,18 +100,17 @@ def graph_node_kinds(graph):
     hip = _hip_runtime()
     raw = ctypes.c_void_p(graph.raw_cuda_graph())
     n = ctypes.c_size_t(0)
-    if hip.hipGraphGetNodes(raw, None, ctypes.byref(n)) != 0:
-        raise RuntimeError("hipGraphGetNodes failed")
+    _hip_ok(hip.hipGraphGetNodes(raw, None, ctypes.byref(n)), "hipGraphGetNodes (count)")
     nodes = (ctypes.c_void_p * max(n.value, 1))()
-    hip.hipGraphGetNodes(raw, nodes, ctypes.byref(n))
+    _hip_ok(hip.hipGraphGetNodes(raw, nodes, ctypes.byref(n)), "hipGraphGetNodes")
     hist = {}
     for i in range(n.value):
         t = ctypes.c_int(-1)
-        hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t))
+        _hip_ok(hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t)), "hipGraphNodeGetType")
         kind = _NODE_KINDS.get(t.value, 'type%d' % t.value)
         hist[kind] = hist.get(kind, 0) + 1
     e = ctypes.c_size_t(0)
-    hip.hipGraphGetEdges(raw, None, None, ctypes.byref(e))
+    _hip_ok(hip.hipGraphGetEdges(raw, None, None, ctypes.byref(e)), "hipGraphGetEdges")
     return hist, int(n.value), int(e.value)
 
 
@@ -124,11 +138,16 @@ class TrainStepRunner:
     statistics version afterwards so that an eval-mode forward re-folds them."""
 
     def __init__(self, net, height, width, channels, num_gt, info, warmup=2, autotune=True, grads=None, inline=False,
-                 group_wgrad=None, debug_dump=None):
+                 group_wgrad=None, debug_dump=None, defer_bn_stats=False):
         """``num_gt``: boxes of the first frame (fixes the buffer capacity).  ``grads``: gradient buffers (one per trainable
         parameter, in net.parameters() order) the captured backward accumulates into; default: the parameters' own
         ``.grad`` (created as zeros when missing).  A pipeline slot passes its private buffers (``TrainPipeline``).
-        ``inline``: capture the filter gradients in line (one chain) instead of on a side stream."""
+        ``inline``: capture the filter gradients in line (one chain) instead of on a side stream.
+        ``defer_bn_stats``: the captured BatchNorm launches leave the frame's batch mean / unbiased variance in buffers
+        private to this runner instead of updating the modules' running statistics; ``fold_bn_stats()`` applies the update
+        ``running = (1 - momentum) * running + momentum * stat`` afterwards.  Runners of different pipeline slots replay
+        CONCURRENTLY: an in-kernel read-modify-write of the shared statistics would lose updates (and count); the
+        pipeline folds in frame order instead, which is the reference's sequential per-frame update."""
         self.net = net
         self.info = np.asarray(info, dtype=np.float32).copy()
         dev = torch.device(net._device)
@@ -144,6 +163,9 @@ class TrainStepRunner:
         self.key = (height, width, channels, self.gt_cap, tuple(float(v) for v in self.info))
         self.bn_modules = [m for m in net.modules()
                            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training and m.track_running_stats]
+        self.bn_private = None
+        if defer_bn_stats and self.bn_modules:
+            self.bn_private = {id(m): (torch.zeros_like(m.running_mean), torch.zeros_like(m.running_var)) for m in self.bn_modules}
         from .. import ops
         # warm-up / capture frame: zeros with ONE plausible box, so that the target layers see a regular problem
         self._fill_placeholder_gt(height, width)
@@ -187,11 +209,13 @@ class TrainStepRunner:
         if debug_dump:
             self.graph.enable_debug_mode()
         self.inline = bool(inline)
+        autograd_ops.BN_STAT_SINK = self.bn_private
         try:
             with torch.cuda.graph(self.graph):
                 self.loss, self.counts = self._step()
         finally:
             autograd_ops.ASYNC_WGRAD, autograd_ops.WGRAD_ON_SIDE_STREAM, autograd_ops.GROUP_WGRAD = prev
+            autograd_ops.BN_STAT_SINK = None
         if debug_dump:
             self.graph.debug_dump(debug_dump)
         self.node_kinds, self.nodes, self.edges = graph_node_kinds(self.graph)
@@ -266,9 +290,36 @@ class TrainStepRunner:
             seed = self.net.next_uc_seed()
             self.uc_seed_dev.fill_(seed - (1 << 32) if seed >= (1 << 31) else seed)
         self.graph.replay()
-        for m in self.bn_modules:      # the captured launches updated the running statistics in place
-            m.__dict__['_frcnn_stats_version'] = m.__dict__.get('_frcnn_stats_version', 0) + 1
+        if self.bn_private is None:
+            for m in self.bn_modules:      # the captured launches updated the running statistics in place
+                m.__dict__['_frcnn_stats_version'] = m.__dict__.get('_frcnn_stats_version', 0) + 1
         return self.loss, self.counts
+
+    def fold_bn_stats(self):
+        """Deferred statistics (``defer_bn_stats``): apply this replay's batch statistics to the modules' running statistics
+        on the current stream - bn_fwd_final_kernel's expression (csrc/batchnorm.hip: two products and a sum, each rounded)
+        as multi-tensor launches over all layers: running = (1 - m) * running + m * stat, num_batches_tracked += 1."""
+        if self.bn_private is None:
+            return
+        if getattr(self, '_fold_groups', None) is None:
+            groups = {}
+            for m in self.bn_modules:
+                g = groups.setdefault(float(m.momentum), ([], [], []))
+                pm, pv = self.bn_private[id(m)]
+                g[0].extend((m.running_mean, m.running_var))
+                g[1].extend((pm, pv))
+                if m.num_batches_tracked is not None:
+                    g[2].append(m.num_batches_tracked)
+            self._fold_groups = groups
+        with torch.no_grad():
+            for mom, (running, stat, counts) in self._fold_groups.items():
+                keep = float(np.float32(1.0) - np.float32(mom))
+                torch._foreach_mul_(running, keep)
+                torch._foreach_add_(running, torch._foreach_mul(stat, float(np.float32(mom))))
+                if counts:
+                    torch._foreach_add_(counts, 1)
+        for m in self.bn_modules:
+            m.__dict__['_frcnn_stats_version'] = m.__dict__.get('_frcnn_stats_version', 0) + 1
 
 
 def after_optimizer_step(net):
@@ -286,11 +337,14 @@ class TrainPipeline:
     losses in submission order, ``flush`` adds the slots' gradients into ``param.grad`` (one multi-tensor add per slot)
     before the optimizer step.  Same arithmetic as the sequential loop except for the order in which the frames'
     gradients are summed.
-    MEASURED (profiles/r03_train_step.md): on the res101+FPN 1000x600 step 2 / 4 frames in flight run at 16.7 / 17.1 ms per
-    frame against 17.0 ms for one - no gain.  Unlike the inference frame, the captured training step already runs two
-    chains side by side (data-gradient chain || filter gradients: 24.6 -> 17.0 ms) and that fills the chip; what is left is
-    the efficiency of the individual small-GEMM kernels, not idle CUs.  The class stays as the host-side pipelining of the
-    solver loop (cfg.TRAIN.FRAMES_IN_FLIGHT, default 1)."""
+    MEASURED: forked graphs (filter gradients on a side stream) of different slots do not overlap - 2 / 4 frames in flight ran
+    at 16.7 / 17.1 ms per res101+FPN 1000x600 step against 17.0 ms for one (profiles/r03_train_step.md); single-chain graphs
+    (``inline``) do: 10.3 ms per step with 3 in flight against 14.7 ms one at a time (profiles/r04_bench.json).
+    cfg.TRAIN.FRAMES_IN_FLIGHT (default 3) is the solver's slot count.
+    BatchNorm on batch statistics (LiDAR backbone, FIXED_BLOCKS == -1): the slots' captured launches write their frame's
+    batch statistics to slot-private buffers and ``submit`` folds them into the modules' running statistics in SUBMISSION
+    order (``TrainStepRunner.fold_bn_stats`` chained by an event from frame to frame) - concurrent in-kernel updates of
+    the shared statistics would lose updates, and the reference updates them once per frame, in order."""
 
     def __init__(self, net, slots=4, max_graphs=8, inline=None):
         """``inline``: capture every slot's step as one chain so that the slots' replays overlap (default: when
@@ -312,6 +366,7 @@ class TrainPipeline:
         self.pending = [None] * self.slots         # per slot: [runner, event, loss value or None, counts or None]
         self.order = []                            # slots in submission order, not collected yet
         self.next_slot = 0
+        self.fold_event = None                     # end of the latest frame's running-statistics update (frame order)
 
     def _finish(self, s):
         ent = self.pending[s]
@@ -341,14 +396,14 @@ class TrainPipeline:
             torch.cuda.synchronize(self.dev)       # captures happen with the device idle
             try:
                 runner = TrainStepRunner(self.net, key[0], key[1], key[2], key[3], info, grads=self.grads[s],
-                                         autotune=not any(self.runners), inline=self.inline)
+                                         autotune=not any(self.runners), inline=self.inline, defer_bn_stats=True)
             except InlineCaptureUnsafe as e:
                 import warnings
                 warnings.warn("TrainPipeline: %s; capturing forked graphs instead (correct, but replays of different slots do "
                               "not overlap)" % e)
                 self.inline = False
                 runner = TrainStepRunner(self.net, key[0], key[1], key[2], key[3], info, grads=self.grads[s],
-                                         autotune=False, inline=False)
+                                         autotune=False, inline=False, defer_bn_stats=True)
             self.runners[s][key] = runner
             if self.inline:
                 # every newly captured single-chain runner proves that its replays reproduce each other (3 replays)
@@ -359,11 +414,21 @@ class TrainPipeline:
                     warnings.warn(str(e) + "  Falling back to forked graphs.")
                     self.inline = False
                     runner = self.runners[s][key] = TrainStepRunner(self.net, key[0], key[1], key[2], key[3], info,
-                                                                    grads=self.grads[s], autotune=False, inline=False)
+                                                                    grads=self.grads[s], autotune=False, inline=False,
+                                                                    defer_bn_stats=True)
         st = self.streams[s]
         st.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(st):
             runner.run(blobs)
+            if runner.bn_private is not None:
+                # BatchNorm on batch statistics: the slots' replays overlap, the running statistics advance one frame at a
+                # time in SUBMISSION order (the reference's sequential update, lib/model/train_val.py:458 per frame) - this
+                # frame's fold waits for the previous frame's
+                if self.fold_event is not None:
+                    st.wait_event(self.fold_event)
+                runner.fold_bn_stats()
+                self.fold_event = torch.cuda.Event()
+                self.fold_event.record(st)
             ev = torch.cuda.Event()
             ev.record(st)
         self.pending[s] = [runner, ev, None, None]
@@ -397,11 +462,19 @@ class TrainPipeline:
                 m.running_var.copy_(var)
                 if nbt is not None:
                     m.num_batches_tracked.copy_(nbt)
-        scale = max(float(a.abs().max()) for a in incs[0]) or 1.0
-        worst = max(float((a - b).abs().max()) for k in (1, 2) for a, b in zip(incs[0], incs[k])) / scale
+        # per tensor, relative to that tensor's own largest increment (a corrupted small-magnitude gradient must not hide
+        # behind the largest one); tensors whose increment is below 1e-6 of the global scale are compared on that floor
+        top = max(float(a.abs().max()) for a in incs[0]) or 1.0
+        worst, worst_i = 0.0, -1
+        for i, a in enumerate(incs[0]):
+            scale = max(float(a.abs().max()), 1e-6 * top)
+            dev = max(float((a - incs[k][i]).abs().max()) for k in (1, 2)) / scale
+            if not dev <= worst:          # NaN counts as the worst
+                worst, worst_i = dev, i
         if not worst <= 1e-3:
             raise RuntimeError("TrainPipeline: a replayed single-chain training graph does not reproduce its own gradients "
-                               "(deviation %.3e of their scale; node kinds %s)." % (worst, runner.node_kinds))
+                               "(gradient tensor %d deviates by %.3e of its own scale; node kinds %s)."
+                               % (worst_i, worst, runner.node_kinds))
 
     def in_flight(self):
         return len(self.order)

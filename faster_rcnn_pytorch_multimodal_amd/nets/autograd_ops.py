@@ -52,6 +52,9 @@ def _side_stream(device):
 # launches and 17.5 -> 16.2 ms of kernel time per FPN step) but they run AFTER their stage's data-gradient chain instead of
 # next to it, and the step is bound by that chain: 15.3-15.4 ms against 15.0-15.2 ms per replayed step (same-box A/B).
 GROUP_WGRAD = False
+# {id(BatchNorm module): (mean buffer, variance buffer)} while a training step with DEFERRED running statistics is captured
+# (model/train_graph.TrainStepRunner(defer_bn_stats=True)), else None: see _BnTrainFn.forward
+BN_STAT_SINK = None
 GROUP_WGRAD_SIZE = 24  # layers per grouped launch (<= ops.WGRAD_MAX_GROUPS): a whole ResNet stage
 _DEFER = {}          # key -> list of (x, d_conv, grad)
 _DEFER_AGE = {}      # key -> _wgrad calls since the key last came up
@@ -266,15 +269,22 @@ class _BnTrainFn(torch.autograd.Function):
     def forward(ctx, y, residual, gamma, beta, bn, relu):
         track = bn.track_running_stats and bn.running_mean is not None
         momentum = bn.momentum
-        if track and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
-            if momentum is None:                       # cumulative moving average (torch.nn.modules.batchnorm)
-                momentum = 1.0 / float(bn.num_batches_tracked)
+        sink = BN_STAT_SINK.get(id(bn)) if (track and BN_STAT_SINK is not None) else None
+        if sink is not None:
+            # deferred statistics (model/train_graph.TrainPipeline): this launch leaves the frame's batch mean / unbiased
+            # variance in the slot's private buffers - momentum 1 turns the kernel's update (1 - m) * old + m * stat into
+            # 0 * old + stat - and the running statistics are folded afterwards, in frame order
+            run_mean, run_var, momentum = sink[0], sink[1], 1.0
+        else:
+            run_mean, run_var = (bn.running_mean, bn.running_var) if track else (None, None)
+            if track and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+                if momentum is None:                       # cumulative moving average (torch.nn.modules.batchnorm)
+                    momentum = 1.0 / float(bn.num_batches_tracked)
         out, mean, invstd = ops.bn_train_fwd(y, gamma.detach() if gamma is not None else None,
                                              beta.detach() if beta is not None else None, bn.eps, momentum or 0.0,
-                                             bn.running_mean if track else None, bn.running_var if track else None,
-                                             residual, relu)
-        if track:
+                                             run_mean, run_var, residual, relu)
+        if track and sink is None:
             bn.__dict__['_frcnn_stats_version'] = bn.__dict__.get('_frcnn_stats_version', 0) + 1
         ctx.relu = relu
         ctx.has_res = residual is not None

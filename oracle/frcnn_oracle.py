@@ -1325,6 +1325,37 @@ class FpnNetOracle(nn.Module):
         h = F.relu(self.t_fc1(pool5.reshape(pool5.shape[0], -1)))          # NCHW flattening (C,7,7)
         return F.relu(self.t_fc3(F.relu(self.t_fc2(h))))
 
+    @torch.no_grad()
+    def test_frame(self, data, info, structured=None):
+        """TEST-mode frame of the FPN detector, the variant tools/test_net.py:196-197 switches on (cfg.USE_FPN for
+        evaluation): pyramid (lib/nets/fpn.py:56-68) -> RPN on p2 -> proposal_layer with the TEST settings 6000 / 300 / 0.7 on
+        all H/4 x W/4 x A anchors (lib/layer_utils/proposal_layer.py:18-57) -> LevelMapper + per-level RoIAlign
+        (lib/utils/torchpoolers.py:137-200) -> t_fc1..3 -> heads -> de-normalised decode.  Same return as
+        ImageNetOracle.test_frame; ``structured=(cls_score (1,2A,H,W), bbox_pred (1,H,W,4A))`` replaces the RPN head's output."""
+        image = torch.from_numpy(np.ascontiguousarray(data)).permute(0, 3, 1, 2).contiguous()
+        pyr = self.pyramid(image)
+        p2 = pyr[0]
+        a, (h, w) = self._num_anchors, p2.shape[2:]
+        anchors = torch.from_numpy(generate_anchors_pre(h, w, self._feat_stride, self._anchor_scales, self._anchor_ratios,
+                                                        float(info[6]))[0])
+        rpn = F.relu(self.rpn_net(p2))
+        cls_score = self.rpn_cls_score_net(rpn)
+        bbox_pred = self.rpn_bbox_pred_net(rpn).permute(0, 2, 3, 1).contiguous()
+        if structured is not None:
+            cls_score, bbox_pred = structured
+        prob = F.softmax(cls_score.view(1, 2, a * h, w), dim=1).view(1, 2 * a, h, w).permute(0, 2, 3, 1).contiguous()
+        rois, scores, dbg = proposal_layer(prob, bbox_pred, info, anchors, a, return_debug=True)
+        pool5, levels = self.pool(pyr, rois, image.shape[2:])
+        fc7 = self.tail(pool5)
+        cls_score_d, det_box = self.cls_score_net(fc7), self.bbox_pred_net(fc7)
+        cls_prob = F.softmax(cls_score_d, dim=1)
+        stds = torch.tensor(BBOX_NORMALIZE_STDS).repeat(self._num_classes).unsqueeze(0)
+        means = torch.tensor(BBOX_NORMALIZE_MEANS).repeat(self._num_classes).unsqueeze(0)
+        pred_boxes = bbox_transform_inv(rois[:, 1:5], det_box.mul(stds).add(means), float(info[6]))
+        self._dbg = {"anchors": anchors, "rpn_cls_prob": prob, "rpn_bbox_pred": bbox_pred, "rpn_cls_score": cls_score,
+                     "pyramid": pyr, "pool5": pool5, "fc7": fc7, "levels": levels, "bbox_pred": det_box, **dbg}
+        return cls_score_d, cls_prob, pred_boxes, rois, {}
+
     def train_forward(self, data, info, gt_boxes, generator=None, pre_nms=12000, post_nms=2000, proposals=None):
         """One TRAIN forward: returns the dict of losses (torch scalars with a graph) and the sampled targets.
         ``proposals=(rois (N,5), scores (N,1))`` replaces the proposal_layer output (tests: a random-init RPN never

@@ -1733,7 +1733,7 @@ def test_proposal_target_layer_sampling_properties(hip):
 # ------------------------------------------------------------------------------------------------
 # FPN detector: forward + backward of one training step (BASELINE config 4)
 # ------------------------------------------------------------------------------------------------
-def _build_fpn_pair(seed=21):
+def _build_fpn_pair(seed=21, cls_head_scale=1.0):
     from faster_rcnn_pytorch_multimodal_amd.model import config as C
     from faster_rcnn_pytorch_multimodal_amd.nets.imagenet import imagenet
     C.reset_cfg()
@@ -1743,6 +1743,7 @@ def _build_fpn_pair(seed=21):
     C.cfg.ENABLE_CUSTOM_TAIL = True                     # tools/trainval_net.py:326-330
     oracle = O.FpnNetOracle(num_classes=2)
     sd = O.seeded_state_dict(oracle, seed, bn_mode="tame")
+    sd["cls_score_net.weight"] = sd["cls_score_net.weight"] * cls_head_scale
     oracle.load_state_dict(sd, strict=True)
     oracle.set_trainable(1)
     net = imagenet(num_layers=101)
@@ -1821,6 +1822,113 @@ def test_fpn_train_step_matches_oracle_autograd(hip, h, w):
         checked += 1
     assert checked == 121          # layer2..4 convs (93) + FPN (12) + RPN (6) + heads (4) + tail (6)
     print("fpn train step: %d parameter gradients checked, worst relative L2 error %.2e" % (checked, worst))
+    C.reset_cfg()
+
+
+def _box_bounds_against_oracle(pred_boxes, pb_r, rois_r, what):
+    """The decoded-box bar of tests/test_timed_path.py: <= 1e-4 px where the box scale max(diagonal, |coordinate|) is
+    <= 128 px, <= 12 ulp of that scale beyond (two correct fp32 evaluations of roi + delta x diagonal)."""
+    rw, rh = rois_r[:, 3] - rois_r[:, 1] + 1.0, rois_r[:, 4] - rois_r[:, 2] + 1.0
+    diag = torch.sqrt(rw * rw + rh * rh)
+    diff = (pred_boxes - pb_r).abs()
+    scale = torch.maximum(diag, pb_r.abs().max(1).values)
+    ulp = torch.from_numpy(np.spacing(scale.numpy().astype(np.float32)))
+    small = scale <= 128.0
+    worst_small = float(diff[small].max()) if small.any() else 0.0
+    worst_ulp = float((diff[~small] / ulp[~small, None]).max()) if (~small).any() else 0.0
+    print("%s: |pred_boxes - oracle| %.3e px on the %d boxes of scale <= 128 px, %.2f ulp(box scale) on the %d larger ones"
+          % (what, worst_small, int(small.sum()), worst_ulp, int((~small).sum())))
+    assert worst_small <= 1e-4, "%s: boxes up to 128 px differ by %.3e px" % (what, worst_small)
+    assert worst_ulp <= 12.0, "%s: large boxes differ by %.2f ulp of their scale" % (what, worst_ulp)
+
+
+@pytest.mark.parametrize("h,w", [(256, 320), (600, 1000)])
+def test_fpn_detector_test_mode_against_oracle(hip, h, w, nms_at_equal):
+    """The image detector on the FPN backbone in TEST mode - the variant tools/test_net.py:196-197 evaluates (cfg.USE_FPN):
+    pyramid (lib/nets/fpn.py:56-68), proposal_layer 6000 / 300 on p2's H/4 x W/4 x 25 anchors (937 500 at 1000x600),
+    LevelMapper + per-level RoIAlign (lib/utils/torchpoolers.py:137-200), t_fc1..3, heads, decode, per-class filter -
+    against O.FpnNetOracle.test_frame / O.frame_detect.  Structured RPN logits on both sides make the
+    ranking well-conditioned, so the COMPOSED device path is held to: proposal indices bit-exact, level map identical, RoIs /
+    class probabilities / regression deltas / scores within 1e-4, decoded boxes within the bounds of tests/test_timed_path.py,
+    the same detections per class.  The stages are additionally re-run on the oracle's intermediate tensors, and the frame
+    is replayed as a captured hipGraph (FrameRunner) and must equal the eager record bit for bit."""
+    import bench
+    from faster_rcnn_pytorch_multimodal_amd.layer_utils.proposal_layer import proposal_layer_device
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.model.frame_graph import FrameRunner
+    from faster_rcnn_pytorch_multimodal_amd.model.test import detect_frame_device
+    from faster_rcnn_pytorch_multimodal_amd.utils.filter_predictions import filter_and_draw_prep
+    net, oracle = _build_fpn_pair(seed=23, cls_head_scale=2.0)
+    net.eval()
+    a, thresh, max_dets = 25, 0.1, 100
+    data = (np.random.default_rng(31).standard_normal((1, h, w, 3)) * 50).astype(np.float32)
+    info = np.array([0, w, 0, h, 0, 0, 1.0], np.float32)
+    ph, pw = (h + 3) // 4, (w + 3) // 4
+    cls, box = bench.structured_rpn(7, ph, pw, a)
+    cs_r, cp_r, pb_r, rois_r, _ = oracle.test_frame(data, info, (cls, box))
+    d = oracle._dbg
+    assert d["scores"].shape[0] == ph * pw * a and len(torch.unique(d["levels"])) >= 3
+    _, boxes_r, pbc_r = O.filter_and_draw_prep(rois_r, cp_r, pb_r, info, 2, thresh)
+    ref = [O.max_dets_cut(b, max_dets) for b in boxes_r]                  # == O.frame_detect (lib/model/test.py:68-93,210-221)
+    assert len(ref[1]) >= 10
+    # ---- the composed device path (eager), RPN output injected ------------------------------------------------------
+    rpn_dev = bench.fuse_rpn(cls, box).to(DEV)
+    net._rpn_override = rpn_dev
+    try:
+        cs, cp, pb, rois, _ = net.test_frame(data, info)
+        p = dict(net._predictions)
+        pyr = [f.clone() for f in net._pyramid]
+        dets, counts = detect_frame_device(net, torch.from_numpy(data).to(DEV), info, thresh, max_dets, max_dets)
+        dets, counts = dets.clone(), counts.clone()
+    finally:
+        net._rpn_override = None
+    assert net._feat_stride == 4 and net._anchors.shape[0] == ph * pw * a
+    for lvl, (mine, want) in enumerate(zip(pyr, d["pyramid"])):
+        _close_feat(mine.cpu().permute(0, 3, 1, 2).numpy(), want.numpy(), "p%d" % (lvl + 2), 5e-5)
+    np.testing.assert_array_equal(net._anchors.cpu().numpy(), d["anchors"].numpy())
+    n = int(p["rois_count"].item())
+    assert n == rois_r.shape[0] == rois.shape[0]
+    assert torch.equal(p["rpn_order"][p["rpn_keep"][:n]].cpu(), d["order"][d["keep"]]), "proposal indices differ"
+    np.testing.assert_allclose(rois.cpu().numpy(), rois_r.numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_array_equal(p["roi_levels"][:n].cpu().numpy(), d["levels"].numpy())
+    np.testing.assert_allclose(cp.cpu().numpy(), cp_r.numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(p["bbox_pred"][:n].cpu().numpy(), d["bbox_pred"].numpy(), rtol=0, atol=1e-4)
+    _box_bounds_against_oracle(pb.cpu(), pb_r, rois_r, "FPN TEST %dx%d" % (w, h))
+    # detection records of the composed path against O.frame_detect
+    dets_h, counts_h = dets.cpu().numpy(), counts.cpu().numpy()
+    for j in range(1, 2):
+        assert int(counts_h[j]) == len(ref[j]), "class %d: %d detections vs oracle %d" % (j, int(counts_h[j]), len(ref[j]))
+        g = dets_h[j, :len(ref[j])]
+        assert float(np.abs(g[:, 4] - ref[j][:, 4]).max()) <= 1e-4
+        assert float(np.abs(g[:, :4] - ref[j][:, :4]).max()) <= 1e-3
+    # ---- the same frame as a captured hipGraph --------------------------------------------------------------------
+    runner = FrameRunner(net, h, w, 3, info, thresh, max_dets, autotune=False, rpn_override_shape=tuple(rpn_dev.shape))
+    for _ in range(2):
+        g_d, g_c = runner.run(torch.from_numpy(data).to(DEV), rpn=rpn_dev, poison=True)
+        torch.cuda.synchronize()
+        assert torch.equal(g_c, counts) and torch.equal(g_d, dets)
+    # ---- stage by stage on the ORACLE's intermediate tensors -------------------------------------------------------------
+    fg = d["rpn_cls_prob"][..., a:].contiguous().view(-1).to(DEV)
+    res = proposal_layer_device(d["anchors"].to(DEV), info, a, 6000, 300, 0.7, rpn_cls_prob_fg=fg,
+                                rpn_bbox_pred=d["rpn_bbox_pred"].reshape(-1, 4).contiguous().to(DEV))
+    assert int(res.count.item()) == n and torch.equal(res.order[res.keep_idx[:n]].cpu(), d["order"][d["keep"]])
+    with torch.no_grad():
+        net._mode = "TEST"
+        net._pyramid = [f.permute(0, 2, 3, 1).contiguous().to(DEV) for f in d["pyramid"]]
+        net._frame_scale = 1.0
+        net._predictions = {"rois": rois_r.contiguous().to(DEV)}
+        pooled = net._crop_pool_layer(None, rois_r.contiguous().to(DEV))
+        np.testing.assert_array_equal(net._predictions["roi_levels"].cpu().numpy(), d["levels"].numpy())
+        _close_feat(pooled.cpu().numpy(), d["pool5"].numpy(), "pool5", 2e-5)
+        fc7 = net._head_to_tail(pooled)
+        _close_feat(fc7.cpu().numpy(), d["fc7"].numpy(), "fc7", 5e-5)
+        cls_prob, bbox_pred = net._region_classification(fc7)
+    np.testing.assert_allclose(cls_prob.cpu().numpy(), cp_r.numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(bbox_pred.cpu().numpy(), d["bbox_pred"].numpy(), rtol=0, atol=1e-4)
+    # per-class filter on the oracle's probabilities / boxes: identical detections
+    _, got_boxes, _ = filter_and_draw_prep(rois_r.to(DEV), cp_r.contiguous().to(DEV), pb_r.contiguous().to(DEV), {}, info, 2,
+                                           thresh, "image")
+    np.testing.assert_array_equal(np.asarray(got_boxes[1]), boxes_r[1])
     C.reset_cfg()
 
 

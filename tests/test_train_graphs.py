@@ -196,3 +196,56 @@ def test_solver_validation_replays_captured_frames(hip, tmp_path):
     assert torch.equal(out_g[1], out_e[1]) and torch.equal(out_g[3], out_e[3]) and torch.equal(out_g[4], out_e[4])
     assert net.training                                             # run_eval put the module back into train() mode
     C.reset_cfg()
+
+
+def test_train_pipeline_updates_batchnorm_statistics_in_frame_order(hip):
+    """BatchNorm on batch statistics (LiDAR layer2/3, lib/nets/lidarnet.py:152-175) with three captured steps in flight
+    (cfg.TRAIN.FRAMES_IN_FLIGHT, the solver's default): the slots' replays overlap, so the running statistics must not be
+    read-modify-written by the captured launches themselves (lost updates, lost counts).  Every slot leaves its frame's batch
+    statistics in private buffers and the pipeline folds them in submission order - after 7 strongly different frames the
+    running statistics and num_batches_tracked equal those of the sequential eager loop (the reference's per-frame update)."""
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.model.train_graph import TrainPipeline
+    net_e, oracle = T._build_lidar_pair(seed=9)
+    net_p, _ = T._build_lidar_pair(seed=9)
+    data, info, gt, _, _, _ = T._lidar_train_case(oracle)
+    for n in (net_e, net_p):
+        n.train()
+    frames = [{"data": data * (1.0 + 0.6 * it), "info": info, "gt_boxes": (gt, gt[:2], gt[1:4])[it % 3],
+               "gt_boxes_dc": np.zeros((0, 4), np.float32)} for it in range(7)]
+    pipe = TrainPipeline(net_p, slots=3)
+    torch.manual_seed(91)
+    for b in frames:
+        if pipe.in_flight() >= pipe.slots:
+            pipe.collect()
+        pipe.submit(b)
+    assert all(r.bn_private is not None for slot in pipe.runners for r in slot.values())
+    while pipe.in_flight():
+        loss, _ = pipe.collect()
+        assert np.isfinite(loss)
+    pipe.flush()
+    torch.cuda.synchronize()
+    opt = torch.optim.SGD([p for p in net_e.parameters() if p.requires_grad], lr=1e-4)
+    opt.zero_grad(set_to_none=False)
+    torch.manual_seed(91)                                     # the same sampling seeds, frame by frame
+    for b in frames:
+        net_e.train_step(b, opt, update_weights=False)
+    torch.cuda.synchronize()
+    checked = equal = 0
+    for (k, be), (_, bp) in zip(net_e.named_buffers(), net_p.named_buffers()):
+        if k.endswith("num_batches_tracked"):
+            assert int(be) == int(bp), (k, int(be), int(bp))
+            if int(be):
+                assert int(be) == len(frames), (k, int(be))
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            checked += 1
+            equal += int(torch.equal(be, bp))
+            assert torch.allclose(be, bp, rtol=1e-5, atol=1e-7), (k, float((be - bp).abs().max()))
+    moved = sum(int(m.num_batches_tracked) > 0 for m in net_p.modules() if isinstance(m, torch.nn.BatchNorm2d))
+    assert moved >= 20 and checked >= 2 * moved
+    print("pipeline vs sequential BatchNorm statistics: %d tensors compared, %d bit-equal, %d layers on batch statistics"
+          % (checked, equal, moved))
+    # the gradients of the pseudo batch agree as well (sum over the slots vs sequential accumulation)
+    worst, name = _grad_dev(net_e, net_p)
+    assert worst <= 5e-3, (name, worst)
+    C.reset_cfg()
