@@ -1151,7 +1151,8 @@ extern "C" int frcnn_conv2d_plan_algo(int n, int h, int w, int c, int k, int r, 
 }
 
 extern "C" int frcnn_conv2d_set_autotune(int enable) {
-  g_autotune = enable ? 1 : 0;
+  FRCNN_REQUIRE(enable >= 0 && enable <= 2, "conv2d_set_autotune: 0 off, 1 time each candidate alone, 2 time it under load");
+  g_autotune = enable;
   return FRCNN_OK;
 }
 
@@ -1488,6 +1489,31 @@ size_t plan_ws_bytes(const Plan& pl, const ConvParams& p, long M, int k) {
   return pl.splits > 1 ? (size_t)pl.splits * M * k * sizeof(float) : 0;
 }
 
+// frcnn_conv2d_set_autotune(2): candidates are timed UNDER LOAD - kLoadCopies launches of the candidate in flight at once,
+// one per stream (the caller's + three of the library's own).  The product keeps four frames in flight on four streams
+// (model/frame_graph.FramePool), where what counts is the chip time a plan takes away from the other frames' kernels, not
+// the latency of one launch on an idle chip: timed alone, a grid of many small tiles that fills 256 CUs once beats the
+// larger tiles whose matrix pipe runs at 1.5x the efficiency; with four copies competing the ranking is by throughput.
+// The copies read and write the SAME tensors: they compute identical values, so the races are between equal stores.
+constexpr int kLoadCopies = 4;
+struct LoadStreams {
+  hipStream_t s[kLoadCopies - 1];
+  hipEvent_t done[kLoadCopies - 1];
+  bool ok = false;
+};
+LoadStreams& load_streams() {
+  static LoadStreams ls;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    bool ok = true;
+    for (int j = 0; j < kLoadCopies - 1 && ok; ++j)
+      ok = hipStreamCreateWithFlags(&ls.s[j], hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&ls.done[j], hipEventDisableTiming) == hipSuccess;
+    ls.ok = ok;
+  });
+  return ls;
+}
+
 // time every candidate plan on the caller's tensors; returns false when tuning is not possible here
 bool tune_plan(const ConvParams& p, long M, int k, const float* scale, const float* shift, const float* residual,
                float* y, int relu, void* ws, size_t ws_bytes, hipStream_t stream, bool allow_split, bool wino, Plan* best) {
@@ -1515,6 +1541,11 @@ bool tune_plan(const ConvParams& p, long M, int k, const float* scale, const flo
     }
   }
   std::vector<float> best_of(cands.size(), 1e30f);
+  LoadStreams* ls = nullptr;
+  if (g_autotune == 2) {
+    ls = &load_streams();
+    if (!ls->ok) ls = nullptr;     // no extra streams: fall back to timing alone
+  }
   for (int pass = 0; pass < 2; ++pass) {
     for (size_t ci = 0; ci < cands.size(); ++ci) {
       const Plan& pl = cands[ci];
@@ -1524,7 +1555,20 @@ bool tune_plan(const ConvParams& p, long M, int k, const float* scale, const flo
       (void)hipEventRecord(e0, stream);
       const int reps = 3;
       bool ok = true;
-      for (int i = 0; i < reps && ok; ++i) ok = launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, stream) == FRCNN_OK;
+      if (ls) {
+        for (int j = 0; j < kLoadCopies - 1; ++j) (void)hipStreamWaitEvent(ls->s[j], e0, 0);
+        for (int i = 0; i < reps && ok; ++i) {
+          ok = launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, stream) == FRCNN_OK;
+          for (int j = 0; j < kLoadCopies - 1 && ok; ++j)
+            ok = launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, ls->s[j]) == FRCNN_OK;
+        }
+        for (int j = 0; j < kLoadCopies - 1; ++j) {      // the caller's stream ends the region when every copy is done
+          (void)hipEventRecord(ls->done[j], ls->s[j]);
+          (void)hipStreamWaitEvent(stream, ls->done[j], 0);
+        }
+      } else {
+        for (int i = 0; i < reps && ok; ++i) ok = launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, stream) == FRCNN_OK;
+      }
       (void)hipEventRecord(e1, stream);
       if (hipEventSynchronize(e1) != hipSuccess || !ok) continue;
       float ms = 0.f;

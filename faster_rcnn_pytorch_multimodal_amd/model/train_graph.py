@@ -165,7 +165,9 @@ class TrainStepRunner:
                            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training and m.track_running_stats]
         self.bn_private = None
         if defer_bn_stats and self.bn_modules:
-            self.bn_private = {id(m): (torch.zeros_like(m.running_mean), torch.zeros_like(m.running_var)) for m in self.bn_modules}
+            # [mean, unbiased variance, "the captured step launched this module"]
+            self.bn_private = {id(m): [torch.zeros_like(m.running_mean), torch.zeros_like(m.running_var), False]
+                               for m in self.bn_modules}
         from .. import ops
         # warm-up / capture frame: zeros with ONE plausible box, so that the target layers see a regular problem
         self._fill_placeholder_gt(height, width)
@@ -304,8 +306,10 @@ class TrainStepRunner:
         if getattr(self, '_fold_groups', None) is None:
             groups = {}
             for m in self.bn_modules:
+                pm, pv, used = self.bn_private[id(m)]
+                if not used:          # a train()-mode module the step never calls keeps its statistics, as in the eager step
+                    continue
                 g = groups.setdefault(float(m.momentum), ([], [], []))
-                pm, pv = self.bn_private[id(m)]
                 g[0].extend((m.running_mean, m.running_var))
                 g[1].extend((pm, pv))
                 if m.num_batches_tracked is not None:
@@ -319,7 +323,8 @@ class TrainStepRunner:
                 if counts:
                     torch._foreach_add_(counts, 1)
         for m in self.bn_modules:
-            m.__dict__['_frcnn_stats_version'] = m.__dict__.get('_frcnn_stats_version', 0) + 1
+            if self.bn_private[id(m)][2]:
+                m.__dict__['_frcnn_stats_version'] = m.__dict__.get('_frcnn_stats_version', 0) + 1
 
 
 def after_optimizer_step(net):

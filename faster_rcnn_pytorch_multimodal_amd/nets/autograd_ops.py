@@ -275,6 +275,7 @@ class _BnTrainFn(torch.autograd.Function):
             # variance in the slot's private buffers - momentum 1 turns the kernel's update (1 - m) * old + m * stat into
             # 0 * old + stat - and the running statistics are folded afterwards, in frame order
             run_mean, run_var, momentum = sink[0], sink[1], 1.0
+            sink[2] = True          # this module really runs in the captured step (layer4's BatchNorms of the LiDAR net do not)
         else:
             run_mean, run_var = (bn.running_mean, bn.running_var) if track else (None, None)
             if track and bn.num_batches_tracked is not None:

@@ -9,6 +9,8 @@ Layouts: activations NHWC ``(N, H, W, C)`` contiguous fp32, filters KRSC ``(K, R
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _hip
@@ -61,11 +63,17 @@ def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+# what set_conv_autotune(True) means: 1 = every candidate plan is timed alone on an idle chip, 2 = under load (four launches
+# of the candidate in flight on four streams: ranked by throughput, the objective of the four-frames-in-flight schedule)
+AUTOTUNE_LEVEL = int(os.environ.get('FRCNN_AUTOTUNE_LEVEL', '1'))
+
+
 def set_conv_autotune(enable):
     """Turn the convolution plan autotuner on/off (frcnn_conv2d_set_autotune): tune during eager warm-up frames,
-    the cached plans are then used inside captured graphs."""
+    the cached plans are then used inside captured graphs.  ``True`` = AUTOTUNE_LEVEL; 1 / 2 select the level."""
     global _CONV_AUTOTUNE
-    _hip.check(_hip.load().frcnn_conv2d_set_autotune(int(bool(enable))), "frcnn_conv2d_set_autotune")
+    level = (AUTOTUNE_LEVEL if enable is True else int(enable)) if enable else 0
+    _hip.check(_hip.load().frcnn_conv2d_set_autotune(level), "frcnn_conv2d_set_autotune")
     _CONV_AUTOTUNE = bool(enable)
 
 
@@ -181,7 +189,7 @@ def conv2d_nhwc(x, w_krsc, scale=None, shift=None, residual=None, stride=1, pad=
                    "frcnn_conv2d_fwd")
     if PROFILE is not None:
         PROFILE.append({"n": n, "h": h, "w": w, "c": c, "k": k, "r": r, "s": s, "stride": stride, "pad": pad,
-                        "flops": 2.0 * n * ho * wo * k * r * s * c})
+                        "residual": residual is not None, "relu": bool(relu), "flops": 2.0 * n * ho * wo * k * r * s * c})
     if FLOPS is not None:
         _log_flops('fwd', 2.0 * n * ho * wo * k * r * s * c,
                    residual is None and winograd_eligible(k, r, s, c, stride, pad) and _CONV_ALGO_MODE != 1 and
