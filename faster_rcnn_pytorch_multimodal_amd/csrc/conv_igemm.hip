@@ -76,6 +76,7 @@ struct ConvParams {
   int wiH, wiW, wth, wtw;
   int epi_lds;   // 1: the register-staged kernels transpose their accumulator tiles through LDS before storing (conv_epilogue_lds)
   int kloop;     // 1: the 64x64 register-staged kernel runs its hand-interleaved K-step (kstep_il); 0: the compiler-scheduled one
+  unsigned xbytes, wbytes;   // byte range of (a group's) activations / filter for the buffer-load kernel (0: range >= 2 GB, kernel not usable)
   const float* zero;   // device address of g_zero_page (resolved once on the host: a kernel argument costs no s_getpc / s_load in the K loop)
 };
 
@@ -984,6 +985,199 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma2_f32(const ConvParams p
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA through BUFFER loads (buffer_load_dwordx4 ... lds), three stages, any 4- or 8-wave tile: written for the small
+// tiles, above all the 64x64 tile whose waves own ONE 32x32 accumulator.
+//
+// Why (profiles/r05_mfma_chain.txt, profiles/r05_conv_pmc_probe.md): on gfx950 nothing a wave issues hides behind its own
+// fp32 MFMAs for free - beside a dependent v_mfma_f32_32x32x2_f32 chain one wave per SIMD pays ~7 cycles per v_fma, ~5 per
+// SALU instruction, ~66 per ds_write_b128 and ~85 per global_load_dwordx4 of MFMA time.  The register-staged 64x64 kernel
+// issues, per 16 MFMAs (1024 cycles), 4 global loads + 4 ds_write_b128 + ~27 VALU + ~25 SALU instructions: a wave alone on
+// its SIMD keeps the matrix pipe busy 53 % of its life, and 2.7 such waves per SIMD only reach 50 %.  This kernel removes the
+// instructions instead of rescheduling them:
+//   * tiles go global -> LDS by DMA: no VGPR staging, no ds_write pass, no vmcnt -> ds_write dependency;
+//   * addresses are  buffer resource (SGPRs) + per-lane byte offset (VGPR, constant while the tap is) + a scalar offset that
+//     advances with the K-step: ZERO vector instructions per K-step on a 1x1 layer (a 3x3 layer recomputes its per-lane
+//     offsets once per tap, i.e. every C/32 steps);
+//   * out-of-range lanes (padding taps, M / K tails) carry the offset 2^31: the buffer's range check returns zeros, no
+//     zero page, no select.  (Activation and filter ranges must be < 2 GB: the host falls back to the other kernels.)
+// LDS layout, XOR swizzle, k order and epilogue are those of conv_igemm_dma_f32: results are bit-identical to every other
+// kernel for split_k == 1.
+// ------------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN, (TM * TN == 1) ? 3 : 2) void conv_igemm_buf_f32(const ConvParams p) {
+  constexpr int NW = WM * WN;
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr int PA = BM / (8 * NW), PB = BN / (8 * NW);   // DMA instructions (8 rows of 128 bytes each) per wave per K-step
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must be a multiple of the DMA pass");
+  constexpr int STAGE = (BM + BN) * 32;                   // floats per stage
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][BM + BN][32]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wr = wave / WN, wc = wave % WN;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  int tile_m, tile_n;
+  tile_coords(tile, p.tiles_m, p.tiles_n, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int step_begin = blockIdx.z * p.steps_per_split;
+  const int step_end = min(step_begin + p.steps_per_split, p.ksteps);
+  const int nsteps = step_end - step_begin;
+
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x + (size_t)blockIdx.y * p.gx), 0, (int)p.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.w + (size_t)blockIdx.y * p.gw), 0, (int)p.wbytes, 0x00020000);
+
+  // ---- per-lane sources: lane i of instruction j feeds row 8 (wave PA + j) + (i >> 3), physical chunk i & 7 -------------
+  const int lrow = lane >> 3, lchunk = lane & 7;
+  int a_pix[PA], a_hi0[PA], a_wi0[PA];      // byte offset of pixel (img, hi0, wi0), -1 for a row past M
+  unsigned a_swz[PA], vA[PA], vB[PB];
+#pragma unroll
+  for (int j = 0; j < PA; ++j) {
+    const int row = (wave * PA + j) * 8 + lrow;
+    const int m = m0 + row;
+    a_swz[j] = (unsigned)((lchunk ^ ((row >> 1) & 7)) * 16);
+    if (m < p.M) {
+      const int img = m / (p.Ho * p.Wo);
+      const int rem = m - img * p.Ho * p.Wo;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      a_hi0[j] = ho * p.stride - p.pad;
+      a_wi0[j] = wo * p.stride - p.pad;
+      a_pix[j] = ((img * p.H + a_hi0[j]) * p.W + a_wi0[j]) * p.C * 4;
+    } else {
+      a_hi0[j] = -(1 << 20);
+      a_wi0[j] = 0;
+      a_pix[j] = 0;
+    }
+    vA[j] = OOB;
+  }
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const int row = (wave * PB + j) * 8 + lrow;
+    const int n = n0 + row;
+    vB[j] = n < p.K ? (unsigned)(n * p.Ktot * 4 + (lchunk ^ ((row >> 1) & 7)) * 16) : OOB;
+  }
+  int tr, ts, tc;
+  {
+    const int kf = step_begin * BK;
+    const int tap = kf / p.C;
+    tc = kf - tap * p.C;
+    tr = tap / p.S;
+    ts = tap - tr * p.S;
+  }
+  bool new_tap = true;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  // issue() is called for consecutive steps (the tap state advances by one step per call)
+  auto issue = [&](int step, int stage) {
+    float* sA = smem + stage * STAGE + (wave * PA) * 8 * 32;
+    float* sB = smem + stage * STAGE + BM * 32 + (wave * PB) * 8 * 32;
+    if (new_tap) {                          // uniform: once per tap (once per kernel on a 1x1 layer)
+      const int toff = (tr * p.W + ts) * p.C * 4;
+#pragma unroll
+      for (int j = 0; j < PA; ++j) {
+        const int hi = a_hi0[j] + tr, wi = a_wi0[j] + ts;
+        const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        vA[j] = ok ? (unsigned)(a_pix[j] + toff) + a_swz[j] : OOB;
+      }
+    }
+    const int sa = tc * 4, sb = step * (BK * 4);
+#pragma unroll
+    for (int j = 0; j < PA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(sA + j * 8 * 32), 16, (int)vA[j], sa, 0, 0);
+#pragma unroll
+    for (int j = 0; j < PB; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr)(sB + j * 8 * 32), 16, (int)vB[j], sb, 0, 0);
+    tc += BK;
+    new_tap = tc == p.C;
+    if (new_tap) {
+      tc = 0;
+      if (++ts == p.S) { ts = 0; ++tr; }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment reads: row = tile row of lane & 31, logical chunk 2 kk + (lane >> 5), XOR-swizzled; the four chunk offsets of a
+  // row are kept in registers (no address arithmetic in the loop)
+  const int lh = lane >> 5;
+  int fa_off[TM][4], fb_off[TN][4];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row = (wr * TM + i) * 32 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) fa_off[i][kk] = row * 32 + (((2 * kk + lh) ^ ((row >> 1) & 7)) << 2);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int row = (wc * TN + j) * 32 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) fb_off[j][kk] = BM * 32 + row * 32 + (((2 * kk + lh) ^ ((row >> 1) & 7)) << 2);
+  }
+  f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+  auto read_frags = [&](f32x4* fa, f32x4* fb, int stage, int kk) {
+    const float* base = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(base + fa_off[i][kk]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(base + fb_off[j][kk]);
+  };
+  auto mma = [&](const f32x4* fa, const f32x4* fb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][q], fa[i][q], acc[i][j], 0, 0, 0);
+  };
+
+  // Schedule of one K-step as in conv_igemm_dma_f32: the barrier sits in the MIDDLE of the step (stage s+1 has landed for
+  // every wave and every wave is past step s-1), the loads of step s+2 are issued right behind it.
+  if (nsteps > 0) issue(step_begin, 0);
+  if (nsteps > 1) issue(step_begin + 1, 1);
+  if (nsteps > 0) {
+    if (nsteps > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(fa0, fb0, 0, 0);
+  }
+  int stage = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    const int next = stage == 2 ? 0 : stage + 1;
+    read_frags(fa1, fb1, stage, 1);
+    mma(fa0, fb0);
+    read_frags(fa0, fb0, stage, 2);
+    mma(fa1, fb1);
+    if (s + 1 < nsteps) {
+      // only the loads of step s+1 are outstanding here (step s+2 is issued below)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 2 < nsteps) issue(step_begin + s + 2, stage == 0 ? 2 : stage - 1);
+    }
+    read_frags(fa1, fb1, stage, 3);
+    mma(fa0, fb0);
+    if (s + 1 < nsteps) read_frags(fa0, fb0, next, 0);
+    mma(fa1, fb1);
+    stage = next;
+  }
+  if (p.epi_lds && (p.K & 3) == 0) {
+    __syncthreads();   // the last step has no barrier behind its fragment reads: every wave must be done with the stages
+    conv_epilogue_lds<TM, TN>(p, acc, m0, n0, wr, wc, lane, smem + wave * 32 * LDS_PITCH);
+  } else {
+    conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
+  }
+}
+
+
 // Split-K second pass: y = act((sum_z partial[z]) * scale + shift + res), slabs summed in z order.
 __global__ __launch_bounds__(256) void conv_splitk_epilogue(const float* __restrict__ partial, int splits,
                                                            size_t mk, int K, const float* scale,
@@ -1014,6 +1208,9 @@ constexpr TileCfg kTiles[] = {
     {1, 2, 2, 2, 1, 2},  // 64x128
     {1, 1, 2, 2, 1, 1},  // 64x64
     {2, 2, 2, 2, 2, 2},  // 128x128, 4 waves, LDS-DMA with two stages: two workgroups per CU (C % 32 == 0; else as index 2)
+    {1, 1, 2, 2, 1, 1},  // 64x64,  LDS-DMA through buffer loads, three stages (conv_igemm_buf_f32; C % 32 == 0 and < 2 GB operands, else as index 5)
+    {2, 1, 2, 2, 2, 1},  // 128x64, the same kernel (else as index 3)
+    {1, 2, 2, 2, 1, 2},  // 64x128, the same kernel (else as index 4)
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -1204,6 +1401,26 @@ int launch_conv_dma(const ConvParams& p, int splits, int groups, hipStream_t str
   return frcnn::check_launch("conv_igemm_dma_f32");
 }
 
+template <int WM, int WN, int TM, int TN>
+int launch_conv_buf(const ConvParams& p, int splits, int groups, hipStream_t stream) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr size_t lds = (size_t)3 * (BM + BN) * 32 * sizeof(float);
+  static std::atomic<bool> configured{false};   // idempotent attribute call: a race only repeats it
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_buf_f32<WM, WN, TM, TN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return frcnn::fail(FRCNN_ERR_LAUNCH, "conv: set LDS size: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, groups, splits);
+  hipEvent_t e0, e1;
+  if (prof_events(0, &e0, &e1, stream))
+    hipExtLaunchKernelGGL((conv_igemm_buf_f32<WM, WN, TM, TN>), grid, dim3(64 * WM * WN), (uint32_t)lds, stream, e0, e1, 0, p);
+  else
+    hipLaunchKernelGGL((conv_igemm_buf_f32<WM, WN, TM, TN>), grid, dim3(64 * WM * WN), lds, stream, p);
+  return frcnn::check_launch("conv_igemm_buf_f32");
+}
+
 int launch_conv_dma2(const ConvParams& p, int splits, int groups, hipStream_t stream) {
   constexpr size_t lds = (size_t)2 * (128 + 128) * 32 * sizeof(float);
   static std::atomic<bool> configured{false};   // idempotent attribute call: a race only repeats it
@@ -1257,7 +1474,7 @@ extern "C" int frcnn_conv2d_set_algo(int mode) {
 }
 
 extern "C" int frcnn_conv2d_set_staging(int use_lds_dma) {
-  FRCNN_REQUIRE(use_lds_dma >= 0 && use_lds_dma <= 2, "conv2d_set_staging: mode %d (0, 1 or 2)", use_lds_dma);
+  FRCNN_REQUIRE(use_lds_dma >= 0 && use_lds_dma <= 3, "conv2d_set_staging: mode %d (0 .. 3)", use_lds_dma);
   if (g_use_dma.exchange(use_lds_dma) != use_lds_dma) frcnn::bump_settings_epoch();
   return FRCNN_OK;
 }
@@ -1562,10 +1779,30 @@ int launch_gemm(ConvParams p, const Plan& pl, long M, int k, int groups, hipStre
       if (aligned && g_use_dma) rc = launch_conv_dma2(p, pl.splits, groups, stream);
       else FRCNN_CONV_CASE(2, 2, 2, 2);
       break;
-    case 3: FRCNN_CONV_CASE(2, 2, 2, 1); break;
-    case 4: FRCNN_CONV_CASE(2, 2, 1, 2); break;
+    case 3:
+      if (aligned && g_use_dma == 3 && p.xbytes && p.wbytes) rc = launch_conv_buf<2, 2, 2, 1>(p, pl.splits, groups, stream);
+      else FRCNN_CONV_CASE(2, 2, 2, 1);
+      break;
+    case 4:
+      if (aligned && g_use_dma == 3 && p.xbytes && p.wbytes) rc = launch_conv_buf<2, 2, 1, 2>(p, pl.splits, groups, stream);
+      else FRCNN_CONV_CASE(2, 2, 1, 2);
+      break;
+    case 7:
+      if (aligned && g_use_dma && p.xbytes && p.wbytes) rc = launch_conv_buf<2, 2, 1, 1>(p, pl.splits, groups, stream);
+      else if (aligned && p.kloop) rc = launch_conv<2, 2, 1, 1, true, false, true>(p, pl.splits, groups, stream);
+      else FRCNN_CONV_CASE(2, 2, 1, 1);
+      break;
+    case 8:
+      if (aligned && g_use_dma && p.xbytes && p.wbytes) rc = launch_conv_buf<2, 2, 2, 1>(p, pl.splits, groups, stream);
+      else FRCNN_CONV_CASE(2, 2, 2, 1);
+      break;
+    case 9:
+      if (aligned && g_use_dma && p.xbytes && p.wbytes) rc = launch_conv_buf<2, 2, 1, 2>(p, pl.splits, groups, stream);
+      else FRCNN_CONV_CASE(2, 2, 1, 2);
+      break;
     default:
-      if (aligned && p.kloop) rc = launch_conv<2, 2, 1, 1, true, false, true>(p, pl.splits, groups, stream);
+      if (aligned && g_use_dma == 3 && p.xbytes && p.wbytes) rc = launch_conv_buf<2, 2, 1, 1>(p, pl.splits, groups, stream);
+      else if (aligned && p.kloop) rc = launch_conv<2, 2, 1, 1, true, false, true>(p, pl.splits, groups, stream);
       else FRCNN_CONV_CASE(2, 2, 1, 1);
       break;
   }
@@ -1615,6 +1852,11 @@ int launch_winograd(const ConvParams& p, const Plan& pl, const float* scale, con
   q.epi_lds = p.epi_lds;
   q.kloop = p.kloop;
   q.zero = p.zero;
+  {
+    const size_t xb = q.gx * sizeof(float), wb = q.gw * sizeof(float);   // one transform component's slice
+    q.xbytes = xb < ((size_t)1 << 31) ? (unsigned)xb : 0;
+    q.wbytes = wb < ((size_t)1 << 31) ? (unsigned)wb : 0;
+  }
   Plan gp{pl.cfg, 1, q.ksteps};
   if (pl.fuse_in) {          // the GEMM reads the layer's input itself: no V tensor
     q.x = p.x;
@@ -1777,6 +2019,11 @@ int run_conv(const float* x, const float* wgt, const float* scale, const float* 
   p.wiH = p.wiW = p.wth = p.wtw = 0;
   p.epi_lds = g_epi_lds;
   p.kloop = g_kloop;
+  {
+    const size_t xb = (size_t)n * h * w * c * sizeof(float), wb = (size_t)k * p.Ktot * sizeof(float);
+    p.xbytes = xb < ((size_t)1 << 31) ? (unsigned)xb : 0;
+    p.wbytes = wb < ((size_t)1 << 31) ? (unsigned)wb : 0;
+  }
   p.zero = zero_page_address();
   if (!p.zero) return frcnn::fail(FRCNN_ERR_LAUNCH, "conv2d: cannot resolve the zero page's device address");
   FRCNN_REQUIRE((long)k * p.Ktot < (1L << 31), "conv2d: filter too large for int32 indexing");

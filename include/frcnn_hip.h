@@ -149,7 +149,9 @@ int frcnn_conv2d_import_plans(const int* in, int entries);
 
 /* Tuning / test hook: 1 (default) stages the 8-wave tiles with LDS-DMA (global_load_lds) when C % 32 == 0 (and the
  * autotuner may pick the two-stage LDS-DMA 128x128 tile, plan tile index 6), 0 uses the register-staged kernels
- * everywhere, 2 additionally runs a FORCED 128x128 tile (frcnn_conv2d_set_tile(2, 2)) on the two-stage LDS-DMA kernel.
+ * everywhere, 2 additionally runs a FORCED 128x128 tile (frcnn_conv2d_set_tile(2, 2)) on the two-stage LDS-DMA kernel,
+ * 3 runs the 64x64 / 128x64 / 64x128 tiles (forced, or plan tile indices 3, 4, 5) on the buffer-load LDS-DMA kernel
+ * (conv_igemm_buf_f32: plan tile indices 7, 8, 9 select it in every mode but 0).
  * Results are bit-identical for split_k = 1. */
 int frcnn_conv2d_set_staging(int use_lds_dma);
 

@@ -265,6 +265,63 @@ def test_conv2d_interleaved_kstep_is_bit_identical(hip, case):
 
 
 @pytest.mark.parametrize("case", [(1, 38, 63, 256, 1024, 1, 1, 0), (1, 38, 63, 1024, 256, 1, 1, 0), (1, 75, 125, 128, 128, 3, 1, 1),
+                                  (1, 9, 11, 32, 64, 1, 1, 0), (2, 9, 11, 96, 72, 1, 1, 0), (1, 10, 7, 128, 200, 1, 1, 0),
+                                  (1, 19, 32, 512, 512, 3, 2, 1), (3, 7, 7, 32, 36, 3, 1, 1), (1, 38, 62, 256, 512, 1, 2, 0),
+                                  (1, 5, 6, 288, 68, 1, 1, 0), (300, 7, 7, 512, 512, 1, 1, 0), (2, 13, 9, 64, 132, 5, 1, 2)])
+def test_conv2d_buffer_dma_kernel_is_bit_identical(hip, case):
+    """conv_igemm_buf_f32 (LDS-DMA through buffer loads: per-lane byte offsets + a scalar K-step offset, out-of-range lanes
+    zero-filled by the buffer's range check; 64x64, 128x64 and 64x128 tiles) against the register-staged kernels of the
+    same tiles: same k order -> identical bits.  Cases: padding taps of 3x3 / 5x5 filters (range-checked lanes), strides,
+    M and K tails, 1 .. 72 K-steps, split-K, residual + ReLU, the data-gradient forms, and the Winograd GEMM on these tiles."""
+    ops = _ops()
+    from faster_rcnn_pytorch_multimodal_amd import _hip
+    lib = _hip.load()
+    n, h, w, c, k, r, stride, pad = case
+    g = torch.Generator().manual_seed(5 * c + k)
+    x = torch.randn(n, h, w, c, generator=g).to(DEV)
+    wt = (torch.randn(k, r, r, c, generator=g) / (r * c ** 0.5)).to(DEV)
+    sc, sh = (torch.rand(k, generator=g) + 0.5).to(DEV), torch.randn(k, generator=g).to(DEV)
+    ho, wo = (h + 2 * pad - r) // stride + 1, (w + 2 * pad - r) // stride + 1
+    res = torch.randn(n, ho, wo, k, generator=g).to(DEV)
+    ksteps = r * r * c // 32
+    wino = ops.winograd_eligible(k, r, r, c, stride, pad)
+    outs = {}
+    try:
+        for staging in (0, 3):                                           # register-staged / buffer-load LDS-DMA
+            _hip.check(lib.frcnn_conv2d_set_staging(staging), "set_staging")
+            got = []
+            for tm, tn in ((1, 1), (2, 1), (1, 2)):
+                ops.set_conv_algo(1)
+                _hip.check(lib.frcnn_conv2d_set_tile(tm, tn), "set_tile")
+                got.append(ops.conv2d_nhwc(x, wt, sc, sh, res, stride=stride, pad=pad, relu=True, split_k=1))
+                got.append(ops.conv2d_nhwc(x, wt, None, None, None, stride=stride, pad=pad, relu=False, split_k=1))
+                if ksteps >= 4:
+                    got.append(ops.conv2d_nhwc(x, wt, sc, sh, None, stride=stride, pad=pad, relu=True, split_k=2))
+                if k % 4 == 0:
+                    wt_t = ops.conv2d_transpose_filter(wt)
+                    got.append(ops.conv2d_bwd_data(res, wt_t, (n, h, w, c), stride=stride, pad=pad))
+                if wino:                                                 # the grouped Winograd GEMM on this tile
+                    _hip.check(lib.frcnn_conv2d_set_tile(0, 0), "set_tile")
+                    code = {(1, 1): 5, (2, 1): 3, (1, 2): 4}[(tm, tn)] + 16
+                    ops.import_conv_plans([[n, h, w, c, k, r, r, stride, pad, 1, code, 1, (c + 31) // 32]])
+                    ops.set_conv_algo(0)
+                    got.append(ops.conv2d_nhwc(x, wt, sc, sh, None, stride=stride, pad=pad, relu=True))
+                    hip.frcnn_conv2d_clear_plans()
+            outs[staging] = got
+    finally:
+        _hip.check(lib.frcnn_conv2d_set_tile(0, 0), "set_tile")
+        _hip.check(lib.frcnn_conv2d_set_staging(1), "set_staging")
+        ops.set_conv_algo(0)
+        hip.frcnn_conv2d_clear_plans()
+    torch.cuda.synchronize()
+    assert len(outs[0]) == len(outs[3]) >= 6
+    for i, (a, b) in enumerate(zip(outs[0], outs[3])):
+        assert torch.equal(a, b), "output %d differs (max %.3e)" % (i, float((a - b).abs().max()))
+    ref = _conv_ref(x.cpu(), wt.cpu().permute(0, 3, 1, 2), sc.cpu(), sh.cpu(), res.cpu(), stride, pad, True)
+    _close_feat(outs[3][0].cpu().numpy(), ref.numpy(), "buffer-load kernel vs float64 reference", 1e-5)
+
+
+@pytest.mark.parametrize("case", [(1, 38, 63, 256, 1024, 1, 1, 0), (1, 38, 63, 1024, 256, 1, 1, 0), (1, 75, 125, 128, 128, 3, 1, 1),
                                   (2, 9, 11, 64, 2048, 1, 1, 0), (1, 19, 32, 512, 512, 3, 2, 1), (1, 13, 17, 32, 100, 3, 1, 1),
                                   (300, 7, 7, 512, 512, 1, 1, 0), (1, 38, 62, 256, 512, 1, 2, 0)])
 def test_conv2d_lds_transposed_epilogue_is_bit_identical(hip, case):
@@ -331,7 +388,7 @@ def test_conv2d_autotune_may_pick_winograd_and_plans_round_trip(hip):
         assert torch.equal(a, b)
         plans = ops.export_conv_plans()
         row = [r for r in plans if list(r[:10]) == [64, 7, 7, 256, 256, 3, 3, 1, 1, 1]]
-        assert len(row) == 1 and (row[0][10] >> 4) in (0, 1) and (row[0][10] & 15) < 6
+        assert len(row) == 1 and (row[0][10] >> 4) in (0, 1, 2) and (row[0][10] & 15) < 7      # 2 = Winograd with the fused input transform
         hip.frcnn_conv2d_clear_plans()
         ops.import_conv_plans(plans)
         c = ops.conv2d_nhwc(x, wt, stride=1, pad=1, relu=True)
