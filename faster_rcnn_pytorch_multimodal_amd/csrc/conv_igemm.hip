@@ -1211,6 +1211,9 @@ constexpr TileCfg kTiles[] = {
     {1, 1, 2, 2, 1, 1},  // 64x64,  LDS-DMA through buffer loads, three stages (conv_igemm_buf_f32; C % 32 == 0 and < 2 GB operands, else as index 5)
     {2, 1, 2, 2, 2, 1},  // 128x64, the same kernel (else as index 3)
     {1, 2, 2, 2, 1, 2},  // 64x128, the same kernel (else as index 4)
+    {2, 2, 2, 2, 2, 2},  // 128x128, the same kernel, 96 KB of LDS: one workgroup per CU (else as index 2)
+    {4, 2, 4, 2, 2, 2},  // 256x128, the same kernel, 8 waves (else as index 0)
+    {2, 4, 2, 4, 2, 2},  // 128x256, the same kernel, 8 waves (else as index 1)
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -1764,20 +1767,35 @@ int launch_gemm(ConvParams p, const Plan& pl, long M, int k, int groups, hipStre
                : launch_conv<WM_, WN_, TM_, TN_, false>(p, pl.splits, groups, stream)
   switch (pl.cfg) {
     case 0:
-      if (aligned && g_use_dma) rc = launch_conv_dma<4, 2>(p, pl.splits, groups, stream);
+      if (aligned && g_use_dma == 3 && p.xbytes && p.wbytes) rc = launch_conv_buf<4, 2, 2, 2>(p, pl.splits, groups, stream);
+      else if (aligned && g_use_dma) rc = launch_conv_dma<4, 2>(p, pl.splits, groups, stream);
       else FRCNN_CONV_CASE(4, 2, 2, 2);
       break;
     case 1:
-      if (aligned && g_use_dma) rc = launch_conv_dma<2, 4>(p, pl.splits, groups, stream);
+      if (aligned && g_use_dma == 3 && p.xbytes && p.wbytes) rc = launch_conv_buf<2, 4, 2, 2>(p, pl.splits, groups, stream);
+      else if (aligned && g_use_dma) rc = launch_conv_dma<2, 4>(p, pl.splits, groups, stream);
       else FRCNN_CONV_CASE(2, 4, 2, 2);
       break;
     case 2:
-      if (aligned && g_use_dma == 2) rc = launch_conv_dma2(p, pl.splits, groups, stream);   // test hook, see set_staging
+      if (aligned && g_use_dma == 3 && p.xbytes && p.wbytes) rc = launch_conv_buf<2, 2, 2, 2>(p, pl.splits, groups, stream);
+      else if (aligned && g_use_dma == 2) rc = launch_conv_dma2(p, pl.splits, groups, stream);   // test hook, see set_staging
       else FRCNN_CONV_CASE(2, 2, 2, 2);
       break;
     case 6:
       if (aligned && g_use_dma) rc = launch_conv_dma2(p, pl.splits, groups, stream);
       else FRCNN_CONV_CASE(2, 2, 2, 2);
+      break;
+    case 10:
+      if (aligned && g_use_dma && p.xbytes && p.wbytes) rc = launch_conv_buf<2, 2, 2, 2>(p, pl.splits, groups, stream);
+      else FRCNN_CONV_CASE(2, 2, 2, 2);
+      break;
+    case 11:
+      if (aligned && g_use_dma && p.xbytes && p.wbytes) rc = launch_conv_buf<4, 2, 2, 2>(p, pl.splits, groups, stream);
+      else FRCNN_CONV_CASE(4, 2, 2, 2);
+      break;
+    case 12:
+      if (aligned && g_use_dma && p.xbytes && p.wbytes) rc = launch_conv_buf<2, 4, 2, 2>(p, pl.splits, groups, stream);
+      else FRCNN_CONV_CASE(2, 4, 2, 2);
       break;
     case 3:
       if (aligned && g_use_dma == 3 && p.xbytes && p.wbytes) rc = launch_conv_buf<2, 2, 2, 1>(p, pl.splits, groups, stream);

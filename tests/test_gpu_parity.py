@@ -270,7 +270,7 @@ def test_conv2d_interleaved_kstep_is_bit_identical(hip, case):
                                   (1, 5, 6, 288, 68, 1, 1, 0), (300, 7, 7, 512, 512, 1, 1, 0), (2, 13, 9, 64, 132, 5, 1, 2)])
 def test_conv2d_buffer_dma_kernel_is_bit_identical(hip, case):
     """conv_igemm_buf_f32 (LDS-DMA through buffer loads: per-lane byte offsets + a scalar K-step offset, out-of-range lanes
-    zero-filled by the buffer's range check; 64x64, 128x64 and 64x128 tiles) against the register-staged kernels of the
+    zero-filled by the buffer's range check; every tile from 64x64 to 256x128) against the register-staged kernels of the
     same tiles: same k order -> identical bits.  Cases: padding taps of 3x3 / 5x5 filters (range-checked lanes), strides,
     M and K tails, 1 .. 72 K-steps, split-K, residual + ReLU, the data-gradient forms, and the Winograd GEMM on these tiles."""
     ops = _ops()
@@ -290,7 +290,7 @@ def test_conv2d_buffer_dma_kernel_is_bit_identical(hip, case):
         for staging in (0, 3):                                           # register-staged / buffer-load LDS-DMA
             _hip.check(lib.frcnn_conv2d_set_staging(staging), "set_staging")
             got = []
-            for tm, tn in ((1, 1), (2, 1), (1, 2)):
+            for tm, tn in ((1, 1), (2, 1), (1, 2), (2, 2), (4, 2), (2, 4)):
                 ops.set_conv_algo(1)
                 _hip.check(lib.frcnn_conv2d_set_tile(tm, tn), "set_tile")
                 got.append(ops.conv2d_nhwc(x, wt, sc, sh, res, stride=stride, pad=pad, relu=True, split_k=1))
@@ -302,7 +302,7 @@ def test_conv2d_buffer_dma_kernel_is_bit_identical(hip, case):
                     got.append(ops.conv2d_bwd_data(res, wt_t, (n, h, w, c), stride=stride, pad=pad))
                 if wino:                                                 # the grouped Winograd GEMM on this tile
                     _hip.check(lib.frcnn_conv2d_set_tile(0, 0), "set_tile")
-                    code = {(1, 1): 5, (2, 1): 3, (1, 2): 4}[(tm, tn)] + 16
+                    code = {(1, 1): 5, (2, 1): 3, (1, 2): 4, (2, 2): 2, (4, 2): 0, (2, 4): 1}[(tm, tn)] + 16
                     ops.import_conv_plans([[n, h, w, c, k, r, r, stride, pad, 1, code, 1, (c + 31) // 32]])
                     ops.set_conv_algo(0)
                     got.append(ops.conv2d_nhwc(x, wt, sc, sh, None, stride=stride, pad=pad, relu=True))
@@ -388,7 +388,7 @@ def test_conv2d_autotune_may_pick_winograd_and_plans_round_trip(hip):
         assert torch.equal(a, b)
         plans = ops.export_conv_plans()
         row = [r for r in plans if list(r[:10]) == [64, 7, 7, 256, 256, 3, 3, 1, 1, 1]]
-        assert len(row) == 1 and (row[0][10] >> 4) in (0, 1, 2) and (row[0][10] & 15) < 7      # 2 = Winograd with the fused input transform
+        assert len(row) == 1 and (row[0][10] >> 4) in (0, 1, 2) and (row[0][10] & 15) < 13      # 2 = Winograd with the fused input transform
         hip.frcnn_conv2d_clear_plans()
         ops.import_conv_plans(plans)
         c = ops.conv2d_nhwc(x, wt, stride=1, pad=1, relu=True)
