@@ -75,7 +75,6 @@ struct ConvParams {
   // blockIdx.y the transform component
   int wiH, wiW, wth, wtw;
   int epi_lds;   // 1: the register-staged kernels transpose their accumulator tiles through LDS before storing (conv_epilogue_lds)
-  int kloop;     // 1: the 64x64 register-staged kernel runs its hand-interleaved K-step (kstep_il); 0: the compiler-scheduled one
   unsigned xbytes, wbytes;   // byte range of (a group's) activations / filter for the buffer-load kernel (0: range >= 2 GB, kernel not usable)
   const float* zero;   // device address of g_zero_page (resolved once on the host: a kernel argument costs no s_getpc / s_load in the K loop)
 };
@@ -261,12 +260,9 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvParams& p, f32x16 (&
 __device__ float g_zero_page[64];
 
 // (the one-accumulator wave of the 64x64 tile is held to 128 VGPRs: four workgroups per CU, as its 36 KB of LDS allow)
-// ILV: the hand-interleaved K-step (kstep_il below) instead of the compiler-scheduled one; an instantiation of its own so that
-// neither form carries the other's registers.
-template <int WM, int WN, int TM, int TN, bool ALIGNED, bool WINO = false, bool ILV = false>
-__global__ __launch_bounds__(64 * WM * WN, ILV ? 4 : 2) void conv_igemm_f32(const ConvParams p) {
+template <int WM, int WN, int TM, int TN, bool ALIGNED, bool WINO = false>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_f32(const ConvParams p) {
   static_assert(!WINO || ALIGNED, "the fused Winograd input transform needs C % 32 == 0");
-  static_assert(!ILV || (ALIGNED && !WINO && TM == 1 && TN == 1), "the interleaved K-step is written for the one-accumulator wave");
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr int RPP = NT / 8;                // tile rows staged per pass (8 threads x 16 B cover one row)
@@ -460,140 +456,6 @@ __global__ __launch_bounds__(64 * WM * WN, ILV ? 4 : 2) void conv_igemm_f32(cons
   if (nsteps > 0) read_frags(fa0, fb0, 0, 0);
 
   int cur = 0;
-  // ---- hand-interleaved K-step of the one-accumulator wave (TM = TN = 1: the 64x64 tile) -------------------------------
-  // A wave of this tile owns ONE 32x32 accumulator: its 16 MFMAs per K-step form a dependent chain, and the wave issues in
-  // order - behind an MFMA it can only issue what does NOT depend on it, until the next MFMA of the chain (64 cycles
-  // later) blocks it.  Left to the compiler the step comes out as runs of 3-4 back-to-back MFMAs separated by clusters of
-  // ds_read / ds_write / address arithmetic / global loads that end in `s_waitcnt lgkmcnt(0)`: the matrix pipe idles through
-  // every cluster (PMC, one wave per SIMD: 53 % of the wave's life on a 32-step tile, profiles/r05_conv_pmc_probe.md).
-  // Here the program order IS the schedule: one small piece of the step's other work behind every MFMA (sched_barrier keeps
-  // the compiler from regrouping), sized to fit the 64-cycle shadow of the MFMA in front of it:
-  //   G0  m . A-frags(1) . m . B-frags(1) . m . store A chunks of tile it+1 . m . store B chunks
-  //   G1  m . A-frags(2) . m . B-frags(2) . m . load A chunk 0 of tile it+3 . m . load A chunk 1
-  //   G2  m . A-frags(3) . m . B-frags(3) . m . load B chunk 0              . m . load B chunk 1, tap state
-  //   barrier (every wave has its last fragments of this buffer; tile it+1 is complete in the other one)
-  //   G3  m . A-frags(0) of the other buffer . m . B-frags(0) . m . m
-  // Same loads, same k order, same arithmetic as kstep: bit-identical results.
-  constexpr bool IL = ILV;
-  int b_off[PB];         // B source offsets without the step term (-1: row past K)
-#pragma unroll
-  for (int j = 0; j < PB; ++j) {
-    const int n = n0 + j * RPP + row0;
-    b_off[j] = n < p.K ? n * p.Ktot + kc * 4 : -1;
-  }
-  const float* const zp = p.zero;
-#define FRCNN_SB() __builtin_amdgcn_sched_barrier(0)
-#define FRCNN_MF(FA, FB, Q) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FB[0][Q], FA[0][Q], acc[0][0], 0, 0, 0)
-  auto kstep_il = [&](int it, auto set, auto more_, auto ld_) {
-    constexpr int SL = decltype(set)::value;
-    constexpr bool MORE = decltype(more_)::value, LD = decltype(ld_)::value;   // tile it+1 / it+3 exists
-    const float* const Ac = As + cur * BM * LDS_PITCH + a_frag;
-    const float* const Bc = Bs + cur * BN * LDS_PITCH + b_frag;
-    const float* const An = As + (cur ^ 1) * BM * LDS_PITCH + a_frag;
-    const float* const Bn = Bs + (cur ^ 1) * BN * LDS_PITCH + b_frag;
-    float* const Aw = As + (cur ^ 1) * BM * LDS_PITCH + row0 * LDS_PITCH + kc * 4;
-    float* const Bw = Bs + (cur ^ 1) * BN * LDS_PITCH + row0 * LDS_PITCH + kc * 4;
-    const int koff = (tr * p.W + ts) * p.C + tc + kc * 4;      // tap state = tile it+3 (load_tiles advances it per call)
-    const int kb = (step_begin + it + 3) * BK;
-    FRCNN_SB();
-    FRCNN_MF(fa0, fb0, 0); FRCNN_SB();
-    fa1[0] = *reinterpret_cast<const f32x4*>(Ac + 8); FRCNN_SB();
-    FRCNN_MF(fa0, fb0, 1); FRCNN_SB();
-    fb1[0] = *reinterpret_cast<const f32x4*>(Bc + 8); FRCNN_SB();
-    FRCNN_MF(fa0, fb0, 2); FRCNN_SB();
-    if (MORE) {
-#pragma unroll
-      for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4*>(Aw + i * RPP * LDS_PITCH) = ra[SL][i];
-    }
-    FRCNN_SB();
-    FRCNN_MF(fa0, fb0, 3); FRCNN_SB();
-    if (MORE) {
-#pragma unroll
-      for (int j = 0; j < PB; ++j) *reinterpret_cast<f32x4*>(Bw + j * RPP * LDS_PITCH) = rb[SL][j];
-    }
-    FRCNN_SB();
-    FRCNN_MF(fa1, fb1, 0); FRCNN_SB();
-    fa0[0] = *reinterpret_cast<const f32x4*>(Ac + 16); FRCNN_SB();
-    FRCNN_MF(fa1, fb1, 1); FRCNN_SB();
-    fb0[0] = *reinterpret_cast<const f32x4*>(Bc + 16); FRCNN_SB();
-    FRCNN_MF(fa1, fb1, 2); FRCNN_SB();
-    if (LD) {
-#pragma unroll
-      for (int i = 0; i < PA / 2; ++i) {
-        const int hi = a_hi0[i] + tr, wi = a_wi0[i] + ts;
-        const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        ra[SL][i] = *reinterpret_cast<const f32x4*>(ok ? px + a_base[i] + koff : zp);
-      }
-    }
-    FRCNN_SB();
-    FRCNN_MF(fa1, fb1, 3); FRCNN_SB();
-    if (LD) {
-#pragma unroll
-      for (int i = PA / 2; i < PA; ++i) {
-        const int hi = a_hi0[i] + tr, wi = a_wi0[i] + ts;
-        const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        ra[SL][i] = *reinterpret_cast<const f32x4*>(ok ? px + a_base[i] + koff : zp);
-      }
-    }
-    FRCNN_SB();
-    FRCNN_MF(fa0, fb0, 0); FRCNN_SB();
-    fa1[0] = *reinterpret_cast<const f32x4*>(Ac + 24); FRCNN_SB();
-    FRCNN_MF(fa0, fb0, 1); FRCNN_SB();
-    fb1[0] = *reinterpret_cast<const f32x4*>(Bc + 24); FRCNN_SB();
-    FRCNN_MF(fa0, fb0, 2); FRCNN_SB();
-    if (LD) {
-#pragma unroll
-      for (int j = 0; j < PB / 2; ++j) rb[SL][j] = *reinterpret_cast<const f32x4*>(b_off[j] >= 0 ? pw + b_off[j] + kb : zp);
-    }
-    FRCNN_SB();
-    FRCNN_MF(fa0, fb0, 3); FRCNN_SB();
-    if (LD) {
-#pragma unroll
-      for (int j = PB / 2; j < PB; ++j) rb[SL][j] = *reinterpret_cast<const f32x4*>(b_off[j] >= 0 ? pw + b_off[j] + kb : zp);
-      // tap state -> tile it+4 (uniform values: scalar selects, no branch)
-      tc += BK;
-      const bool wrap = tc == p.C;
-      tc = wrap ? 0 : tc;
-      ts += wrap ? 1 : 0;
-      const bool wrap2 = ts == p.S;
-      ts = wrap2 ? 0 : ts;
-      tr += wrap2 ? 1 : 0;
-    }
-    FRCNN_SB();
-    __syncthreads();  // buffer cur^1 complete; every wave has its last fragments of buffer cur in registers
-    FRCNN_SB();
-    FRCNN_MF(fa1, fb1, 0); FRCNN_SB();
-    if (MORE) fa0[0] = *reinterpret_cast<const f32x4*>(An);
-    FRCNN_SB();
-    FRCNN_MF(fa1, fb1, 1); FRCNN_SB();
-    if (MORE) fb0[0] = *reinterpret_cast<const f32x4*>(Bn);
-    FRCNN_SB();
-    FRCNN_MF(fa1, fb1, 2); FRCNN_SB();
-    FRCNN_MF(fa1, fb1, 3); FRCNN_SB();
-    cur ^= 1;
-  };
-#undef FRCNN_MF
-  if constexpr (IL) {
-    typedef std::true_type T;
-    typedef std::false_type F;
-    int it = 0;
-    for (; it + 4 < nsteps; it += 2) {
-      kstep_il(it, Set0{}, T{}, T{});
-      kstep_il(it + 1, Set1{}, T{}, T{});
-    }
-    for (; it < nsteps; ++it) {
-      const bool more = it + 1 < nsteps, ld = it + 3 < nsteps;
-      if (it & 1) {
-        if (ld) kstep_il(it, Set1{}, T{}, T{});
-        else if (more) kstep_il(it, Set1{}, T{}, F{});
-        else kstep_il(it, Set1{}, F{}, F{});
-      } else {
-        if (ld) kstep_il(it, Set0{}, T{}, T{});
-        else if (more) kstep_il(it, Set0{}, T{}, F{});
-        else kstep_il(it, Set0{}, F{}, F{});
-      }
-    }
-  } else {
   // one K-step; `set` holds tile it + 1 and is refilled with tile it + 3 once that one is in LDS.  STEADY: tiles it+1 and
   // it+3 exist - no conditions around the loads, so the compiler counts them and waits for the OLDER set only.
   auto kstep = [&](int it, auto set, auto steady) {
@@ -620,7 +482,6 @@ __global__ __launch_bounds__(64 * WM * WN, ILV ? 4 : 2) void conv_igemm_f32(cons
   for (; it < nsteps; it += 2) {
     kstep(it, Set0{}, std::false_type{});
     if (it + 1 < nsteps) kstep(it + 1, Set1{}, std::false_type{});
-  }
   }
 
   if (p.epi_lds && (p.K & 3) == 0)   // (uniform branch; every wave is past the K loop's last barrier and reads no LDS any more)
@@ -1231,8 +1092,6 @@ std::atomic<int> g_wino_fuse{1};
 // test / tuning hook (frcnn_conv2d_set_algo bit 6): 1 = the convolution kernels store through the LDS transpose
 std::atomic<int> g_epi_lds{1};
 
-// test / tuning hook (frcnn_conv2d_set_algo bit 7): 1 = the 64x64 register-staged kernel runs its hand-interleaved K-step
-std::atomic<int> g_kloop{1};
 // device address of g_zero_page, resolved once (hipGetSymbolAddress is a host-side lookup: legal during stream capture)
 const float* zero_page_address() {
   static std::atomic<const float*> cached[64];
@@ -1363,13 +1222,13 @@ bool prof_events(int kind, hipEvent_t* e0, hipEvent_t* e1, hipStream_t stream) {
   return true;
 }
 
-template <int WM, int WN, int TM, int TN, bool ALIGNED, bool WINO = false, bool ILV = false>
+template <int WM, int WN, int TM, int TN, bool ALIGNED, bool WINO = false>
 int launch_conv(const ConvParams& p, int splits, int groups, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_PITCH * sizeof(float);
   static std::atomic<bool> configured{false};   // idempotent attribute call: a race only repeats it
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, TM, TN, ALIGNED, WINO, ILV>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, TM, TN, ALIGNED, WINO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return frcnn::fail(FRCNN_ERR_LAUNCH, "conv: set LDS size: %s", hipGetErrorString(e));
     configured = true;
@@ -1377,10 +1236,10 @@ int launch_conv(const ConvParams& p, int splits, int groups, hipStream_t stream)
   dim3 grid(p.tiles_m * p.tiles_n, groups, splits);
   hipEvent_t e0, e1;
   if (prof_events(0, &e0, &e1, stream))
-    hipExtLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, ALIGNED, WINO, ILV>), grid, dim3(64 * WM * WN), (uint32_t)lds, stream, e0,
+    hipExtLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, ALIGNED, WINO>), grid, dim3(64 * WM * WN), (uint32_t)lds, stream, e0,
                           e1, 0, p);
   else
-    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, ALIGNED, WINO, ILV>), grid, dim3(64 * WM * WN), lds, stream, p);
+    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, ALIGNED, WINO>), grid, dim3(64 * WM * WN), lds, stream, p);
   return frcnn::check_launch("conv_igemm_f32");
 }
 
@@ -1463,16 +1322,14 @@ extern "C" int frcnn_conv2d_set_tile(int tm, int tn) {
 }
 
 extern "C" int frcnn_conv2d_set_algo(int mode) {
-  FRCNN_REQUIRE(mode >= 0 && (mode & 3) <= 2 && (mode & ~(3 | 16 | 32 | 64 | 128)) == 0,
+  FRCNN_REQUIRE(mode >= 0 && (mode & 3) <= 2 && (mode & ~(3 | 16 | 32 | 64)) == 0,
                 "conv2d_set_algo: mode %d (0 auto, 1 implicit GEMM only, 2 Winograd where it applies; +16: never fuse the "
                 "Winograd input transform into the GEMM, +32: forced Winograd uses the 64x64 GEMM with the fused transform, +64: the "
-                "register-staged kernels store straight from the MFMA layout instead of through the LDS transpose, +128: the 64x64 "
-                "kernel runs the compiler-scheduled K-step instead of the hand-interleaved one)", mode);
-  const int fuse = (mode & 16) ? 0 : ((mode & 32) ? 2 : 1), epi = (mode & 64) ? 0 : 1, kl = (mode & 128) ? 0 : 1;
+                "register-staged kernels store straight from the MFMA layout instead of through the LDS transpose)", mode);
+  const int fuse = (mode & 16) ? 0 : ((mode & 32) ? 2 : 1), epi = (mode & 64) ? 0 : 1;
   const bool same = g_algo_mode.exchange(mode & 3) == (mode & 3);
   const bool same_f = g_wino_fuse.exchange(fuse) == fuse, same_e = g_epi_lds.exchange(epi) == epi;
-  const bool same_k = g_kloop.exchange(kl) == kl;
-  if (!(same && same_f && same_e && same_k)) frcnn::bump_settings_epoch();
+  if (!(same && same_f && same_e)) frcnn::bump_settings_epoch();
   return FRCNN_OK;
 }
 
@@ -1807,7 +1664,6 @@ int launch_gemm(ConvParams p, const Plan& pl, long M, int k, int groups, hipStre
       break;
     case 7:
       if (aligned && g_use_dma && p.xbytes && p.wbytes) rc = launch_conv_buf<2, 2, 1, 1>(p, pl.splits, groups, stream);
-      else if (aligned && p.kloop) rc = launch_conv<2, 2, 1, 1, true, false, true>(p, pl.splits, groups, stream);
       else FRCNN_CONV_CASE(2, 2, 1, 1);
       break;
     case 8:
@@ -1820,7 +1676,6 @@ int launch_gemm(ConvParams p, const Plan& pl, long M, int k, int groups, hipStre
       break;
     default:
       if (aligned && g_use_dma == 3 && p.xbytes && p.wbytes) rc = launch_conv_buf<2, 2, 1, 1>(p, pl.splits, groups, stream);
-      else if (aligned && p.kloop) rc = launch_conv<2, 2, 1, 1, true, false, true>(p, pl.splits, groups, stream);
       else FRCNN_CONV_CASE(2, 2, 1, 1);
       break;
   }
@@ -1868,7 +1723,6 @@ int launch_winograd(const ConvParams& p, const Plan& pl, const float* scale, con
   q.mask = q.mscale = nullptr;
   q.wiH = q.wiW = q.wth = q.wtw = 0;
   q.epi_lds = p.epi_lds;
-  q.kloop = p.kloop;
   q.zero = p.zero;
   {
     const size_t xb = q.gx * sizeof(float), wb = q.gw * sizeof(float);   // one transform component's slice
@@ -2036,7 +1890,6 @@ int run_conv(const float* x, const float* wgt, const float* scale, const float* 
   p.gx = p.gw = p.gy = 0;
   p.wiH = p.wiW = p.wth = p.wtw = 0;
   p.epi_lds = g_epi_lds;
-  p.kloop = g_kloop;
   {
     const size_t xb = (size_t)n * h * w * c * sizeof(float), wb = (size_t)k * p.Ktot * sizeof(float);
     p.xbytes = xb < ((size_t)1 << 31) ? (unsigned)xb : 0;

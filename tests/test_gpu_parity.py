@@ -213,58 +213,6 @@ def test_conv2d_winograd_fused_input_transform_is_bit_identical(hip, shape):
 
 
 @pytest.mark.parametrize("case", [(1, 38, 63, 256, 1024, 1, 1, 0), (1, 38, 63, 1024, 256, 1, 1, 0), (1, 75, 125, 128, 128, 3, 1, 1),
-                                  (1, 9, 11, 32, 64, 1, 1, 0), (1, 9, 11, 64, 64, 1, 1, 0), (2, 9, 11, 96, 72, 1, 1, 0),
-                                  (1, 10, 7, 128, 200, 1, 1, 0), (1, 6, 5, 160, 64, 1, 1, 0), (1, 19, 32, 512, 512, 3, 2, 1),
-                                  (3, 7, 7, 32, 36, 3, 1, 1), (1, 38, 62, 256, 512, 1, 2, 0), (1, 5, 6, 288, 68, 1, 1, 0)])
-def test_conv2d_interleaved_kstep_is_bit_identical(hip, case):
-    """conv_igemm_f32<2,2,1,1,true,false,ILV=true> - the 64x64 tile's hand-interleaved K-step (one piece of the step's loads /
-    LDS traffic behind every MFMA of the wave's dependent chain) - against the compiler-scheduled loop of the same kernel
-    (frcnn_conv2d_set_algo flag 128) and against the 128x128 tile: same loads, same k order, same arithmetic -> identical bits.
-    The cases walk every remainder path of the loop (1, 2, 3, 4, 5, 8, 9, 32, 36 ... K-steps per tile, with and without
-    split-K), 3x3 taps incl. padding and stride, M / K tails, residual + ReLU, and the data-gradient forms."""
-    ops = _ops()
-    from faster_rcnn_pytorch_multimodal_amd import _hip
-    lib = _hip.load()
-    n, h, w, c, k, r, stride, pad = case
-    g = torch.Generator().manual_seed(3 * c + k)
-    x = torch.randn(n, h, w, c, generator=g).to(DEV)
-    wt = (torch.randn(k, r, r, c, generator=g) / (r * c ** 0.5)).to(DEV)
-    sc, sh = (torch.rand(k, generator=g) + 0.5).to(DEV), torch.randn(k, generator=g).to(DEV)
-    ho, wo = (h + 2 * pad - r) // stride + 1, (w + 2 * pad - r) // stride + 1
-    res = torch.randn(n, ho, wo, k, generator=g).to(DEV)
-    ksteps = r * r * c // 32
-    outs = {}
-    try:
-        _hip.check(lib.frcnn_conv2d_set_staging(0), "set_staging")
-        for flag in (1, 1 | 128):                                            # implicit GEMM only; interleaved / compiler-scheduled
-            ops.set_conv_algo(flag)
-            _hip.check(lib.frcnn_conv2d_set_tile(1, 1), "set_tile")
-            got = [ops.conv2d_nhwc(x, wt, sc, sh, res, stride=stride, pad=pad, relu=True, split_k=1),
-                   ops.conv2d_nhwc(x, wt, None, None, None, stride=stride, pad=pad, relu=False, split_k=1)]
-            for sp in (2, 3):
-                if ksteps >= 2 * sp:
-                    got.append(ops.conv2d_nhwc(x, wt, sc, sh, None, stride=stride, pad=pad, relu=True, split_k=sp))
-            if k % 4 == 0:
-                wt_t = ops.conv2d_transpose_filter(wt)
-                got.append(ops.conv2d_bwd_data(res, wt_t, (n, h, w, c), stride=stride, pad=pad))
-            outs[flag] = got
-        ops.set_conv_algo(1)
-        _hip.check(lib.frcnn_conv2d_set_tile(2, 2), "set_tile")
-        big = ops.conv2d_nhwc(x, wt, sc, sh, res, stride=stride, pad=pad, relu=True, split_k=1)
-    finally:
-        _hip.check(lib.frcnn_conv2d_set_tile(0, 0), "set_tile")
-        _hip.check(lib.frcnn_conv2d_set_staging(1), "set_staging")
-        ops.set_conv_algo(0)
-    torch.cuda.synchronize()
-    assert len(outs[1]) == len(outs[1 | 128]) >= 2
-    for a, b in zip(outs[1], outs[1 | 128]):
-        assert torch.equal(a, b)
-    assert torch.equal(outs[1][0], big)
-    ref = _conv_ref(x.cpu(), wt.cpu().permute(0, 3, 1, 2), sc.cpu(), sh.cpu(), res.cpu(), stride, pad, True)
-    _close_feat(outs[1][0].cpu().numpy(), ref.numpy(), "interleaved K-step vs float64 reference", 1e-5)
-
-
-@pytest.mark.parametrize("case", [(1, 38, 63, 256, 1024, 1, 1, 0), (1, 38, 63, 1024, 256, 1, 1, 0), (1, 75, 125, 128, 128, 3, 1, 1),
                                   (1, 9, 11, 32, 64, 1, 1, 0), (2, 9, 11, 96, 72, 1, 1, 0), (1, 10, 7, 128, 200, 1, 1, 0),
                                   (1, 19, 32, 512, 512, 3, 2, 1), (3, 7, 7, 32, 36, 3, 1, 1), (1, 38, 62, 256, 512, 1, 2, 0),
                                   (1, 5, 6, 288, 68, 1, 1, 0), (300, 7, 7, 512, 512, 1, 1, 0), (2, 13, 9, 64, 132, 5, 1, 2)])

@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--json", default="")
     ap.add_argument("--streams", type=int, default=4)
+    ap.add_argument("--plan", default="", help="only candidate plans whose label contains one of these comma-separated substrings")
     args = ap.parse_args()
     from faster_rcnn_pytorch_multimodal_amd import _hip, ops
     lib = _hip.load()
@@ -125,6 +126,8 @@ def main():
         key = [n, h, w, c, k, r, r, stride, pad, 1 + (256 if res else 0)]
         rows = []
         for label, code, sp, sps in candidates(M, c, k, r, wino_ok):
+            if args.plan and not any(t == label or (t.endswith("*") and t[:-1] in label) for t in args.plan.split(",")):
+                continue
             try:
                 ops.import_conv_plans([key + [code, sp, sps]])
             except Exception as e:          # a plan the library refuses for this shape
