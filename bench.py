@@ -34,8 +34,12 @@ MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix pe
 HBM_PEAK_GBS = 8000.0
 REFERENCE_ORDER_FLOPS = 628.4e9          # the frame's convolutions in the reference's order of operations
 MIN_TIMED_S = 1.0                    # repeat the --steps region until about this much timed work exists
-PMC_TIMED_FILES = ("r04_pmc_timed.json",)     # PMC pass over the TIMED mode (hipGraph replays on 4 streams), tools/pmc_timed.py
-PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02b_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # committed rocprofv3 PMC passes, newest first
+# Committed rocprofv3 PMC passes (counters cannot be collected inside the timed run: one counter per pass, serialised
+# dispatches).  They were collected with the plan table PLANS_FILE; by default this run LOADS that table instead of re-tuning,
+# so the kernels it times are the kernels the passes measured (roofline.from_profiles.plans_match says so in the line).
+PMC_TIMED_FILE = "r05_pmc_timed.json"         # PMC pass over the TIMED mode (hipGraph replays on 4 streams), tools/pmc_timed.py
+PMC_FILE = "r05_pmc_traffic.json"             # FETCH_SIZE / WRITE_SIZE / MfmaUtil passes over the eager one-stream mode
+PLANS_FILE = "r05_plans.json"                 # the tuned convolution plans those passes replayed
 
 
 def synthetic_frame(seed):
@@ -113,7 +117,7 @@ def conv_roofline(net, frame, info, steps):
                               "tflops": v[2] / v[1] / 1e6} for k, v in per_layer.items()}}
 
 
-def roi_align_timing(net, steps):
+def roi_align_timing(net, steps, prof=None):
     """HIP-event timing of the RoIAlign launch on the last frame's feature map / rois."""
     from faster_rcnn_pytorch_multimodal_amd import ops
     feat = net._act_summaries["conv"]
@@ -130,7 +134,9 @@ def roi_align_timing(net, steps):
     n, h, w, c = feat.shape
     bytes_ = h * w * c * 4 + rois.shape[0] * 7 * 7 * c * 4 + rois.numel() * 4
     out = {"bound": "hbm", "kernel": "roi_plan_kernel + roi_align_fwd_planned (one frcnn_roi_align_fwd call)", "achieved": bytes_ / us / 1e3, "peak": HBM_PEAK_GBS,
-           "unit": "GB/s", "frac": bytes_ / us / 1e3 / HBM_PEAK_GBS, "traffic": pmc_traffic("roi_align_fwd"),
+           "unit": "GB/s", "frac": bytes_ / us / 1e3 / HBM_PEAK_GBS, "traffic": (prof or {}).get("roi_align_traffic_bytes_per_call"),
+           "traffic_source": "roofline.from_profiles (committed rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE passes; the RoIAlign kernels do not "
+                             "depend on the convolution plans)",
            "us_per_launch": us,
            "algorithmic_bytes": bytes_,
            "what": "the reference's operation: RoIAlign of the %d-channel feature map (Network._crop_pool_layer)" % c}
@@ -421,45 +427,57 @@ def drop_in_uncertainty(device, n_frames, frames_host, info, calls=3):
         Cfg.reset_cfg()
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/r02_pmc_traffic.json:
-    FETCH_SIZE and WRITE_SIZE are collected in separate runs, so they cannot be measured inside the timed run)."""
-    for name in PMC_FILES:
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f)["kernels"][kernel]["traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            continue
-    return None
+def plans_sha(rows):
+    """Hash of a convolution plan table (ops.export_conv_plans rows), independent of row order."""
+    import hashlib
+    return hashlib.sha1(json.dumps(sorted([int(v) for v in r] for r in rows)).encode()).hexdigest()[:16]
 
 
-def pmc_mfma_util():
-    """MfmaUtil (percent of SIMD cycles with the matrix pipe busy, duration-weighted over the conv launches of the
-    roofline frames) from the committed PMC pass; None when the file has no such pass."""
-    for name in PMC_FILES:
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f)["kernels"]["conv_igemm"]["mfma"]["mfma_util_percent"]
-        except (OSError, KeyError, ValueError):
+def _profile(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def from_profiles(run_plans_sha):
+    """Everything this line takes from COMMITTED profile files (another process, another box, another day), in one object,
+    with what it was collected on: file names, the git head recorded at collection, the hash of the plan table the
+    profiled command replayed and whether it equals this run's.  Values of a profile whose plans differ from this run's are
+    reported as null (they would describe other kernels)."""
+    traffic, timed = _profile(PMC_FILE), _profile(PMC_TIMED_FILE)
+    out = {"what": "rocprofv3 PMC passes kept under profiles/ - NOT measured by this run (counters are collected one per pass "
+                   "with serialised dispatches); valid for this run only where plans_match is true",
+           "plans_sha_run": run_plans_sha, "files": {}}
+    ok_all = True
+    for key, name, prof in (("traffic", PMC_FILE, traffic), ("timed", PMC_TIMED_FILE, timed)):
+        if prof is None:
+            out["files"][key] = {"file": "profiles/" + name, "present": False}
+            ok_all = False
             continue
-    return None
+        sha = prof.get("plans_sha")
+        out["files"][key] = {"file": "profiles/" + name, "present": True, "collected_at_head": prof.get("collected_at_head"),
+                             "plans_sha": sha, "plans_match": sha == run_plans_sha}
+        ok_all = ok_all and sha == run_plans_sha
+    out["plans_match"] = ok_all
+    conv = (traffic or {}).get("kernels", {}).get("conv_igemm", {}) if out["files"]["traffic"].get("plans_match") else {}
+    roi = (traffic or {}).get("kernels", {}) if traffic else {}
+    out["conv_traffic_bytes_per_call"] = conv.get("traffic_bytes_per_launch")
+    out["conv_mfma_util_percent_isolated"] = (conv.get("mfma") or {}).get("mfma_util_percent")
+    out["conv_mfma_util_by_kernel_isolated"] = {k: round(v["mfma_util_percent"], 1)
+                                                for k, v in ((conv.get("mfma") or {}).get("by_kernel") or {}).items()}
+    # the RoIAlign kernels do not depend on the conv plans
+    out["roi_align_traffic_bytes_per_call"] = (roi.get("roi_align_fwd") or {}).get("traffic_bytes_per_launch")
+    out["roi_align_affine_traffic_bytes_per_call"] = (roi.get("roi_align_fwd_affine") or {}).get("traffic_bytes_per_launch")
+    out["mfma_busy_ms_per_frame_timed_mode"] = (timed.get("mfma_busy_ms_per_frame")
+                                                if timed and out["files"]["timed"].get("plans_match") else None)
+    return out
 
 
 def Cfg_post_nms():
     from faster_rcnn_pytorch_multimodal_amd.model.config import cfg
     return cfg.TEST.RPN_POST_NMS_TOP_N
-
-
-def pmc_timed():
-    """Matrix-pipe busy time per frame from the committed PMC pass over the timed mode (hipGraph replays, 4 streams):
-    sum over a frame's dispatches of MfmaUtil x duration, in ms of a fully busy chip (tools/pmc_timed.py)."""
-    for name in PMC_TIMED_FILES:
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f)
-        except (OSError, ValueError):
-            continue
-    return None
 
 
 def extra_configs(steps):
@@ -486,6 +504,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--conv-algo", type=int, default=0, help="frcnn_conv2d_set_algo: 0 = the autotuner may pick Winograd F(2x2,3x3) "
                     "for the eligible 3x3 layers (default), 1 = implicit GEMM only")
+    ap.add_argument("--retune", action="store_true", help="tune the convolution plans in this run instead of loading the committed "
+                    "table profiles/%s" % PLANS_FILE)
     ap.add_argument("--plans", default=None, help="JSON file of tuned conv plans: loaded when it exists (profiler runs "
                     "then use exactly the kernels of the timed run), written after warm-up otherwise")
     ap.add_argument("--streams", type=int, default=4,
@@ -633,8 +653,12 @@ def main(argv=None):
         frames = [f.to(device) for f in frames_pinned]
         _ops.set_conv_algo(args.conv_algo)
         plans_loaded = False
-        if args.plans and os.path.exists(args.plans):
-            with open(args.plans) as f:
+        plans_path = args.plans
+        if not plans_path and not args.retune and os.path.exists(os.path.join(ROOT, "profiles", PLANS_FILE)):
+            # default: the committed plan table - the kernels the profiles under profiles/ measured (roofline.from_profiles)
+            plans_path = os.path.join(ROOT, "profiles", PLANS_FILE)
+        if plans_path and os.path.exists(plans_path):
+            with open(plans_path) as f:
                 _ops.import_conv_plans(json.load(f))
             plans_loaded = True
         runners = [FrameRunner(net, H, W, C, info, THRESH, MAX_DETS, use_graph=not args.no_graph) for _ in range(n_streams)]
@@ -848,6 +872,9 @@ def main(argv=None):
             out["value"] = None
         else:
             conv = conv_roofline(net, frames[0], info, steps=min(args.steps, 5))
+            run_plans = _ops.export_conv_plans()
+            run_sha = plans_sha(run_plans)
+            prof = from_profiles(run_sha)
             # ALGORITHMIC FLOPs of a frame's convolutions = SURVEY.md section 8(d) / BASELINE.md section 3: 628.4 GFLOP, the
             # reference's formulation (direct-form 3x3 convolutions, layer4[0].conv1 / downsample[0] on the pooled RoIs).  The
             # launches of this build do less arithmetic for the same function (Winograd; those two convolutions moved in front of
@@ -871,19 +898,24 @@ def main(argv=None):
                 "bound": "mfma", "kernel": "frcnn_conv2d_fwd: conv_igemm_* (all instantiations) + split-K second passes + Winograd "
                 "transforms, %d calls/frame" % round(conv["launches_per_frame"]), "achieved": achieved,
                 "peak": MFMA_F32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic("conv_igemm"),
+                "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": prof["conv_traffic_bytes_per_call"],
+                "traffic_source": "from_profiles (NOT measured by this run; null when the profile's plan table differs from this run's)",
+                "from_profiles": prof,
+                "plans": {"source": ("profiles/" + PLANS_FILE if (plans_loaded and not args.plans) else
+                                     (args.plans if plans_loaded else "tuned in this run (autotune level %d)" % _ops.AUTOTUNE_LEVEL)),
+                          "sha": run_sha, "entries": len(run_plans)},
                 "mode": "isolated kernels: eager launches on one stream, every dispatch bracketed by its own start / stop HIP "
                         "events (hipExtLaunchKernelGGL) = rocprofv3's per-dispatch duration; avg_launch_us is per "
                         "frcnn_conv2d_fwd call (every launch it makes); the timed run overlaps %d frames, see "
                         "frac_timed" % n_streams,
                 "achieved_launched": achieved_launched, "frac_launched": achieved_launched / MFMA_F32_PEAK_TFLOPS,
                 "algorithmic_flops_per_frame": algorithmic,
-                "achieved_timed": timed_tflops, "frac_timed": timed_tflops / MFMA_F32_PEAK_TFLOPS,
+                "achieved_timed_algorithmic": timed_tflops,
+                "frac_timed_algorithmic_not_pipe_utilisation": timed_tflops / MFMA_F32_PEAK_TFLOPS,
                 "frac_timed_launched": timed_launched / MFMA_F32_PEAK_TFLOPS,
-                "frac_timed_what": "all conv FLOPs of a frame / ms_per_step of the TIMED run (hipGraph x %d streams) / "
-                                   "peak: a lower bound on the conv kernels' rate in the timed mode, since the step also "
-                                   "holds every non-conv kernel" % n_streams,
-                "mfma_util_pmc_percent": pmc_mfma_util(),
+                "frac_timed_what": "ALGORITHMIC conv FLOPs of a frame (628.4 GFLOP, the reference's formulation) / ms_per_step of "
+                                   "the TIMED run (hipGraph x %d streams) / peak.  NOT the matrix pipe's utilisation: Winograd and "
+                                   "the head reorder make the pipe execute fewer FLOPs - that figure is frac_executed_timed" % n_streams,
                 "frac_executed_timed": conv["executed_flops_per_frame"] / (1e-3 * 1e3 * elapsed / args.steps) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                 "frac_executed_timed_what": "FLOPs the matrix pipe EXECUTES per frame (Winograd layers: 16/36 of the direct form) / "
                                             "ms_per_step of the timed run / peak: the MFMA pipe's utilisation in the timed mode; "
@@ -913,18 +945,22 @@ def main(argv=None):
                 "winograd_calls_per_frame": conv["winograd_calls_per_frame"],
                 "winograd_transform_launches_per_frame": conv["winograd_transform_launches_per_frame"],
                 "winograd_transform_us_per_frame": conv["winograd_transform_us_per_frame"]}
-            pt = pmc_timed()
-            if pt is not None:
-                busy = pt["mfma_busy_ms_per_frame"]
-                out["roofline"]["mfma_util_timed_percent"] = 100.0 * busy / (1e3 * elapsed / args.steps)
-                out["roofline"]["mfma_util_timed_what"] = (
+            busy = prof["mfma_busy_ms_per_frame_timed_mode"]
+            if busy is not None:
+                prof["mfma_util_timed_percent"] = 100.0 * busy / (1e3 * elapsed / args.steps)
+                prof["mfma_util_timed_what"] = (
                     "matrix-pipe busy time per frame (%.3f ms: sum over the frame's dispatches of MfmaUtil x duration, rocprofv3 "
-                    "PMC pass over the hipGraph x %d-stream mode, %s) / ms_per_step of THIS run" % (busy, n_streams, pt.get("file", "profiles/")))
+                    "PMC pass over the hipGraph x %d-stream mode, profiles/%s) / ms_per_step of THIS run" % (busy, n_streams, PMC_TIMED_FILE))
+            # the per-layer table of the isolated pass (what DESIGN.md's kernel section cites), largest share first
+            out["roofline"]["per_layer"] = [
+                {"shape": k, "calls_per_frame": v["calls_per_frame"], "us_per_call": round(v["us_per_call"], 2),
+                 "tflops": round(v["tflops"], 1)}
+                for k, v in sorted(conv["per_layer"].items(), key=lambda kv: -kv[1]["us_per_call"] * kv[1]["calls_per_frame"])]
             if args.layers:
                 for k, v in sorted(conv["per_layer"].items(), key=lambda kv: -kv[1]["us_per_call"] * kv[1]["calls_per_frame"]):
                     print("%-40s x%-4.0f %9.1f us/call %7.1f TFLOP/s" % (k, v["calls_per_frame"], v["us_per_call"], v["tflops"]),
                           file=sys.stderr)
-            out["roofline_roi_align"] = roi_align_timing(net, 20)
+            out["roofline_roi_align"] = roi_align_timing(net, 20, prof)
             out["roofline_nms"] = nms_timing(net, 20)
             if world == 1 and not args.no_drop_in:
                 out["drop_in"] = drop_in_timing(net, frames, info, max(args.steps, args.drop_in_frames), out["value"])

@@ -65,7 +65,7 @@ def _workspace(nbytes, device):
 
 # what set_conv_autotune(True) means: 1 = every candidate plan is timed alone on an idle chip, 2 = under load (four launches
 # of the candidate in flight on four streams: ranked by throughput, the objective of the four-frames-in-flight schedule)
-AUTOTUNE_LEVEL = int(os.environ.get('FRCNN_AUTOTUNE_LEVEL', '1'))
+AUTOTUNE_LEVEL = int(os.environ.get('FRCNN_AUTOTUNE_LEVEL', '2'))
 
 
 def set_conv_autotune(enable):

@@ -237,8 +237,15 @@ def test_bench_runs_its_collective_path_over_rccl_with_one_rank(hip):
     # the measurement objects of the contract, produced by this run's code (not read from a committed file)
     assert abs(out["value"] - 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]          # one frame per step on one GPU
     r = out["roofline"]
-    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_timed")) <= set(r) and r["bound"] == "mfma"
-    assert r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.4 < r["frac"] < r["frac_timed"] < 1.0
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "from_profiles", "frac_executed_timed", "per_layer",
+                "frac_timed_algorithmic_not_pipe_utilisation")) <= set(r) and r["bound"] == "mfma"
+    assert r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0.4 < r["frac"] < r["frac_timed_algorithmic_not_pipe_utilisation"] < 1.05 and 0.3 < r["frac_executed_timed"] < 1.0
+    fp = r["from_profiles"]
+    assert fp["plans_sha_run"] == r["plans"]["sha"] and isinstance(fp["plans_match"], bool)
+    if not fp["plans_match"]:                       # a profile of other kernels must not be quoted for this run
+        assert r["traffic"] is None and fp["mfma_busy_ms_per_frame_timed_mode"] is None
+    assert len(r["per_layer"]) >= 15 and all(row["us_per_call"] > 0 for row in r["per_layer"])
     ra = out["roofline_roi_align"]
     assert ra["bound"] == "hbm" and ra["unit"] == "GB/s" and abs(ra["frac"] - ra["achieved"] / ra["peak"]) < 1e-9
 

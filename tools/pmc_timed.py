@@ -19,7 +19,15 @@ import re
 import sys
 
 
-def main(directory, only_timed_json, command):
+def plans_sha(path):
+    """bench.plans_sha of a saved plan table (hash independent of row order)."""
+    import hashlib
+    with open(path) as f:
+        rows = json.load(f)
+    return hashlib.sha1(json.dumps(sorted([int(v) for v in r] for r in rows)).encode()).hexdigest()[:16]
+
+
+def main(directory, only_timed_json, command, plans=None, head=None, tag="r05"):
     paths = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
     if not paths:
         raise SystemExit("no *counter_collection.csv under %s" % directory)
@@ -52,7 +60,8 @@ def main(directory, only_timed_json, command):
         key = m.group(1) if m else name.split("(")[0][:48]
         n, sd, sb = fam.get(key, (0, 0, 0.0))
         fam[key] = (n + 1, sd + (e - s), sb + (e - s) * u / 100.0)
-    out = {"file": "profiles/r04_pmc_timed.json", "command": command, "frames_total": frames,
+    out = {"file": "profiles/%s_pmc_timed.json" % tag, "command": command, "collected_at_head": head,
+           "plans_sha": plans_sha(plans) if plans else None, "frames_total": frames,
            "frames_replayed_as_graphs": int(info["frames_replayed"]), "dispatches": len(rows),
            "queues": len({q for _, _, _, _, q in rows}),
            "kernel_ms_per_frame": dur / 1e6 / frames, "mfma_busy_ms_per_frame": busy / 1e6 / frames,
@@ -67,4 +76,6 @@ def main(directory, only_timed_json, command):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], " ".join(sys.argv[3:]))
+    opts = {a.split("=", 1)[0][2:]: a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--") and "=" in a}
+    args = [a for a in sys.argv[1:] if not (a.startswith("--") and "=" in a)]
+    main(args[0], args[1], " ".join(args[2:]), opts.get("plans"), opts.get("head"), opts.get("tag", "r05"))

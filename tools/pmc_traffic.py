@@ -100,10 +100,19 @@ def mfma_util(directory):
                           for k, (n, sv, sd) in sorted(by.items())}}
 
 
-def main(fetch_dir, write_dir, command="", mfma_dir=None):
+def plans_sha(path):
+    """bench.plans_sha of a saved plan table (hash independent of row order)."""
+    import hashlib
+    with open(path) as f:
+        rows = json.load(f)
+    return hashlib.sha1(json.dumps(sorted([int(v) for v in r] for r in rows)).encode()).hexdigest()[:16]
+
+
+def main(fetch_dir, write_dir, command="", mfma_dir=None, plans=None, head=None):
     fetch = per_kernel(fetch_dir, "FETCH_SIZE")
     write = per_kernel(write_dir, "WRITE_SIZE")
-    out = {"command": command + " (one counter per pass)",
+    out = {"command": command + " (one counter per pass)", "collected_at_head": head,
+           "plans_sha": plans_sha(plans) if plans else None,
            "method": "per-dispatch FETCH_SIZE / WRITE_SIZE (KB) summed per kernel family and divided by its launch "
                      "count; FETCH_SIZE doubled (gfx950 reports half of wide 16 B/lane streaming reads, "
                      "MI355X_MICROARCH.md HBM section); Infinity-Cache hits are included in FETCH_SIZE",
@@ -129,6 +138,6 @@ if __name__ == "__main__":
         if a.startswith("--conv-calls="):
             LAST["conv_igemm"] = 5 * int(a.split("=", 1)[1])
     sys.argv = [a for a in sys.argv if not a.startswith("--conv-calls=")]
-    args = [a for a in sys.argv[1:] if not a.startswith("--mfma=")]
-    mfma = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--mfma=")]
-    main(args[0], args[1], " ".join(args[2:]), mfma[0] if mfma else None)
+    opts = {a.split("=", 1)[0][2:]: a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--") and "=" in a}
+    args = [a for a in sys.argv[1:] if not (a.startswith("--") and "=" in a)]
+    main(args[0], args[1], " ".join(args[2:]), opts.get("mfma"), opts.get("plans"), opts.get("head"))
