@@ -92,8 +92,10 @@ __device__ __forceinline__ bool iou_gt_lazy_div(const float* a, const float* b, 
   return hit;
 }
 
-// fp32 -> u32 key whose ASCENDING order is DESCENDING score (-0 is folded into +0 first).
+// fp32 -> u32 key whose ASCENDING order is DESCENDING score (-0 is folded into +0 first).  NaN - with either sign bit - gets
+// the smallest key: torch.sort(descending=True) (lib/layer_utils/proposal_layer.py:39) ranks NaN above +Inf, ties by index.
 __device__ __forceinline__ uint32_t desc_key(float s) {
+  if (s != s) return 0u;
   if (s == 0.f) s = 0.f;
   uint32_t u = __float_as_uint(s);
   u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);

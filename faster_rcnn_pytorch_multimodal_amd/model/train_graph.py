@@ -16,9 +16,9 @@ gradients on a side stream - is captured ONCE per problem shape and replayed per
   * weight-derived tensors (KRSC / transposed / fused filters) live in storage-stable caches
     (``nets.hip_modules.stable_store``) that ``refresh_derived_weights`` re-derives in place after every optimizer step.
 
-A graph is specific to (H, W, C, number of gt boxes); ``Network.train_step`` keeps one runner per key when
-``net.enable_train_graphs()`` was called and falls back to the eager step for anything a graph cannot express
-(BatchNorm on batch statistics, the uncertainty heads' counter-based draws, don't-care boxes).
+A graph is specific to (H, W, C, capacity of the gt buffer); ``Network.train_step`` keeps one runner per key when
+``net.enable_train_graphs()`` was called and falls back to the eager step for what a graph cannot express (``graphable``:
+BatchNorm with momentum=None, more don't-care boxes than the buffer holds).
 """
 import numpy as np
 import torch
@@ -30,6 +30,10 @@ from .config import cfg
 
 
 GT_CAPACITY_MIN = 32      # rows of a captured step's gt buffer: max(32, next power of two of the frame's boxes)
+DC_CAPACITY = 64          # rows of a captured step's don't-care buffer (cfg.TRAIN.IGNORE_DC); unused rows hold DC_FAR
+# a box no proposal overlaps: IoU 0 < cfg.TRAIN.DC_THRESH, so a padding row never masks a RoI (proposal_target_layer.py:180-187
+# drops RoIs by their BEST overlap with a don't-care box) - the buffer needs no device-side count
+DC_FAR = (-1.0e6, -1.0e6, -1.0e6 + 1.0, -1.0e6 + 1.0)
 
 
 def gt_capacity(num_gt):
@@ -116,8 +120,8 @@ def graph_node_kinds(graph):
 
 def graphable(net, blobs):
     """Why this step cannot run as a graph (a string), or None."""
-    if cfg.TRAIN.IGNORE_DC and blobs.get('gt_boxes_dc') is not None and len(blobs['gt_boxes_dc']) > 0:
-        return "don't-care boxes (their number varies per frame and they are read on the host)"
+    if cfg.TRAIN.IGNORE_DC and blobs.get('gt_boxes_dc') is not None and len(blobs['gt_boxes_dc']) > DC_CAPACITY:
+        return "more than %d don't-care boxes (the captured step's buffer)" % DC_CAPACITY
     if len(blobs['gt_boxes']) == 0:
         return "no ground-truth boxes"
     for m in net.modules():
@@ -157,6 +161,10 @@ class TrainStepRunner:
         self.static_gt = torch.zeros((self.gt_cap, 5), dtype=torch.float32, device=dev)
         self.static_true_gt = torch.zeros((self.gt_cap, 8), dtype=torch.float32, device=dev) if self.lidar else None
         self.gt_count = torch.ones((1,), dtype=torch.int32, device=dev)
+        # don't-care boxes (cfg.TRAIN.IGNORE_DC, lib/roi_data_layer/minibatch.py:168-176): fixed-capacity buffer padded with a
+        # far-away box; the flag is part of the capture (a runner is built under one cfg)
+        self.dc_far = torch.tensor([DC_FAR], dtype=torch.float32, device=dev).repeat(DC_CAPACITY, 1) if cfg.TRAIN.IGNORE_DC else None
+        self.static_dc = self.dc_far.clone() if self.dc_far is not None else None
         self.seed_dev = torch.zeros((2,), dtype=torch.int32, device=dev)
         from ..nets import uncertainty
         self.uc_seed_dev = torch.zeros((1,), dtype=torch.int32, device=dev) if uncertainty.enabled() else None
@@ -252,7 +260,7 @@ class TrainStepRunner:
         net._seed_dev, net._gt_count_dev, net._uc_seed_dev = self.seed_dev, self.gt_count, self.uc_seed_dev
         try:
             gt = (self.static_gt, self.static_true_gt) if self.lidar else self.static_gt
-            net.forward(self.static_in, self.info, gt, None, mode='TRAIN')
+            net.forward(self.static_in, self.info, gt, self.static_dc, mode='TRAIN')
         finally:
             net._seed_dev = net._gt_count_dev = net._uc_seed_dev = None
         loss = net._losses['total_loss']
@@ -285,6 +293,17 @@ class TrainStepRunner:
             if isinstance(gt, np.ndarray):
                 gt = torch.from_numpy(np.ascontiguousarray(gt, dtype=np.float32))
             self.static_gt[:g].copy_(gt[:, :5], non_blocking=True)
+        if self.static_dc is not None:
+            dc = blobs.get('gt_boxes_dc')
+            n_dc = 0 if dc is None else int(len(dc))
+            if n_dc > DC_CAPACITY:
+                raise ValueError("TrainStepRunner: %d don't-care boxes, this runner holds %d" % (n_dc, DC_CAPACITY))
+            self.static_dc.copy_(self.dc_far, non_blocking=True)
+            if n_dc:
+                dc_t = dc if isinstance(dc, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(dc, dtype=np.float32)))
+                self.static_dc[:n_dc].copy_(dc_t[:, :4], non_blocking=True)
+        elif cfg.TRAIN.IGNORE_DC:
+            raise RuntimeError("TrainStepRunner: cfg.TRAIN.IGNORE_DC was switched on after this step was captured")
         self.static_in.copy_(data, non_blocking=True)
         self.gt_count.fill_(g)
         self.seed_dev.copy_(torch.tensor([_draw_seed(), _draw_seed()], dtype=torch.int32))    # 8 bytes, host -> device
@@ -393,7 +412,7 @@ class TrainPipeline:
                                "%d frames)" % (s, self.slots))
         data, info = blobs['data'], np.asarray(blobs['info'], dtype=np.float32)
         key = (int(data.shape[1]), int(data.shape[2]), int(data.shape[3]), gt_capacity(len(blobs['gt_boxes'])),
-               tuple(float(v) for v in info))
+               tuple(float(v) for v in info), bool(cfg.TRAIN.IGNORE_DC))
         runner = self.runners[s].get(key)
         if runner is None:
             if len(self.runners[s]) >= self.max_graphs:

@@ -249,3 +249,108 @@ def test_train_pipeline_updates_batchnorm_statistics_in_frame_order(hip):
     worst, name = _grad_dev(net_e, net_p)
     assert worst <= 5e-3, (name, worst)
     C.reset_cfg()
+
+
+def test_captured_step_with_dont_care_boxes(hip):
+    """cfg.TRAIN.IGNORE_DC (lib/layer_utils/proposal_target_layer.py:180-187: RoIs whose best overlap with a don't-care box
+    reaches DC_THRESH are dropped before sampling; lib/roi_data_layer/minibatch.py:168-176 hands a varying number of such
+    boxes per frame): the captured step holds a fixed-capacity don't-care buffer padded with a box no RoI overlaps, so frames
+    with 0, 3 and 9 don't-care boxes replay ONE graph and follow the eager step - no eager fallback, no warning."""
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    net_e, _ = T._build_fpn_pair(seed=23)
+    net_g, _ = T._build_fpn_pair(seed=23)
+    C.cfg.TRAIN.IGNORE_DC = True
+    try:
+        data, info, gt, _, _ = T._fpn_case()
+        rng = np.random.default_rng(8)
+
+        def dc_boxes(n):
+            wh = rng.uniform(30, 160, (n, 2))
+            xy = rng.uniform(0, 1, (n, 2)) * (np.array([320, 256]) - wh - 1)
+            return np.concatenate((xy, xy + wh), 1).astype(np.float32)
+
+        for n in (net_e, net_g):
+            n.train()
+        net_g.enable_train_graphs(True)
+        opts = [torch.optim.SGD([p for p in n.parameters() if p.requires_grad], lr=1e-3) for n in (net_e, net_g)]
+        masked = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            for it, n_dc in enumerate((3, 0, 9)):
+                blobs = {"data": data * (1.0 + 0.1 * it), "info": info, "gt_boxes": gt, "gt_boxes_dc": dc_boxes(n_dc)}
+                for o in opts:
+                    o.zero_grad(set_to_none=False)
+                losses = [None, None]
+                for idx in (1, 0):
+                    torch.manual_seed(500 + it)
+                    losses[idx] = (net_e, net_g)[idx].train_step(blobs, opts[idx], update_weights=False)
+                assert abs(losses[0] - losses[1]) <= 2e-5 * max(1.0, abs(losses[0])), (it, losses)
+                worst, name = _grad_dev(net_e, net_g)
+                assert worst <= 1e-4, (it, n_dc, name, worst)
+                masked.append(int(net_e._proposal_targets["counts"][:2].sum().item()))
+        assert len(net_g._train_graphs) == 1
+        assert masked[1] > masked[0] or masked[1] > masked[2]          # the don't-care boxes really removed candidates
+    finally:
+        C.reset_cfg()
+
+
+def test_chain_with_torch_memcpy_nodes_replays_bit_identically_on_four_streams(hip):
+    """The captured steps still contain torch's own device-to-device ``copy_`` calls, i.e. hipGraph MEMCPY nodes (round 4's
+    replay fault was traced to the library's memset / memcpy nodes inside single-chain graphs; the library now emits kernel
+    nodes only, torch's copies remain).  Four single-chain graphs - library convolutions with torch ``copy_`` nodes between
+    them - replayed 8 rounds on four streams with fresh inputs each round, no host synchronisation inside a round: every
+    output equals the eager evaluation bit for bit, and the node census is what the test means to exercise."""
+    from faster_rcnn_pytorch_multimodal_amd.model.train_graph import graph_node_kinds
+    ops = T._ops()
+    g = torch.Generator().manual_seed(12)
+    w1 = (torch.randn(256, 3, 3, 256, generator=g) / 48).to(DEV)
+    w2 = (torch.randn(512, 1, 1, 256, generator=g) / 16).to(DEV)
+    w3 = (torch.randn(256, 1, 1, 512, generator=g) / 22).to(DEV)
+    sc, sh = (torch.rand(256, generator=g) + 0.5).to(DEV), torch.randn(256, generator=g).to(DEV)
+
+    def chain(x, mid, mid2, out):
+        y = ops.conv2d_nhwc(x, w1, sc, sh, None, stride=1, pad=1, relu=True)
+        mid.copy_(y)                                             # torch D2D copy: a memcpy node inside the capture
+        u = ops.conv2d_nhwc(mid, w2, None, None, None, relu=True)
+        mid2.copy_(u)
+        v = ops.conv2d_nhwc(mid2, w3, sc, sh, y, relu=True)
+        out.copy_(v)
+
+    n_streams, rounds = 4, 8
+    streams = [torch.cuda.Stream() for _ in range(n_streams)]
+    xs = [torch.zeros(1, 38, 63, 256, device=DEV) for _ in range(n_streams)]
+    mids = [torch.zeros(1, 38, 63, 256, device=DEV) for _ in range(n_streams)]
+    mid2s = [torch.zeros(1, 38, 63, 512, device=DEV) for _ in range(n_streams)]
+    outs = [torch.zeros(1, 38, 63, 256, device=DEV) for _ in range(n_streams)]
+    for k in range(n_streams):
+        chain(xs[k], mids[k], mid2s[k], outs[k])                 # warm-up: plans, allocator
+    torch.cuda.synchronize()
+    graphs = []
+    for k, st in enumerate(streams):
+        st.wait_stream(torch.cuda.current_stream())
+        gr = torch.cuda.CUDAGraph(keep_graph=True)
+        with torch.cuda.graph(gr, stream=st):
+            chain(xs[k], mids[k], mid2s[k], outs[k])
+        kinds, nodes, edges = graph_node_kinds(gr)
+        assert kinds.get("memcpy", 0) >= 3 and kinds.get("memset", 0) == 0 and kinds.get("kernel", 0) >= 3, kinds
+        assert edges == nodes - 1                                 # one chain
+        gr.instantiate()
+        graphs.append(gr)
+    inputs = [[torch.randn(1, 38, 63, 256, generator=g).to(DEV) for _ in range(n_streams)] for _ in range(rounds)]
+    torch.cuda.synchronize()
+    got = []
+    for r in range(rounds):
+        for k, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                xs[k].copy_(inputs[r][k], non_blocking=True)
+                graphs[k].replay()
+                got.append(outs[k].clone())
+    torch.cuda.synchronize()
+    ref_x, ref_mid, ref_mid2, ref_out = (torch.zeros_like(t) for t in (xs[0], mids[0], mid2s[0], outs[0]))
+    for r in range(rounds):
+        for k in range(n_streams):
+            ref_x.copy_(inputs[r][k])
+            chain(ref_x, ref_mid, ref_mid2, ref_out)
+            torch.cuda.synchronize()
+            assert torch.equal(got[r * n_streams + k], ref_out), (r, k)
+    assert len({t.cpu().numpy().tobytes() for t in got}) == rounds * n_streams
