@@ -48,8 +48,11 @@ __device__ __forceinline__ void decode_box_lidar(float x1, float y1, float x2, f
   out[6] = d[6];
 }
 
-// torch.clamp(v, lo, hi) = min(max(v, lo), hi)
-__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+// torch.clamp(v, lo, hi) = min(max(v, lo), hi), and like torch's it hands a NaN through (fminf / fmaxf would return the
+// bound: a NaN coordinate of a diverged regression would silently become a frame edge).  clamp_min / clamp_max likewise.
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ float clamp_minf(float v, float lo) { return v < lo ? lo : v; }
+__device__ __forceinline__ float clamp_maxf(float v, float hi) { return v > hi ? hi : v; }
 
 // What happens when IoU == threshold exactly is a RUN-TIME choice (frcnn_nms_set_suppress_at_equal, csrc/boxes.hip; DESIGN.md
 // section 1): torchvision 0.4.0 (req.txt:283, not vendored) suppresses on `iou >= threshold` in its CPU kernel and on

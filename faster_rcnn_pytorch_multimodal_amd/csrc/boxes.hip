@@ -716,10 +716,10 @@ __global__ __launch_bounds__(256) void clamp_pred_boxes_kernel(float* __restrict
   // filter_predictions.py:85-91: x1,y1 = clamp_min(0); x2 = clamp_max(frame_w/scale - 1); y2 likewise
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total_boxes; i += gridDim.x * blockDim.x) {
     float4 b = reinterpret_cast<float4*>(boxes)[i];
-    b.x = fmaxf(b.x, 0.f);
-    b.y = fmaxf(b.y, 0.f);
-    b.z = fminf(b.z, x_hi);
-    b.w = fminf(b.w, y_hi);
+    b.x = clamp_minf(b.x, 0.f);
+    b.y = clamp_minf(b.y, 0.f);
+    b.z = clamp_maxf(b.z, x_hi);
+    b.w = clamp_maxf(b.w, y_hi);
     reinterpret_cast<float4*>(boxes)[i] = b;
   }
 }

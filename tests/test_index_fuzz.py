@@ -163,7 +163,7 @@ def test_sort_topk_at_fpn_size_with_special_values(hip):
 def test_fuzz_rpn_decode_clip(hip, seed, hw, scale, special):
     """Decode + clip with deltas far outside the trained range: exp() overflow to Inf (Inf - Inf = NaN through the clip), NaN
     deltas.  Finite results within 1e-4 (relative for huge boxes), non-finite results in the same places with the same
-    class (NaN / +Inf / -Inf); clipped coordinates identical."""
+    class (NaN / +Inf / -Inf; torch.clamp hands NaN through, so must the kernel); clipped coordinates identical."""
     ops = _ops()
     h, w = hw
     a = 25
@@ -186,7 +186,15 @@ def test_fuzz_rpn_decode_clip(hip, seed, hw, scale, special):
     assert torch.equal(torch.isnan(got), torch.isnan(ref)), "NaN pattern differs"
     assert torch.equal(torch.isfinite(got), fin)
     assert torch.equal(got[~fin & ~torch.isnan(ref)], ref[~fin & ~torch.isnan(ref)])        # +-Inf with the same sign
-    np.testing.assert_allclose(got[fin].numpy(), ref[fin].numpy(), rtol=2e-6, atol=1e-4)
+    # a coordinate is centre -+ half a size: with deltas this large the two terms reach 1e5 .. 1e30 before the clip and the
+    # last-ulp freedom of expf is amplified by the cancellation - the tolerance follows the terms, not the result
+    aw, ah = anchors[:, 2] - anchors[:, 0] + 1.0, anchors[:, 3] - anchors[:, 1] + 1.0
+    with np.errstate(all="ignore"):
+        term_x = (deltas[:, 0] * aw).abs() + torch.exp(deltas[:, 2]) * aw
+        term_y = (deltas[:, 1] * ah).abs() + torch.exp(deltas[:, 3]) * ah
+    tol = 1e-4 + 1e-6 * torch.stack((term_x, term_y, term_x, term_y), 1)
+    tol = torch.nan_to_num(tol, nan=float("inf"), posinf=float("inf"))
+    assert bool(((got - ref).abs()[fin] <= tol[fin]).all()), float(((got - ref).abs()[fin] - tol[fin]).max())
 
 
 @settings(max_examples=40, **SETTINGS)

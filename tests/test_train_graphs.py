@@ -260,12 +260,13 @@ def test_captured_step_with_dont_care_boxes(hip):
     net_e, _ = T._build_fpn_pair(seed=23)
     net_g, _ = T._build_fpn_pair(seed=23)
     C.cfg.TRAIN.IGNORE_DC = True
+    C.cfg.TRAIN.DC_THRESH = 0.05                  # low bar + large boxes: an untrained RPN's proposals really get masked
     try:
         data, info, gt, _, _ = T._fpn_case()
         rng = np.random.default_rng(8)
 
         def dc_boxes(n):
-            wh = rng.uniform(30, 160, (n, 2))
+            wh = rng.uniform(120, 250, (n, 2))
             xy = rng.uniform(0, 1, (n, 2)) * (np.array([320, 256]) - wh - 1)
             return np.concatenate((xy, xy + wh), 1).astype(np.float32)
 
@@ -287,9 +288,11 @@ def test_captured_step_with_dont_care_boxes(hip):
                 assert abs(losses[0] - losses[1]) <= 2e-5 * max(1.0, abs(losses[0])), (it, losses)
                 worst, name = _grad_dev(net_e, net_g)
                 assert worst <= 1e-4, (it, n_dc, name, worst)
-                masked.append(int(net_e._proposal_targets["counts"][:2].sum().item()))
+                masked.append([int(v) for v in net_e._proposal_targets["counts"][:4].cpu()])
         assert len(net_g._train_graphs) == 1
-        assert masked[1] > masked[0] or masked[1] > masked[2]          # the don't-care boxes really removed candidates
+        print("[sampled fg, sampled bg, fg candidates, bg candidates] with 3, 0, 9 don't-care boxes:", masked)
+        cand = [m[2] + m[3] for m in masked]
+        assert cand[1] > min(cand[0], cand[2])                          # the don't-care boxes really removed candidates
     finally:
         C.reset_cfg()
 
