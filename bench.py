@@ -489,9 +489,9 @@ def extra_configs(steps):
     out = []
     t0 = time.perf_counter()
     out.append(BC.lidar_forward(max(steps, 80)))
-    res = BC.fpn_train(16, modes=["eager", "graph", "pipeline"])
+    res = BC.fpn_train(64, modes=["eager", "graph", "pipeline"])
     out += res if isinstance(res, list) else [res]
-    res = BC.lidar_train(16, modes=("eager", "graph", "pipeline"))
+    res = BC.lidar_train(64, modes=("eager", "graph", "pipeline"))
     out += res if isinstance(res, list) else [res]
     return {"seconds": time.perf_counter() - t0, "runs": out}
 

@@ -161,6 +161,26 @@ def _build_fpn_train():
     return net, opt, blobs
 
 
+def _snapshot(net):
+    return {k: v.detach().clone() for k, v in net.state_dict().items()}
+
+
+def _restore(net, opt, state):
+    """Weights, buffers (BatchNorm statistics) and optimizer back to the snapshot, IN PLACE (captured graphs read parameters
+    and the derived filters by address), so that the modes of one run train the same net from the same point and their losses
+    are comparable."""
+    from faster_rcnn_pytorch_multimodal_amd.nets.hip_modules import refresh_derived_weights
+    with torch.no_grad():
+        own = net.state_dict()
+        for k, v in state.items():
+            own[k].copy_(v)
+        refresh_derived_weights(net)
+    opt.state.clear()
+    opt.zero_grad(set_to_none=False)
+    torch.manual_seed(7)
+    torch.cuda.synchronize()
+
+
 def _tune_and_count(net, opt, blobs, autotune=True):
     """Two eager steps with the plan autotuner on, then one eager step whose convolution calls are counted."""
     from faster_rcnn_pytorch_multimodal_amd import ops
@@ -191,7 +211,9 @@ def fpn_train(steps, autotune=True, graph=False, inflight=1, modes=None):
     if modes is None:
         modes = ["pipeline"] if inflight > 1 else ["graph"] if graph else ["eager"]
     out = []
+    start = _snapshot(net)
     for mode in modes:
+        _restore(net, opt, start)          # every mode starts from the SAME weights and an empty optimizer state
         if mode == "pipeline":
             n_in = inflight if inflight > 1 else 3
             losses, dt = _timed_pipeline_windows(net, blobs, opt, steps, n_in)
@@ -208,7 +230,8 @@ def fpn_train(steps, autotune=True, graph=False, inflight=1, modes=None):
                     "unit": "steps/s", "ms_per_step": 1e3 * dt / steps, "n_gpus": 1, "steps": steps, "dtype": "f32",
                     "mode": mode, "roofline": _roofline(fl, dt / steps, ("fwd", "dgrad", "wgrad")),
                     "config": {"workload": "BASELINE.json configs[3]: 8 random gt boxes, 12000/2000 proposals, 256 sampled RoIs, "
-                                           "FIXED_BLOCKS=1, SGD update every 16 steps",
+                                           "FIXED_BLOCKS=1, SGD update every 16 steps; every mode of a run starts from the same weights "
+                                           "and an empty optimizer state, median of 3 windows of `steps` steps",
                                "launch": launch, "filter_gradients": wg, "loss_first": losses[0], "loss_last": losses[-1],
                                "packet_capture_env": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")}})
     C.reset_cfg()
@@ -248,7 +271,9 @@ def lidar_train(steps, modes=("eager",)):
     blobs = {"data": data, "info": info, "gt_boxes": gt, "gt_boxes_dc": np.zeros((0, 4), np.float32)}
     fl = _tune_and_count(net, opt, blobs)
     out = []
+    start = _snapshot(net)
     for mode in modes:
+        _restore(net, opt, start)
         if mode == "graph":
             net.enable_train_graphs(True)
         if mode == "pipeline":
@@ -307,12 +332,12 @@ def main():
     if args.lidar or both:
         print(json.dumps(lidar_forward(args.steps or 80)))
     if args.train or both:
-        res = fpn_train(args.steps or 16, not args.no_autotune, args.graph, args.inflight,
+        res = fpn_train(args.steps or 64, not args.no_autotune, args.graph, args.inflight,
                         modes=args.modes.split(",") if args.modes else None)
         for r in (res if isinstance(res, list) else [res]):
             print(json.dumps(r))
     if args.lidar_train or both:
-        res = lidar_train(args.steps or 16, modes=tuple(args.modes.split(",")) if args.modes else ("eager", "graph", "pipeline"))
+        res = lidar_train(args.steps or 64, modes=tuple(args.modes.split(",")) if args.modes else ("eager", "graph", "pipeline"))
         for r in (res if isinstance(res, list) else [res]):
             print(json.dumps(r))
 
