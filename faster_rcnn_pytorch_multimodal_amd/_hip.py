@@ -112,7 +112,7 @@ PROTOTYPES = {
                                            c_int, c_int, _P, c_size_t, _P]),
     "frcnn_set_memops_mode": (c_int, [c_int]),
     "frcnn_get_memops_mode": (c_int, []),
-    "frcnn_settings_epoch": (ctypes.c_uint, []),
+    "frcnn_settings_signature": (ctypes.c_uint, []),
     "frcnn_dropout_fwd": (c_int, [_P, c_int64, c_int, c_float, c_uint32, _P, c_uint32, _P, _P]),
     "frcnn_dropout_bwd": (c_int, [_P, c_int64, c_int, c_float, c_uint32, _P, c_uint32, _P, _P]),
     "frcnn_logit_distort": (c_int, [_P, _P, c_int64, c_int, c_uint32, _P, c_uint32, c_int, _P, _P, _P]),

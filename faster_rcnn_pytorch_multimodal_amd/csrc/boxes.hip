@@ -1174,7 +1174,7 @@ extern "C" int frcnn_gather_rows(const float* rows, const int64_t* order, const 
 // kernel, `>`).  Read at launch time; a captured hipGraph keeps the setting it was captured under.
 static std::atomic<int> g_nms_at_equal{1};
 extern "C" int frcnn_nms_set_suppress_at_equal(int on) {
-  if (g_nms_at_equal.exchange(on ? 1 : 0) != (on ? 1 : 0)) frcnn::bump_settings_epoch();
+  g_nms_at_equal.store(on ? 1 : 0);
   return FRCNN_OK;
 }
 extern "C" int frcnn_nms_get_suppress_at_equal(void) { return g_nms_at_equal.load(); }
@@ -1224,9 +1224,11 @@ extern "C" int frcnn_make_rois(const float* sorted_boxes, const float* sorted_sc
 // test hook: 0 = automatic (LDS kernel for num_rois <= 1024), 1 = always the general kernel
 static int g_filter_variant = 0;
 extern "C" int frcnn_filter_set_variant(int v) {
-  if (g_filter_variant != v) frcnn::bump_settings_epoch();
   g_filter_variant = v;
   return FRCNN_OK;
+}
+unsigned long long frcnn::boxes_settings_word() {
+  return (unsigned long long)(unsigned)g_filter_variant | ((unsigned long long)(unsigned)g_nms_at_equal.load() << 32);
 }
 
 static size_t filter_ws_per_class(int num_rois) {

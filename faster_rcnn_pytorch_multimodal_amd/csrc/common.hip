@@ -68,15 +68,18 @@ hipError_t copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t stre
 
 }  // namespace frcnn
 
-namespace frcnn {
-static std::atomic<unsigned> g_settings_epoch{0};
-void bump_settings_epoch() { g_settings_epoch.fetch_add(1); }
-}  // namespace frcnn
-extern "C" unsigned frcnn_settings_epoch(void) { return frcnn::g_settings_epoch.load(); }
+extern "C" unsigned frcnn_settings_signature(void) {
+  unsigned long long words[4] = {(unsigned long long)frcnn::g_memops_mode.load(), frcnn::conv_settings_word(),
+                                 frcnn::roi_settings_word(), frcnn::boxes_settings_word()};
+  unsigned long long h = 1469598103934665603ull;                    // FNV-1a over the words' bytes
+  for (unsigned long long w : words)
+    for (int b = 0; b < 8; ++b) { h ^= (w >> (8 * b)) & 0xffu; h *= 1099511628211ull; }
+  return (unsigned)(h ^ (h >> 32));
+}
 
 extern "C" int frcnn_set_memops_mode(int mode) {
   if (mode != 0 && mode != 1) return frcnn::fail(FRCNN_ERR_ARG, "set_memops_mode: 0 (kernels) or 1 (hipMemsetAsync / hipMemcpyAsync)");
-  if (frcnn::g_memops_mode.exchange(mode) != mode) frcnn::bump_settings_epoch();
+  frcnn::g_memops_mode.store(mode);
   return FRCNN_OK;
 }
 extern "C" int frcnn_get_memops_mode(void) { return frcnn::g_memops_mode.load(); }

@@ -1316,8 +1316,8 @@ extern "C" int frcnn_conv2d_set_tile(int tm, int tn) {
   for (int i = 0; i < kNumTiles; ++i) known = known || (kTiles[i].tm == tm && kTiles[i].tn == tn);
   FRCNN_REQUIRE(known, "conv2d_set_tile: tiles are 64*tm x 64*tn with (tm,tn) in "
                        "{(4,2),(2,4),(2,2),(2,1),(1,2),(1,1)} ((0,0) = automatic)");
-  if (g_force_tm.exchange(tm) != tm) frcnn::bump_settings_epoch();
-  if (g_force_tn.exchange(tn) != tn) frcnn::bump_settings_epoch();
+  g_force_tm = tm;
+  g_force_tn = tn;
   return FRCNN_OK;
 }
 
@@ -1326,16 +1326,15 @@ extern "C" int frcnn_conv2d_set_algo(int mode) {
                 "conv2d_set_algo: mode %d (0 auto, 1 implicit GEMM only, 2 Winograd where it applies; +16: never fuse the "
                 "Winograd input transform into the GEMM, +32: forced Winograd uses the 64x64 GEMM with the fused transform, +64: the "
                 "register-staged kernels store straight from the MFMA layout instead of through the LDS transpose)", mode);
-  const int fuse = (mode & 16) ? 0 : ((mode & 32) ? 2 : 1), epi = (mode & 64) ? 0 : 1;
-  const bool same = g_algo_mode.exchange(mode & 3) == (mode & 3);
-  const bool same_f = g_wino_fuse.exchange(fuse) == fuse, same_e = g_epi_lds.exchange(epi) == epi;
-  if (!(same && same_f && same_e)) frcnn::bump_settings_epoch();
+  g_algo_mode = mode & 3;
+  g_wino_fuse = (mode & 16) ? 0 : ((mode & 32) ? 2 : 1);
+  g_epi_lds = (mode & 64) ? 0 : 1;
   return FRCNN_OK;
 }
 
 extern "C" int frcnn_conv2d_set_staging(int use_lds_dma) {
   FRCNN_REQUIRE(use_lds_dma >= 0 && use_lds_dma <= 3, "conv2d_set_staging: mode %d (0 .. 3)", use_lds_dma);
-  if (g_use_dma.exchange(use_lds_dma) != use_lds_dma) frcnn::bump_settings_epoch();
+  g_use_dma = use_lds_dma;
   return FRCNN_OK;
 }
 
@@ -1394,6 +1393,12 @@ extern "C" int frcnn_conv2d_set_autotune(int enable) {
 }
 
 bool frcnn::autotune_enabled() { return g_autotune != 0; }
+
+unsigned long long frcnn::conv_settings_word() {
+  return (unsigned long long)g_algo_mode.load() | ((unsigned long long)g_wino_fuse.load() << 4) |
+         ((unsigned long long)g_epi_lds.load() << 8) | ((unsigned long long)g_use_dma.load() << 12) |
+         ((unsigned long long)g_force_tm.load() << 16) | ((unsigned long long)g_force_tn.load() << 24);
+}
 
 extern "C" int frcnn_conv2d_clear_plans(void) {
   {

@@ -901,11 +901,15 @@ constexpr bool RES_AUTO = false;   // flipped when the map-resident kernel beats
 static int g_res_dbg = 0;      // ablation mask of the map-resident kernel (variant 1000 + mask): 1 no map load, 2 no tables,
                                // 4 no stores, 8 no row loop - timing experiments only, results are then wrong
 extern "C" int frcnn_roi_align_set_variant(int v) {
-  frcnn::bump_settings_epoch();
   if (v >= 1000) { g_res_dbg = v - 1000; return FRCNN_OK; }
   if (v >= 100) { g_roi_heavy_loads = v; return FRCNN_OK; }
   g_roi_variant = v;
   return FRCNN_OK;
+}
+
+unsigned long long frcnn::roi_settings_word() {
+  return (unsigned long long)(unsigned)g_roi_variant | ((unsigned long long)(unsigned)g_roi_heavy_loads << 16) |
+         ((unsigned long long)(unsigned)g_res_dbg << 40);
 }
 
 static bool resident_ok(int h, int w, int c, int pooled) {

@@ -136,7 +136,7 @@ def cfg_fingerprint(net):
     """Everything outside the frame's shape that a captured frame bakes in: proposal / NMS / pooling settings, the
     uncertainty flags and sample counts, the process-wide kernel switches (the Python-level ones by value, the library's -
     forced tile, convolution algorithm / staging, RoIAlign and filter variants, memops mode, NMS tie rule - through
-    ``frcnn_settings_epoch``, which advances whenever one of them changes value), the modules' train / eval state."""
+    ``frcnn_settings_signature``, a hash of their current values), the modules' train / eval state."""
     from .. import _hip, ops
     from ..nets import network as N
     t, u = cfg.TEST, cfg.UC
@@ -147,7 +147,7 @@ def cfg_fingerprint(net):
             str(t.get('MODE', 'nms')), int(t.get('RPN_TOP_N', 0)), str(cfg.POOLING_MODE), int(cfg.POOLING_SIZE),
             bool(cfg.ENABLE_CUSTOM_TAIL), uc, int(u.E_NUM_SAMPLE), int(u.A_NUM_CE_SAMPLE), ops.nms_suppress_at_equal(),
             ops._CONV_ALGO_MODE, ops._CONV_ALGO_FLAGS, bool(N.PROJECT_BEFORE_POOLING), bool(N.FUSE_PROJECTIONS),
-            int(N.ROI_ALIGN_SAMPLING_RATIO), int(_hip.load().frcnn_settings_epoch()), hash(modes))
+            int(N.ROI_ALIGN_SAMPLING_RATIO), int(_hip.load().frcnn_settings_signature()), hash(modes))
 
 
 class FramePool:

@@ -36,11 +36,11 @@ int frcnn_version(void);
  * (memset / memcpy graph nodes).  See DESIGN.md section 4.8 for why the default is 0.  Process-wide, read at call time. */
 int frcnn_set_memops_mode(int mode);
 int frcnn_get_memops_mode(void);
-/* Counter that advances whenever a process-wide switch that selects kernels changes value (frcnn_set_memops_mode,
- * frcnn_conv2d_set_tile / _set_algo / _set_staging, frcnn_roi_align_set_variant, frcnn_filter_set_variant,
- * frcnn_nms_set_suppress_at_equal): a caller that holds captured hipGraphs of entry points of this library (the reference's
- * per-frame loop lib/model/test.py:183-228 replayed by model/frame_graph.FramePool) compares it to know its captures are stale. */
-unsigned frcnn_settings_epoch(void);
+/* Hash of the CURRENT VALUES of every process-wide switch that selects kernels (frcnn_set_memops_mode, frcnn_conv2d_set_tile /
+ * _set_algo / _set_staging, frcnn_roi_align_set_variant, frcnn_filter_set_variant, frcnn_nms_set_suppress_at_equal): a caller
+ * that holds captured hipGraphs of entry points of this library (the reference's per-frame loop lib/model/test.py:183-228
+ * replayed by model/frame_graph.FramePool) keys its captures by it - another value means the captures describe other kernels. */
+unsigned frcnn_settings_signature(void);
 const char* frcnn_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------

@@ -283,9 +283,10 @@ def test_storage_stable_weight_caches_keep_addresses_and_refresh():
 
 
 def test_train_graph_refuses_what_it_cannot_capture():
-    """graphable(): what still runs eagerly (with a warning from Network.train_step) - don't-care boxes, frames without gt,
-    BatchNorm with a host-computed momentum.  The LiDAR detector, FIXED_BLOCKS = -1 and the uncertainty heads ARE capturable
-    since round 4 (device-side gt count / seeds, in-kernel running statistics)."""
+    """graphable(): what still runs eagerly (with a warning from Network.train_step) - more don't-care boxes than the captured
+    step's buffer holds, frames without gt, BatchNorm with a host-computed momentum.  The LiDAR detector, FIXED_BLOCKS = -1 and
+    the uncertainty heads ARE capturable since round 4 (device-side gt count / seeds, in-kernel running statistics), frames
+    with don't-care boxes since round 5 (padded buffer)."""
     import torch.nn as nn
     from faster_rcnn_pytorch_multimodal_amd.model import config as C
     from faster_rcnn_pytorch_multimodal_amd.model import train_graph
@@ -304,7 +305,8 @@ def test_train_graph_refuses_what_it_cannot_capture():
     assert train_graph.graphable(net, blobs) is None
     C.reset_cfg()
     C.cfg.TRAIN.IGNORE_DC = True
-    assert "don't-care" in train_graph.graphable(net, dict(blobs, gt_boxes_dc=np.zeros((3, 5), np.float32)))
+    assert train_graph.graphable(net, dict(blobs, gt_boxes_dc=np.zeros((3, 5), np.float32))) is None
+    assert "don't-care" in train_graph.graphable(net, dict(blobs, gt_boxes_dc=np.zeros((train_graph.DC_CAPACITY + 1, 5), np.float32)))
     C.reset_cfg()
     net[1].momentum = None
     assert "momentum" in train_graph.graphable(net, blobs)
