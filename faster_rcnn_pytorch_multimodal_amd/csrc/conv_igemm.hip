@@ -32,6 +32,7 @@
 #include <type_traits>
 #include <hip/hip_ext.h>
 
+#include <algorithm>
 #include <array>
 #include <map>
 #include <mutex>
@@ -1824,41 +1825,59 @@ bool tune_plan(const ConvParams& p, long M, int k, const float* scale, const flo
       cands.push_back(pl);
     }
   }
+  // Level 1: two passes over all candidates, each timed alone; a candidate keeps its best time (a one-off disturbance can
+  // neither crown a slow plan nor bury the fast one).  Level 2: one such pass, then the kLoadFinalists fastest candidates are
+  // timed under load (two passes) and ranked by that - every candidate under load would take 4x the tuning time for plans
+  // that are already 1.3x off alone.
   std::vector<float> best_of(cands.size(), 1e30f);
   LoadStreams* ls = nullptr;
   if (g_autotune == 2) {
     ls = &load_streams();
     if (!ls->ok) ls = nullptr;     // no extra streams: fall back to timing alone
   }
-  for (int pass = 0; pass < 2; ++pass) {
-    for (size_t ci = 0; ci < cands.size(); ++ci) {
-      const Plan& pl = cands[ci];
-      const size_t need = plan_ws_bytes(pl, p, M, k);
-      if (need > ws_bytes || (need > 0 && !ws)) continue;
-      if (pass == 0 && launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, stream) != FRCNN_OK) continue;   // warm-up
-      (void)hipEventRecord(e0, stream);
-      const int reps = 3;
-      bool ok = true;
-      if (ls) {
-        for (int j = 0; j < kLoadCopies - 1; ++j) (void)hipStreamWaitEvent(ls->s[j], e0, 0);
-        for (int i = 0; i < reps && ok; ++i) {
-          ok = launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, stream) == FRCNN_OK;
-          for (int j = 0; j < kLoadCopies - 1 && ok; ++j)
-            ok = launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, ls->s[j]) == FRCNN_OK;
-        }
-        for (int j = 0; j < kLoadCopies - 1; ++j) {      // the caller's stream ends the region when every copy is done
-          (void)hipEventRecord(ls->done[j], ls->s[j]);
-          (void)hipStreamWaitEvent(stream, ls->done[j], 0);
-        }
-      } else {
-        for (int i = 0; i < reps && ok; ++i) ok = launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, stream) == FRCNN_OK;
+  auto time_candidate = [&](size_t ci, bool warm, bool loaded) -> float {
+    const Plan& pl = cands[ci];
+    const size_t need = plan_ws_bytes(pl, p, M, k);
+    if (need > ws_bytes || (need > 0 && !ws)) return 1e30f;
+    if (warm && launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, stream) != FRCNN_OK) return 1e30f;
+    (void)hipEventRecord(e0, stream);
+    const int reps = 3;
+    bool ok = true;
+    if (loaded) {
+      for (int j = 0; j < kLoadCopies - 1; ++j) (void)hipStreamWaitEvent(ls->s[j], e0, 0);
+      for (int i = 0; i < reps && ok; ++i) {
+        ok = launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, stream) == FRCNN_OK;
+        for (int j = 0; j < kLoadCopies - 1 && ok; ++j)
+          ok = launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, ls->s[j]) == FRCNN_OK;
       }
-      (void)hipEventRecord(e1, stream);
-      if (hipEventSynchronize(e1) != hipSuccess || !ok) continue;
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
-      best_of[ci] = std::min(best_of[ci], ms);
+      for (int j = 0; j < kLoadCopies - 1; ++j) {      // the caller's stream ends the region when every copy is done
+        (void)hipEventRecord(ls->done[j], ls->s[j]);
+        (void)hipStreamWaitEvent(stream, ls->done[j], 0);
+      }
+    } else {
+      for (int i = 0; i < reps && ok; ++i) ok = launch_plan(p, pl, M, k, scale, shift, residual, y, relu, ws, stream) == FRCNN_OK;
     }
+    (void)hipEventRecord(e1, stream);
+    if (hipEventSynchronize(e1) != hipSuccess || !ok) return 1e30f;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return 1e30f;
+    return ms;
+  };
+  for (int pass = 0; pass < (ls ? 1 : 2); ++pass)
+    for (size_t ci = 0; ci < cands.size(); ++ci) best_of[ci] = std::min(best_of[ci], time_candidate(ci, pass == 0, false));
+  if (ls) {
+    constexpr size_t kLoadFinalists = 6;
+    std::vector<size_t> order(cands.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return best_of[a] < best_of[b]; });
+    std::vector<float> loaded(cands.size(), 1e30f);
+    for (int pass = 0; pass < 2; ++pass)
+      for (size_t r = 0; r < std::min(kLoadFinalists, order.size()); ++r) {
+        const size_t ci = order[r];
+        if (best_of[ci] >= 1e30f) continue;
+        loaded[ci] = std::min(loaded[ci], time_candidate(ci, false, true));
+      }
+    best_of = loaded;
   }
   float best_ms = 1e30f;
   bool found = false;

@@ -121,10 +121,11 @@ int frcnn_conv2d_set_tile(int tm, int tn);
  * frcnn_conv2d_fwd_ws_bytes returns room for the largest candidate of a not-yet-tuned shape.  Default: off (the
  * analytic model picks).  frcnn_conv2d_bwd_weight follows the same switch with its own cache (tile 128x128 or 64x64 x
  * pixel splits).  frcnn_conv2d_clear_plans forgets both caches.
- * enable == 2: each candidate is timed UNDER LOAD - four launches of it in flight at once on four streams (the caller's and
- * three of the library's own; all copies compute the same values into the same tensors) - i.e. ranked by throughput on a busy
- * chip, which is what a caller that keeps several frames in flight needs (lib/model/test.py:183-228 replayed four frames at a
- * time), instead of by the latency of one launch on an idle chip. */
+ * enable == 2: after one pass that times every candidate alone, the six fastest are timed UNDER LOAD - four launches of the
+ * candidate in flight at once on four streams (the caller's and three of the library's own; all copies compute the same values
+ * into the same tensors) - and ranked by that, i.e. by throughput on a busy chip, which is what a caller that keeps several
+ * frames in flight needs (lib/model/test.py:183-228 replayed four frames at a time), instead of by the latency of one launch on
+ * an idle chip. */
 /* Form of the cached (tuned or imported) plan of a stride-1-output forward call of this shape: -1 none, 0 implicit GEMM,
  * 1 Winograd F(2x2,3x3).  Calls with and without a residual operand are planned separately.  Callers that keep a
  * pre-transformed Winograd filter (frcnn_conv2d_fwd_pre) use this to build it only for layers whose plan reads it. */
