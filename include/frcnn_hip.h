@@ -490,7 +490,10 @@ int frcnn_lidar_bbox_transform(const float* ex_rois, int roi_ld, const float* ex
 size_t frcnn_anchor_target_layer_ws_bytes(int num_anchors_total, int num_gt, int rpn_batchsize);
 int frcnn_anchor_target_layer(const float* anchors, int n, const float* gt_boxes, int num_gt,
                               const int* num_gt_dev /* device int or NULL: live rows of a gt buffer padded to num_gt rows
-                              (one captured training step serves every number of gt boxes) */,
+                              (one captured training step serves every number of gt boxes).  REQUIRED: 1 <= *num_gt_dev <=
+                              num_gt - the kernels clamp the value into that range, so a 0 would make row 0 of the buffer a
+                              ground-truth box; a frame without gt boxes must not be launched (the reference stops on it too,
+                              lib/layer_utils/proposal_target_layer.py:232-235) */,
                               const float* info_host, int rpn_batchsize, float fg_fraction, float negative_overlap,
                               float positive_overlap, uint32_t seed, const uint32_t* seed_dev, float* labels,
                               float* targets, float* inside, float* outside, int* counts, void* ws, size_t ws_bytes,
