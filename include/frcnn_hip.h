@@ -141,18 +141,21 @@ int frcnn_conv2d_profile_begin(void);
 int frcnn_conv2d_profile_end(float* us, int* call, int* kind, int capacity);
 int frcnn_conv2d_set_autotune(int enable);
 int frcnn_conv2d_clear_plans(void);
-/* The plan cache as a table of 13 ints per entry (shape key n,h,w,c,k,r,s,stride,pad,out_stride; tile index [+16], splits,
- * K-steps per split), so that a tuned table can be saved and replayed (e.g. under a profiler, whose instrumentation
- * would otherwise perturb the tuning).  export returns the number of cached entries (fills at most capacity_entries);
- * import validates and inserts. */
+/* The plan cache as a table of 13 ints per entry (shape key n,h,w,c,k,r,s,stride,pad,out_stride [+256: call with a residual];
+ * tile index [+16: Winograd F(2x2,3x3) around the grouped GEMM, +32: with the input transform fused into the 64x64 GEMM], splits,
+ * K-steps per split), so that a tuned table can be saved and replayed (e.g. under a profiler, whose instrumentation would
+ * otherwise perturb the tuning; or shipped with a deployment: bench.py loads profiles/r05_plans.json).  Tile indices:
+ * 0 256x128, 1 128x256 (8 waves, LDS-DMA three stages), 2 128x128, 3 128x64, 4 64x128, 5 64x64 (register-staged), 6 128x128
+ * LDS-DMA two stages, 7 64x64, 8 128x64, 9 64x128, 10 128x128, 11 256x128, 12 128x256 (LDS-DMA through buffer loads, three
+ * stages).  export returns the number of cached entries (fills at most capacity_entries); import validates and inserts. */
 int frcnn_conv2d_export_plans(int* out, int capacity_entries);
 int frcnn_conv2d_import_plans(const int* in, int entries);
 
 /* Tuning / test hook: 1 (default) stages the 8-wave tiles with LDS-DMA (global_load_lds) when C % 32 == 0 (and the
  * autotuner may pick the two-stage LDS-DMA 128x128 tile, plan tile index 6), 0 uses the register-staged kernels
  * everywhere, 2 additionally runs a FORCED 128x128 tile (frcnn_conv2d_set_tile(2, 2)) on the two-stage LDS-DMA kernel,
- * 3 runs the 64x64 / 128x64 / 64x128 tiles (forced, or plan tile indices 3, 4, 5) on the buffer-load LDS-DMA kernel
- * (conv_igemm_buf_f32: plan tile indices 7, 8, 9 select it in every mode but 0).
+ * 3 runs FORCED tiles (and plan tile indices 0 .. 5) on the buffer-load LDS-DMA kernel (conv_igemm_buf_f32: plan tile
+ * indices 7 .. 12 select it in every mode but 0; needs C % 32 == 0 and operands below 2 GB, else the register-staged kernel).
  * Results are bit-identical for split_k = 1. */
 int frcnn_conv2d_set_staging(int use_lds_dma);
 
