@@ -312,3 +312,27 @@ def test_train_graph_refuses_what_it_cannot_capture():
     assert "momentum" in train_graph.graphable(net, blobs)
     assert [train_graph.gt_capacity(n) for n in (1, 32, 33, 64, 65)] == [32, 32, 64, 64, 128]
     C.reset_cfg()
+
+
+def test_committed_profiles_describe_the_committed_plan_table():
+    """bench.py quotes counter values from profiles/ only for the plan table they were collected with: the committed PMC
+    summaries must carry the hash of the committed table (bench.plans_sha) and the head they were collected at, and
+    `from_profiles` must null every plan-dependent value for a run on another table."""
+    import json
+    import bench
+    rows = json.load(open(os.path.join(ROOT, "profiles", bench.PLANS_FILE)))
+    sha = bench.plans_sha(rows)
+    assert sha == bench.plans_sha(list(reversed(rows)))                       # independent of row order
+    for name in (bench.PMC_FILE, bench.PMC_TIMED_FILE):
+        prof = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert prof["plans_sha"] == sha, name
+        assert prof["collected_at_head"] and prof["collected_at_head"] != "unknown", name
+    mine = bench.from_profiles(sha)
+    assert mine["plans_match"] and mine["conv_traffic_bytes_per_call"] > 3e7 and mine["mfma_busy_ms_per_frame_timed_mode"] > 1.0
+    other = bench.from_profiles("0" * 16)
+    assert not other["plans_match"] and other["conv_traffic_bytes_per_call"] is None
+    assert other["mfma_busy_ms_per_frame_timed_mode"] is None and other["conv_mfma_util_percent_isolated"] is None
+    assert other["roi_align_traffic_bytes_per_call"] == mine["roi_align_traffic_bytes_per_call"]   # not plan dependent
+    # every plan of the table is one the library accepts: tile index < 13, algorithm code <= 2
+    for r in rows:
+        assert len(r) == 13 and (r[10] & 15) < 13 and (r[10] >> 4) <= 2 and r[11] >= 1
