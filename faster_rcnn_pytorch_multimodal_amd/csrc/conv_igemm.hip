@@ -107,8 +107,10 @@ __device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, 
 // 32x32 tile are issued before its first store.
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc,
-                                              int lane) {
-  const size_t goff = (size_t)blockIdx.y * p.gy;   // grouped launches have neither a residual nor split-K slabs
+                                              int lane, int gy = -1, int gz = -1) {
+  if (gy < 0) gy = blockIdx.y;                     // (the persistent kernel walks groups / splits itself)
+  if (gz < 0) gz = blockIdx.z;
+  const size_t goff = (size_t)gy * p.gy;   // grouped launches have neither a residual nor split-K slabs
   // The MFMA operands are (weights, activations), so D has the PIXEL on the lane (col = lane&31) and
   // the CHANNEL in the registers: row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Registers 4g..4g+3 are four
   // consecutive channels -> every access of the epilogue is a 16-byte vector per lane, and all
@@ -117,7 +119,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
   // load->wait->store chain per element).
   const int mlane = lane & 31, nhalf = 4 * (lane >> 5);
   const bool vec = (p.K & 3) == 0;
-  float* const slab = p.partial ? p.partial + (size_t)blockIdx.z * p.M * p.K : nullptr;
+  float* const slab = p.partial ? p.partial + (size_t)gz * p.M * p.K : nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + (wr * TM + i) * 32 + mlane;
@@ -194,9 +196,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 // the wave is then 8 rows x 128 contiguous bytes.  Same per-element arithmetic -> bit-identical results.  K % 4 == 0 only.
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue_lds(const ConvParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc,
-                                                  int lane, float* __restrict__ patch) {
-  const size_t goff = (size_t)blockIdx.y * p.gy;
-  float* const slab = p.partial ? p.partial + (size_t)blockIdx.z * p.M * p.K : nullptr;
+                                                  int lane, float* __restrict__ patch, int gy = -1, int gz = -1) {
+  if (gy < 0) gy = blockIdx.y;
+  if (gz < 0) gz = blockIdx.z;
+  const size_t goff = (size_t)gy * p.gy;
+  float* const slab = p.partial ? p.partial + (size_t)gz * p.M * p.K : nullptr;
   const int wpix = lane & 31, whalf = 4 * (lane >> 5);       // write phase: MFMA layout
   const int rrow = lane >> 3, rcol = 4 * (lane & 7);         // read phase: 8 lanes x 16 B per pixel row
 #pragma unroll
@@ -1040,6 +1044,200 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 1) ? 3 : 2) void conv_ige
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// PERSISTENT form of the buffer-load LDS-DMA kernel for the 64x64 tile (plan tile index 13).
+//
+// Section 4.10 of DESIGN.md: a 64x64 tile of a short reduction (layer1-3: 2-16 K-steps, ~1-8 us of MFMA work) is launched,
+// computes its addresses, waits for its first two DMA round trips, runs its K loop, stores and exits - the skeleton costs
+// as much as the loop, and co-resident workgroups only partly cover each other's skeletons.  Here a workgroup is resident for
+// the whole launch (grid = 2 workgroups per CU at most) and walks its WORK ITEMS (tile x group x K-split, item i, i + grid,
+// ...) as ONE stream of K-steps through the same three-stage LDS ring: while the last K-steps of an item compute, the DMA of the
+// next item's first steps is already in flight (a producer cursor runs two steps ahead of the consumer cursor, across item
+// boundaries), so from its second item on a workgroup pays neither dispatch nor address set-up nor a cold first load before
+// its MFMAs - only the epilogue (LDS transpose in a patch of its own, stores) sits between two items' MFMAs.
+// Same LDS image, k order and epilogue arithmetic as conv_igemm_buf_f32: bit-identical for split_k == 1.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv_igemm_pbuf_f32(const ConvParams p, int groups, int splits) {
+  constexpr int WN = 2, TM = 1, TN = 1;
+  constexpr int BM = 64, BN = 64, PA = 2, PB = 2;       // 4 waves x 8 rows per DMA instruction: 2 + 2 instructions per wave and step
+  constexpr int STAGE = (BM + BN) * 32;                 // floats per stage
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][BM + BN][32] ring + [4 waves][32][36] epilogue patches
+  float* const patch = smem + 3 * STAGE + (threadIdx.x >> 6) * 32 * LDS_PITCH;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wr = wave / WN, wc = wave % WN;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int total = ntiles * groups * splits;
+  const int stride = gridDim.x;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+
+  // item -> (tile, group, split); tiles in the XCD-aware raster order of the other kernels
+  auto item_coords = [&](int item, int& m0, int& n0, int& g, int& z) {
+    const int tl = item % ntiles, gz = item / ntiles;
+    g = gz % groups;
+    z = gz / groups;
+    int tile_m, tile_n;
+    tile_coords(xcd_remap(tl, ntiles), p.tiles_m, p.tiles_n, tile_m, tile_n);
+    m0 = tile_m * BM;
+    n0 = tile_n * BN;
+  };
+  auto item_steps = [&](int z, int& begin) {
+    begin = z * p.steps_per_split;
+    return min(begin + p.steps_per_split, p.ksteps) - begin;
+  };
+
+  // ---- producer cursor: the item / step whose tiles are issued next ------------------------------------------------------
+  const int lrow = lane >> 3, lchunk = lane & 7;
+  int p_item = blockIdx.x, p_step = 0, p_nst = 0, p_begin = 0, p_stage = 0;
+  int a_pix[PA], a_hi0[PA], a_wi0[PA];
+  unsigned a_swz[PA], vA[PA], vB[PB];
+  int tr = 0, ts = 0, tc = 0;
+  bool new_tap = true;
+  __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.xbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.wbytes, 0x00020000);
+  auto producer_setup = [&]() {                        // geometry of item p_item (uniform: p_item < total)
+    int m0, n0, g, z;
+    item_coords(p_item, m0, n0, g, z);
+    p_nst = item_steps(z, p_begin);
+    p_step = 0;
+    rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)g * p.gx), 0, (int)p.xbytes, 0x00020000);
+    rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w + (size_t)g * p.gw), 0, (int)p.wbytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+      const int row = (wave * PA + j) * 8 + lrow;
+      const int m = m0 + row;
+      a_swz[j] = (unsigned)((lchunk ^ ((row >> 1) & 7)) * 16);
+      if (m < p.M) {
+        const int img = m / (p.Ho * p.Wo);
+        const int rem = m - img * p.Ho * p.Wo;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        a_hi0[j] = ho * p.stride - p.pad;
+        a_wi0[j] = wo * p.stride - p.pad;
+        a_pix[j] = ((img * p.H + a_hi0[j]) * p.W + a_wi0[j]) * p.C * 4;
+      } else {
+        a_hi0[j] = -(1 << 20);
+        a_wi0[j] = 0;
+        a_pix[j] = 0;
+      }
+      vA[j] = OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const int row = (wave * PB + j) * 8 + lrow;
+      const int n = n0 + row;
+      vB[j] = n < p.K ? (unsigned)(n * p.Ktot * 4 + (lchunk ^ ((row >> 1) & 7)) * 16) : OOB;
+    }
+    const int kf = p_begin * BK;
+    const int tap = kf / p.C;
+    tc = kf - tap * p.C;
+    tr = tap / p.S;
+    ts = tap - tr * p.S;
+    new_tap = true;
+  };
+  // issues the tiles of the producer's step into the producer's stage and advances the cursor; false when the stream is over
+  auto issue_next = [&]() -> bool {
+    if (p_item >= total) return false;
+    float* sA = smem + p_stage * STAGE + (wave * PA) * 8 * 32;
+    float* sB = smem + p_stage * STAGE + BM * 32 + (wave * PB) * 8 * 32;
+    if (new_tap) {
+      const int toff = (tr * p.W + ts) * p.C * 4;
+#pragma unroll
+      for (int j = 0; j < PA; ++j) {
+        const int hi = a_hi0[j] + tr, wi = a_wi0[j] + ts;
+        const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        vA[j] = ok ? (unsigned)(a_pix[j] + toff) + a_swz[j] : OOB;
+      }
+    }
+    const int sa = tc * 4, sb = (p_begin + p_step) * (BK * 4);
+#pragma unroll
+    for (int j = 0; j < PA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(sA + j * 8 * 32), 16, (int)vA[j], sa, 0, 0);
+#pragma unroll
+    for (int j = 0; j < PB; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr)(sB + j * 8 * 32), 16, (int)vB[j], sb, 0, 0);
+    tc += BK;
+    new_tap = tc == p.C;
+    if (new_tap) {
+      tc = 0;
+      if (++ts == p.S) { ts = 0; ++tr; }
+    }
+    p_stage = p_stage == 2 ? 0 : p_stage + 1;
+    if (++p_step == p_nst) {
+      p_item += stride;
+      if (p_item < total) producer_setup();
+    }
+    return true;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+  const int lh = lane >> 5;
+  int fa_off[4], fb_off[4];
+  {
+    const int rowa = wr * 32 + (lane & 31), rowb = wc * 32 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      fa_off[kk] = rowa * 32 + (((2 * kk + lh) ^ ((rowa >> 1) & 7)) << 2);
+      fb_off[kk] = BM * 32 + rowb * 32 + (((2 * kk + lh) ^ ((rowb >> 1) & 7)) << 2);
+    }
+  }
+  f32x4 fa0, fb0, fa1, fb1;
+  auto read_frags = [&](f32x4& fa, f32x4& fb, int stage, int kk) {
+    const float* base = smem + stage * STAGE;
+    fa = *reinterpret_cast<const f32x4*>(base + fa_off[kk]);
+    fb = *reinterpret_cast<const f32x4*>(base + fb_off[kk]);
+  };
+  auto mma = [&](const f32x4& fa, const f32x4& fb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[q], fa[q], acc[0][0], 0, 0, 0);
+  };
+
+  if (blockIdx.x >= total) return;                     // (uniform) more workgroups than items: nothing to do
+  // The stream: step g of this workgroup's items lives in stage g % 3.  `ahead` = steps issued - steps consumed (1 or 2 at the
+  // top of a step): ahead >= 2 <=> a next step exists.
+  producer_setup();
+  issue_next();                                        // stream step 0
+  int ahead = issue_next() ? 2 : 1;                    // stream step 1
+  if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  read_frags(fa0, fb0, 0, 0);
+  int stage = 0;
+  for (int item = blockIdx.x; item < total; item += stride) {
+    int m0, n0, g, z, begin;
+    item_coords(item, m0, n0, g, z);
+    const int nst = item_steps(z, begin);
+    for (int s = 0; s < nst; ++s) {
+      const int next = stage == 2 ? 0 : stage + 1;
+      const bool more = ahead >= 2;
+      read_frags(fa1, fb1, stage, 1);
+      mma(fa0, fb0);
+      read_frags(fa0, fb0, stage, 2);
+      mma(fa1, fb1);
+      if (more) {
+        // everything this wave has issued is waited for: the DMA of the next stream step and, behind an item boundary, the
+        // previous item's stores (issued half a K-step ago)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (issue_next()) ++ahead;                     // stream step + 2 goes into the stage step - 1 used
+      }
+      read_frags(fa1, fb1, stage, 3);
+      mma(fa0, fb0);
+      if (more) read_frags(fa0, fb0, next, 0);
+      mma(fa1, fb1);
+      stage = next;
+      --ahead;
+    }
+    if (p.epi_lds && (p.K & 3) == 0) conv_epilogue_lds<TM, TN>(p, acc, m0, n0, wr, wc, lane, patch, g, z);
+    else conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane, g, z);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+  }
+}
+
 // Split-K second pass: y = act((sum_z partial[z]) * scale + shift + res), slabs summed in z order.
 __global__ __launch_bounds__(256) void conv_splitk_epilogue(const float* __restrict__ partial, int splits,
                                                            size_t mk, int K, const float* scale,
@@ -1076,6 +1274,7 @@ constexpr TileCfg kTiles[] = {
     {2, 2, 2, 2, 2, 2},  // 128x128, the same kernel, 96 KB of LDS: one workgroup per CU (else as index 2)
     {4, 2, 4, 2, 2, 2},  // 256x128, the same kernel, 8 waves (else as index 0)
     {2, 4, 2, 4, 2, 2},  // 128x256, the same kernel, 8 waves (else as index 1)
+    {1, 1, 2, 2, 1, 1},  // 64x64, PERSISTENT workgroups walking their tiles as one K-step stream (conv_igemm_pbuf_f32; else as index 7)
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -1282,6 +1481,25 @@ int launch_conv_buf(const ConvParams& p, int splits, int groups, hipStream_t str
   else
     hipLaunchKernelGGL((conv_igemm_buf_f32<WM, WN, TM, TN>), grid, dim3(64 * WM * WN), lds, stream, p);
   return frcnn::check_launch("conv_igemm_buf_f32");
+}
+
+int launch_conv_pbuf(const ConvParams& p, int splits, int groups, hipStream_t stream) {
+  constexpr size_t lds = ((size_t)3 * (64 + 64) * 32 + (size_t)4 * 32 * LDS_PITCH) * sizeof(float);
+  static std::atomic<bool> configured{false};   // idempotent attribute call: a race only repeats it
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_pbuf_f32),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return frcnn::fail(FRCNN_ERR_LAUNCH, "conv: set LDS size: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  const long total = (long)p.tiles_m * p.tiles_n * groups * splits;
+  dim3 grid((unsigned)std::min<long>(total, 2L * NUM_CU));      // two resident workgroups per CU (66 KB of LDS each)
+  hipEvent_t e0, e1;
+  if (prof_events(0, &e0, &e1, stream))
+    hipExtLaunchKernelGGL(conv_igemm_pbuf_f32, grid, dim3(256), (uint32_t)lds, stream, e0, e1, 0, p, groups, splits);
+  else
+    hipLaunchKernelGGL(conv_igemm_pbuf_f32, grid, dim3(256), lds, stream, p, groups, splits);
+  return frcnn::check_launch("conv_igemm_pbuf_f32");
 }
 
 int launch_conv_dma2(const ConvParams& p, int splits, int groups, hipStream_t stream) {
@@ -1647,6 +1865,10 @@ int launch_gemm(ConvParams p, const Plan& pl, long M, int k, int groups, hipStre
     case 6:
       if (aligned && g_use_dma) rc = launch_conv_dma2(p, pl.splits, groups, stream);
       else FRCNN_CONV_CASE(2, 2, 2, 2);
+      break;
+    case 13:
+      if (aligned && g_use_dma && p.xbytes && p.wbytes) rc = launch_conv_pbuf(p, pl.splits, groups, stream);
+      else FRCNN_CONV_CASE(2, 2, 1, 1);
       break;
     case 10:
       if (aligned && g_use_dma && p.xbytes && p.wbytes) rc = launch_conv_buf<2, 2, 2, 2>(p, pl.splits, groups, stream);

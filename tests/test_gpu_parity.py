@@ -270,6 +270,73 @@ def test_conv2d_buffer_dma_kernel_is_bit_identical(hip, case):
 
 
 @pytest.mark.parametrize("case", [(1, 38, 63, 256, 1024, 1, 1, 0), (1, 38, 63, 1024, 256, 1, 1, 0), (1, 75, 125, 128, 128, 3, 1, 1),
+                                  (1, 150, 250, 64, 256, 1, 1, 0), (1, 9, 11, 32, 64, 1, 1, 0), (2, 9, 11, 96, 72, 1, 1, 0),
+                                  (1, 19, 32, 512, 512, 3, 2, 1), (3, 7, 7, 32, 36, 3, 1, 1), (1, 38, 62, 256, 512, 1, 2, 0),
+                                  (1, 5, 6, 288, 68, 1, 1, 0), (300, 7, 7, 512, 512, 1, 1, 0), (2, 13, 9, 64, 132, 5, 1, 2),
+                                  (1, 38, 63, 256, 256, 3, 1, 1), (4, 38, 63, 256, 1024, 1, 1, 0)])
+def test_conv2d_persistent_kernel_is_bit_identical(hip, case):
+    """conv_igemm_pbuf_f32 (plan tile index 13): resident workgroups that walk their work items - tile x Winograd component x
+    K split - as ONE stream of K-steps through the LDS ring, the DMA of the next item's first steps in flight while the
+    current item finishes.  Against the register-staged 64x64 kernel: identical bits.  The cases cover grids with fewer items
+    than resident workgroups (one item each), with 1.2 .. 19 items per workgroup (the stream crosses item boundaries, incl.
+    boundaries between Winograd components and between K splits), 1 .. 72 K-steps per item, padding taps, strides, M / K
+    tails, residual + ReLU and the data gradient."""
+    ops = _ops()
+    from faster_rcnn_pytorch_multimodal_amd import _hip
+    lib = _hip.load()
+    n, h, w, c, k, r, stride, pad = case
+    g = torch.Generator().manual_seed(7 * c + k + n)
+    x = torch.randn(n, h, w, c, generator=g).to(DEV)
+    wt = (torch.randn(k, r, r, c, generator=g) / (r * c ** 0.5)).to(DEV)
+    sc, sh = (torch.rand(k, generator=g) + 0.5).to(DEV), torch.randn(k, generator=g).to(DEV)
+    ho, wo = (h + 2 * pad - r) // stride + 1, (w + 2 * pad - r) // stride + 1
+    res = torch.randn(n, ho, wo, k, generator=g).to(DEV)
+    ksteps = r * r * c // 32
+    wino = ops.winograd_eligible(k, r, r, c, stride, pad)
+    key = [n, h, w, c, k, r, r, stride, pad]
+
+    def run_all(code_of, splits_of):
+        """code_of(tile code for a plain plan), splits_of(list of splits): outputs of every form under those plans"""
+        out = []
+        for sp in splits_of:
+            sps = (ksteps + sp - 1) // sp
+            hip.frcnn_conv2d_clear_plans()
+            ops.import_conv_plans([key + [1 + 256, code_of, sp, sps], key + [1, code_of, sp, sps]])
+            ops.set_conv_algo(1)
+            out.append(ops.conv2d_nhwc(x, wt, sc, sh, res, stride=stride, pad=pad, relu=True))
+            out.append(ops.conv2d_nhwc(x, wt, None, None, None, stride=stride, pad=pad, relu=False))
+        if wino:
+            hip.frcnn_conv2d_clear_plans()
+            ops.import_conv_plans([key + [1, code_of + 16, 1, (c + 31) // 32]])
+            ops.set_conv_algo(0)
+            out.append(ops.conv2d_nhwc(x, wt, sc, sh, None, stride=stride, pad=pad, relu=True))
+        if stride == 1 and k % 32 == 0:
+            # the data gradient is a forward convolution of dy with the flipped filter: its own shape key
+            hip.frcnn_conv2d_clear_plans()
+            ops.import_conv_plans([[n, ho, wo, k, c, r, r, 1, r - 1 - pad, 1, code_of, 1, r * r * k // 32]])
+            ops.set_conv_algo(1)
+            out.append(ops.conv2d_bwd_data(res, ops.conv2d_transpose_filter(wt), (n, h, w, c), stride=1, pad=pad))
+        return out
+
+    splits = [1] + ([2, 3] if ksteps >= 6 else [])
+    try:
+        _hip.check(lib.frcnn_conv2d_set_staging(0), "set_staging")
+        ref_outs = run_all(5, splits)                                     # register-staged 64x64
+        _hip.check(lib.frcnn_conv2d_set_staging(1), "set_staging")
+        got_outs = run_all(13, splits)                                    # persistent buffer-DMA kernel
+    finally:
+        _hip.check(lib.frcnn_conv2d_set_staging(1), "set_staging")
+        ops.set_conv_algo(0)
+        hip.frcnn_conv2d_clear_plans()
+    torch.cuda.synchronize()
+    assert len(ref_outs) == len(got_outs) >= 2
+    for i, (a, b) in enumerate(zip(ref_outs, got_outs)):
+        assert torch.equal(a, b), "output %d differs (max %.3e)" % (i, float((a - b).abs().max()))
+    ref = _conv_ref(x.cpu(), wt.cpu().permute(0, 3, 1, 2), sc.cpu(), sh.cpu(), res.cpu(), stride, pad, True)
+    _close_feat(got_outs[0].cpu().numpy(), ref.numpy(), "persistent kernel vs float64 reference", 1e-5)
+
+
+@pytest.mark.parametrize("case", [(1, 38, 63, 256, 1024, 1, 1, 0), (1, 38, 63, 1024, 256, 1, 1, 0), (1, 75, 125, 128, 128, 3, 1, 1),
                                   (2, 9, 11, 64, 2048, 1, 1, 0), (1, 19, 32, 512, 512, 3, 2, 1), (1, 13, 17, 32, 100, 3, 1, 1),
                                   (300, 7, 7, 512, 512, 1, 1, 0), (1, 38, 62, 256, 512, 1, 2, 0)])
 def test_conv2d_lds_transposed_epilogue_is_bit_identical(hip, case):
@@ -336,7 +403,7 @@ def test_conv2d_autotune_may_pick_winograd_and_plans_round_trip(hip):
         assert torch.equal(a, b)
         plans = ops.export_conv_plans()
         row = [r for r in plans if list(r[:10]) == [64, 7, 7, 256, 256, 3, 3, 1, 1, 1]]
-        assert len(row) == 1 and (row[0][10] >> 4) in (0, 1, 2) and (row[0][10] & 15) < 13      # 2 = Winograd with the fused input transform
+        assert len(row) == 1 and (row[0][10] >> 4) in (0, 1, 2) and (row[0][10] & 15) < 14      # 2 = Winograd with the fused input transform
         hip.frcnn_conv2d_clear_plans()
         ops.import_conv_plans(plans)
         c = ops.conv2d_nhwc(x, wt, stride=1, pad=1, relu=True)

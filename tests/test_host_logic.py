@@ -335,4 +335,4 @@ def test_committed_profiles_describe_the_committed_plan_table():
     assert other["roi_align_traffic_bytes_per_call"] == mine["roi_align_traffic_bytes_per_call"]   # not plan dependent
     # every plan of the table is one the library accepts: tile index < 13, algorithm code <= 2
     for r in rows:
-        assert len(r) == 13 and (r[10] & 15) < 13 and (r[10] >> 4) <= 2 and r[11] >= 1
+        assert len(r) == 13 and (r[10] & 15) < 14 and (r[10] >> 4) <= 2 and r[11] >= 1

@@ -24,7 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-TILES = ["256x128", "128x256", "128x128", "128x64", "64x128", "64x64", "128x128d2", "64x64buf", "128x64buf", "64x128buf", "128x128buf", "256x128buf", "128x256buf"]   # kTiles order (conv_igemm.hip)
+TILES = ["256x128", "128x256", "128x128", "128x64", "64x128", "64x64", "128x128d2", "64x64buf", "128x64buf", "64x128buf", "128x128buf", "256x128buf", "128x256buf", "64x64pers"]   # kTiles order (conv_igemm.hip)
 BK = 32
 
 
