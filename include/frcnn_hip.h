@@ -147,7 +147,7 @@ int frcnn_conv2d_clear_plans(void);
  * otherwise perturb the tuning; or shipped with a deployment: bench.py loads profiles/r05_plans.json).  Tile indices:
  * 0 256x128, 1 128x256 (8 waves, LDS-DMA three stages), 2 128x128, 3 128x64, 4 64x128, 5 64x64 (register-staged), 6 128x128
  * LDS-DMA two stages, 7 64x64, 8 128x64, 9 64x128, 10 128x128, 11 256x128, 12 128x256 (LDS-DMA through buffer loads, three
- * stages).  export returns the number of cached entries (fills at most capacity_entries); import validates and inserts. */
+ * stages), 13 64x64 with PERSISTENT workgroups (one K-step stream across a workgroup's tiles).  export returns the number of cached entries (fills at most capacity_entries); import validates and inserts. */
 int frcnn_conv2d_export_plans(int* out, int capacity_entries);
 int frcnn_conv2d_import_plans(const int* in, int entries);
 
