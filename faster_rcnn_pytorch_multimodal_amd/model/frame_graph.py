@@ -19,11 +19,35 @@ with the eager path bit for bit and with the CPU oracle.
 problem (shape, info, thresholds, cfg fingerprint); it captures on demand, keeps ``streams`` runners per problem (one per
 HIP stream), notices changed weights, and hands back None (-> the eager path) for shapes it has not decided to capture.
 """
+import contextlib
+import gc
+
 import numpy as np
 import torch
 
 from .config import cfg
 from .test import detect_frame_device
+
+
+@contextlib.contextmanager
+def capture(graph, **kwargs):
+    """``torch.cuda.graph(graph, **kwargs)`` with Python's cyclic collector held off until the capture has ended.
+
+    A capture runs in HIP's global capture mode: a call the runtime counts as unsafe (destroying another graph, releasing
+    its memory pool, ...) made from ANY thread while it lasts is an error, and the destructors such calls sit in treat
+    an error as fatal.  Reference cycles that hold a captured graph exist (a net and its cached TrainStepRunner point at
+    each other), and the collector may wake in any thread that allocates Python objects - e.g. autograd's backward thread
+    in the middle of a captured training step, which is where a round-5 GPU test run aborted.  So: collect first, keep
+    the collector off while capturing, and let whatever became garbage meanwhile be freed after the capture."""
+    was_enabled = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, **kwargs):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def _as_i32(seed):
@@ -85,7 +109,7 @@ class FrameRunner:
         torch.cuda.synchronize(dev)
         if use_graph:
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with capture(self.graph):
                 self.out = self._frame()
 
     def _frame(self):

@@ -27,6 +27,7 @@ from ..layer_utils.anchor_target_layer import _draw_seed
 from ..nets import autograd_ops
 from ..nets.hip_modules import refresh_derived_weights
 from .config import cfg
+from .frame_graph import capture
 
 
 GT_CAPACITY_MIN = 32      # rows of a captured step's gt buffer: max(32, next power of two of the frame's boxes)
@@ -221,7 +222,7 @@ class TrainStepRunner:
         self.inline = bool(inline)
         autograd_ops.BN_STAT_SINK = self.bn_private
         try:
-            with torch.cuda.graph(self.graph):
+            with capture(self.graph):
                 self.loss, self.counts = self._step()
         finally:
             autograd_ops.ASYNC_WGRAD, autograd_ops.WGRAD_ON_SIDE_STREAM, autograd_ops.GROUP_WGRAD = prev

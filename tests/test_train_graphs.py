@@ -303,6 +303,7 @@ def test_chain_with_torch_memcpy_nodes_replays_bit_identically_on_four_streams(h
     nodes only, torch's copies remain).  Four single-chain graphs - library convolutions with torch ``copy_`` nodes between
     them - replayed 8 rounds on four streams with fresh inputs each round, no host synchronisation inside a round: every
     output equals the eager evaluation bit for bit, and the node census is what the test means to exercise."""
+    from faster_rcnn_pytorch_multimodal_amd.model.frame_graph import capture
     from faster_rcnn_pytorch_multimodal_amd.model.train_graph import graph_node_kinds
     ops = T._ops()
     g = torch.Generator().manual_seed(12)
@@ -332,7 +333,7 @@ def test_chain_with_torch_memcpy_nodes_replays_bit_identically_on_four_streams(h
     for k, st in enumerate(streams):
         st.wait_stream(torch.cuda.current_stream())
         gr = torch.cuda.CUDAGraph(keep_graph=True)
-        with torch.cuda.graph(gr, stream=st):
+        with capture(gr, stream=st):
             chain(xs[k], mids[k], mid2s[k], outs[k])
         kinds, nodes, edges = graph_node_kinds(gr)
         assert kinds.get("memcpy", 0) >= 3 and kinds.get("memset", 0) == 0 and kinds.get("kernel", 0) >= 3, kinds
@@ -357,3 +358,53 @@ def test_chain_with_torch_memcpy_nodes_replays_bit_identically_on_four_streams(h
             torch.cuda.synchronize()
             assert torch.equal(got[r * n_streams + k], ref_out), (r, k)
     assert len({t.cpu().numpy().tobytes() for t in got}) == rounds * n_streams
+
+
+def test_capture_collects_dead_graphs_first_and_holds_the_collector_off(hip):
+    """model/frame_graph.capture: a dead reference cycle that owns a captured graph (what a dropped net and its cached
+    TrainStepRunner are) must not be collected DURING a later capture - ``~CUDAGraph`` inside a global-mode capture is
+    hipErrorStreamCaptureUnsupported and fatal, and torch >= 2.9 no longer collects before ``capture_begin``.  The helper
+    collects it before the capture starts, keeps the cyclic collector off while capturing (autograd's backward thread
+    allocates plenty of Python objects) and restores the collector's state afterwards, also when the body raises."""
+    import gc
+    import weakref
+    from faster_rcnn_pytorch_multimodal_amd.model.frame_graph import capture
+
+    class Holder:
+        pass
+
+    x = torch.ones(1024, device=DEV)
+    was = gc.isenabled()
+    gc.disable()                                                  # so that the cycle below is still uncollected at capture()
+    try:
+        a, b = Holder(), Holder()
+        a.other, b.other = b, a
+        a.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(a.graph):
+            a.y = x * 2
+        dead = weakref.ref(a)
+        del a, b
+        assert dead() is not None                                 # garbage, but only the cyclic collector can free it
+        gc.enable()
+        seen = {}
+        g2 = torch.cuda.CUDAGraph()
+        with capture(g2):
+            seen["alive"] = dead() is not None
+            seen["collector"] = gc.isenabled()
+            z = x + 1
+        assert seen == {"alive": False, "collector": False}
+        assert gc.isenabled()
+        g2.replay()
+        torch.cuda.synchronize()
+        assert float(z[0]) == 2.0
+        with pytest.raises(RuntimeError, match="stop"):
+            with capture(torch.cuda.CUDAGraph()):
+                _ = x + 2
+                raise RuntimeError("stop")
+        assert gc.isenabled()
+        gc.disable()
+        with capture(torch.cuda.CUDAGraph()):
+            _ = x + 3
+        assert not gc.isenabled()                                 # a caller that runs with the collector off stays that way
+    finally:
+        gc.enable() if was else gc.disable()

@@ -14,6 +14,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from faster_rcnn_pytorch_multimodal_amd.model.frame_graph import capture  # noqa: E402
 
 # (name, n, h, w, c, k, r, stride, pad, residual, calls per frame)
 SHAPES = [
@@ -135,7 +136,7 @@ def main():
             graphs = []
             for st, xi, yi, ri in zip(sts, xs, ys, rss):
                 gr = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gr, stream=st):
+                with capture(gr, stream=st):
                     for _ in range(args.reps):
                         ops.conv2d_nhwc(xi, wt, sc, sh, ri, stride=stride, pad=pad, relu=True, split_k=args.split, out=yi)
                 graphs.append(gr)

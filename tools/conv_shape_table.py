@@ -23,6 +23,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from faster_rcnn_pytorch_multimodal_amd.model.frame_graph import capture  # noqa: E402
 
 TILES = ["256x128", "128x256", "128x128", "128x64", "64x128", "64x64", "128x128d2", "64x64buf", "128x64buf", "64x128buf", "128x128buf", "256x128buf", "128x256buf", "64x64pers"]   # kTiles order (conv_igemm.hip)
 BK = 32
@@ -140,7 +141,7 @@ def main():
                         ops.conv2d_nhwc(xi, wt, sc, sh, ri, stride=stride, pad=pad, relu=relu, out=yi, w_winograd=u if code >= 16 else None)
                     torch.cuda.synchronize()
                     gr = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gr, stream=st):
+                    with capture(gr, stream=st):
                         for _ in range(args.reps):
                             ops.conv2d_nhwc(xi, wt, sc, sh, ri, stride=stride, pad=pad, relu=relu, out=yi,
                                             w_winograd=u if code >= 16 else None)
