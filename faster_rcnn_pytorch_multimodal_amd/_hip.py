@@ -39,8 +39,11 @@ PROTOTYPES = {
     "frcnn_conv2d_bwd_data_pre": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
     "frcnn_conv2d_bwd_data_act": (c_int, [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
     "frcnn_conv2d_bwd_weight_ws_bytes": (c_size_t, [c_int] * 9),
-    "frcnn_conv2d_bwd_weight": (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
-    "frcnn_conv2d_bwd_weight_acc": (c_int, [_P, _P, _P, c_int, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
+    "frcnn_conv2d_bwd_weight_counters": (c_int, [c_int] * 4),
+    "frcnn_conv2d_wgrad_set_variant": (c_int, [c_int]),
+    "frcnn_conv2d_wgrad_set_plan": (c_int, [c_int, c_int]),
+    "frcnn_conv2d_bwd_weight": (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P, _P]),
+    "frcnn_conv2d_bwd_weight_acc": (c_int, [_P, _P, _P, c_int, _P] + [c_int] * 9 + [_P, c_size_t, _P, _P]),
     "frcnn_conv2d_bwd_weight_acc_grouped_ws_bytes": (c_size_t, [c_int] * 5),
     "frcnn_conv2d_bwd_weight_acc_grouped": (c_int, [_P, _P, _P, c_int, c_int] + [c_int] * 9 + [_P, c_size_t, _P]),
     "frcnn_maxpool3x3s2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

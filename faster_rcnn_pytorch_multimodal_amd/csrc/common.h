@@ -30,11 +30,12 @@ hipError_t copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t stre
 
 // frcnn_settings_signature(): a hash of the CURRENT VALUES of every process-wide switch that changes which kernels an entry
 // point launches (frcnn_set_memops_mode, frcnn_conv2d_set_tile / _set_algo / _set_staging, frcnn_roi_align_set_variant,
-// frcnn_filter_set_variant, frcnn_nms_set_suppress_at_equal).  A holder of captured graphs keys its captures by it: switching a
+// frcnn_filter_set_variant, frcnn_nms_set_suppress_at_equal, frcnn_conv2d_wgrad_set_variant).  A holder of captured graphs keys its captures by it: switching a
 // setting away and back finds the old captures again.  Each translation unit reports its own switches.
 unsigned long long conv_settings_word();
 unsigned long long roi_settings_word();
 unsigned long long boxes_settings_word();
+unsigned long long wgrad_settings_word();
 
 // frcnn_conv2d_set_autotune state (conv_igemm.hip), shared with the filter-gradient kernel's own plan cache
 // (conv_wgrad.hip), which frcnn_conv2d_clear_plans empties as well.

@@ -69,8 +69,8 @@ hipError_t copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t stre
 }  // namespace frcnn
 
 extern "C" unsigned frcnn_settings_signature(void) {
-  unsigned long long words[4] = {(unsigned long long)frcnn::g_memops_mode.load(), frcnn::conv_settings_word(),
-                                 frcnn::roi_settings_word(), frcnn::boxes_settings_word()};
+  unsigned long long words[5] = {(unsigned long long)frcnn::g_memops_mode.load(), frcnn::conv_settings_word(),
+                                 frcnn::roi_settings_word(), frcnn::boxes_settings_word(), frcnn::wgrad_settings_word()};
   unsigned long long h = 1469598103934665603ull;                    // FNV-1a over the words' bytes
   for (unsigned long long w : words)
     for (int b = 0; b < 8; ++b) { h ^= (w >> (8 * b)) & 0xffu; h *= 1099511628211ull; }

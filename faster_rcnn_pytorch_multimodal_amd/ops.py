@@ -286,6 +286,77 @@ def conv2d_bwd_data(dy, w_t, x_shape, stride=1, pad=0, add=None, w_winograd=None
     return dx
 
 
+# Tile counters of the filter-gradient kernels (`counters` of frcnn_conv2d_bwd_weight[_acc]): device ints that are zero when a
+# launch starts and zero again when it ends; launches that may be in flight together must not share them.
+#   * eager launches take consecutive ranges of a per-device ring: a range comes round again only after WGRAD_COUNTER_RING
+#     ints of later launches - far more launches than can be in flight;
+#   * a holder of a captured graph installs its OWN arena for its warm-up and capture (``wgrad_counter_arena``; the ranges
+#     are baked into the graph, and no other graph or eager launch ever gets them) and rewinds it at the start of every
+#     pass over its launch sequence;
+#   * a capture WITHOUT an arena zero-fills fresh counters inside the capture (private to the graph, one fill kernel per call).
+WGRAD_COUNTER_RING = 1 << 20
+_COUNTER_RINGS = {}
+WGRAD_ARENA = None
+
+
+class CounterArena:
+    def __init__(self, device, count=1 << 19):
+        self.ints = torch.zeros(int(count), dtype=torch.int32, device=device)
+        self.cursor = 0
+
+    def rewind(self):
+        self.cursor = 0
+
+    def take(self, count):
+        if self.cursor + count > self.ints.numel():
+            raise _hip.HipError("filter-gradient counter arena exhausted (%d + %d > %d ints)" % (self.cursor, count, self.ints.numel()))
+        start = self.cursor
+        self.cursor += count
+        return self.ints[start:start + count]
+
+
+class wgrad_counter_arena:
+    """``with ops.wgrad_counter_arena(arena):`` - filter-gradient launches inside take their tile counters from ``arena``."""
+
+    def __init__(self, arena):
+        self.arena = arena
+
+    def __enter__(self):
+        global WGRAD_ARENA
+        self.prev, WGRAD_ARENA = WGRAD_ARENA, self.arena
+        return self.arena
+
+    def __exit__(self, *exc):
+        global WGRAD_ARENA
+        WGRAD_ARENA = self.prev
+        return False
+
+
+def _wgrad_counters(device, count):
+    if WGRAD_ARENA is not None:
+        if WGRAD_ARENA.ints.device != device:
+            raise _hip.HipError("filter-gradient counter arena is on %s, the launch on %s" % (WGRAD_ARENA.ints.device, device))
+        return WGRAD_ARENA.take(count)
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(count, dtype=torch.int32, device=device)
+    ring = _COUNTER_RINGS.get(str(device))
+    if ring is None:
+        ring = _COUNTER_RINGS[str(device)] = CounterArena(device, WGRAD_COUNTER_RING)
+    if ring.cursor + count > ring.ints.numel():
+        ring.rewind()
+    return ring.take(count)
+
+
+def set_wgrad_variant(variant):
+    """frcnn_conv2d_wgrad_set_variant: 0 every filter-gradient kernel, 1 register-staged only, 2 LDS-DMA wherever it applies."""
+    _hip.check(_hip.load().frcnn_conv2d_wgrad_set_variant(int(variant)), "frcnn_conv2d_wgrad_set_variant")
+
+
+def set_wgrad_plan(kernel, splits=1):
+    """frcnn_conv2d_wgrad_set_plan: force (kernel 1..4, pixel splits) for every following filter gradient; kernel 0 = off."""
+    _hip.check(_hip.load().frcnn_conv2d_wgrad_set_plan(int(kernel), int(splits)), "frcnn_conv2d_wgrad_set_plan")
+
+
 def conv2d_bwd_weight(x, dy, r, s, stride=1, pad=0, want_bias=False):
     """Returns (dw (K,R,S,C), db (K,) or None)."""
     lib = _hip.load()
@@ -299,8 +370,9 @@ def conv2d_bwd_weight(x, dy, r, s, stride=1, pad=0, want_bias=False):
     _log_flops('wgrad', 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * k * r * s * c)
     ws_bytes = lib.frcnn_conv2d_bwd_weight_ws_bytes(n, h, w, c, k, r, s, stride, pad)
     ws = _workspace(ws_bytes, x.device) if ws_bytes else None
+    counters = _wgrad_counters(x.device, lib.frcnn_conv2d_bwd_weight_counters(c, k, r, s))
     _hip.check(lib.frcnn_conv2d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), n, h, w, c, k, r, s, stride, pad,
-                                           _ptr(ws), ws_bytes, _stream()), "frcnn_conv2d_bwd_weight")
+                                           _ptr(ws), ws_bytes, counters.data_ptr(), _stream()), "frcnn_conv2d_bwd_weight")
     return dw, db
 
 
@@ -321,8 +393,10 @@ def conv2d_bwd_weight_acc(x, dy, r, s, grad_w, grad_b=None, stride=1, pad=0):
     _log_flops('wgrad', 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * k * r * s * c)
     ws_bytes = lib.frcnn_conv2d_bwd_weight_ws_bytes(n, h, w, c, k, r, s, stride, pad)
     ws = _workspace(ws_bytes, x.device)
+    counters = _wgrad_counters(x.device, lib.frcnn_conv2d_bwd_weight_counters(c, k, r, s))
     _hip.check(lib.frcnn_conv2d_bwd_weight_acc(_ptr(x), _ptr(dy), _ptr(grad_w), c_real, _ptr(grad_b), n, h, w, c, k, r, s,
-                                               stride, pad, _ptr(ws), ws_bytes, _stream()), "frcnn_conv2d_bwd_weight_acc")
+                                               stride, pad, _ptr(ws), ws_bytes, counters.data_ptr(), _stream()),
+               "frcnn_conv2d_bwd_weight_acc")
 
 
 WGRAD_MAX_GROUPS = 24

@@ -91,16 +91,33 @@ int frcnn_conv2d_bwd_data_act(const float* dy, const float* w_crsk_flipped, cons
                               const float* act_y, const float* act_scale, float* dx, int n, int h, int w, int c, int k, int r,
                               int s, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
 size_t frcnn_conv2d_bwd_weight_ws_bytes(int n, int h, int w, int c, int k, int r, int s, int stride, int pad);
+/* counters: frcnn_conv2d_bwd_weight_counters(c, k, r, s) ints of device memory that are ZERO on entry and are left zero - one
+ * per output tile: the workgroups that share a tile's pixel-split sums count themselves there and the last one adds the
+ * slabs (in split order: deterministic) and writes / accumulates the result, so no second kernel runs.  Two launches that may
+ * be in flight at the same time must not share counters (give each launch of a captured sequence its own range; launches that
+ * are ordered on one stream may reuse a range).  NULL: only plans that need no counters are used (the register-staged kernel
+ * with its reduction kernels, or an unsplit LDS-DMA launch). */
+int frcnn_conv2d_bwd_weight_counters(int c, int k, int r, int s);
 int frcnn_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, int n, int h, int w, int c, int k,
-                            int r, int s, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+                            int r, int s, int stride, int pad, void* ws, size_t ws_bytes, int* counters, void* stream);
+/* Which filter-gradient kernels may be planned: 0 = all (default), 1 = conv_wgrad_f32 (register-staged, separate reduction /
+ * accumulation kernels) only, 2 = conv_wgrad_dma_f32 (LDS-DMA ring, fused reduction + accumulation) wherever it applies
+ * (operands < 2 GB).  Forgets the tuned filter-gradient plans.  A/B switch for tests and benchmarks. */
+int frcnn_conv2d_wgrad_set_variant(int variant);
+/* Force the filter-gradient plan of every following call (tests): kernel 1 / 2 = conv_wgrad_f32 with the 64 / 128 tile,
+ * 3 / 4 = conv_wgrad_dma_f32 with the 64 / 128 tile; `splits` pixel ranges (clamped to the number of 32-pixel steps).
+ * kernel 0 returns to the tuned / modelled plans.  A call the forced kernel cannot serve fails with FRCNN_ERR_ARG. */
+int frcnn_conv2d_wgrad_set_plan(int kernel, int splits);
 
 /* The same filter gradient ACCUMULATED into a parameter's own gradient buffer: grad_w (K, c_real, R, S) += dw (the layout of
  * nn.Conv2d.weight; nn.Linear.weight with R = S = 1), c_real <= c real input channels (c is the padded count of x),
  * grad_b (K) += db (may be NULL).  One pass sums the pixel-split slabs, drops the channel padding, changes the layout and
- * adds - instead of a reduction launch, a permute copy and an add per parameter.  Uses the plan frcnn_conv2d_bwd_weight tuned
- * for the shape; workspace of frcnn_conv2d_bwd_weight_ws_bytes. */
+ * adds - instead of a reduction launch, a permute copy and an add per parameter; with `counters` (see frcnn_conv2d_bwd_weight)
+ * that pass is the epilogue of the filter-gradient kernel itself.  Uses the plan frcnn_conv2d_bwd_weight tuned for the shape;
+ * workspace of frcnn_conv2d_bwd_weight_ws_bytes. */
 int frcnn_conv2d_bwd_weight_acc(const float* x, const float* dy, float* grad_w, int c_real, float* grad_b, int n, int h, int w,
-                                int c, int k, int r, int s, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+                                int c, int k, int r, int s, int stride, int pad, void* ws, size_t ws_bytes, int* counters,
+                                void* stream);
 /* The same for `groups` (<= 24) convolutions of IDENTICAL shape in one launch pair: grad_w[g] += dW(x[g], dy[g]).  x, dy, grad_w
  * are HOST arrays of `groups` device pointers.  The repeated Bottlenecks of a ResNet stage (22 of the 23 blocks of layer3,
  * lib/nets/resnet.py:131-240) have identical filter-gradient problems whose outputs are too small to fill the chip one at a

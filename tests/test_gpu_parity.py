@@ -1445,6 +1445,117 @@ def test_conv2d_backward_matches_autograd(hip, case):
     assert torch.equal(dw, dw2)                                   # deterministic
 
 
+WGRAD_CASES = CONV_BWD_CASES + [
+    # n, h, w, c, k, r, stride, pad
+    (1, 61, 77, 4, 64, 7, 2, 3),        # the stem: 4 padded channels (3 real), 49 taps inside one 64-column tile
+    (1, 150, 97, 64, 64, 3, 1, 1),      # layer1 conv2: one 128-tile, long pixel reduction, row carries in (img, ho, wo)
+    (3, 5, 6, 64, 128, 3, 1, 1),        # images shorter than one 32-pixel step: two image carries per step
+    (2, 9, 11, 136, 72, 1, 1, 0),       # tails in k and q of both tile sizes
+    (1, 33, 47, 256, 256, 1, 1, 0),     # layer3-like 1x1
+]
+
+
+def _wgrad_reference(case, seed):
+    n, h, w, c, k, r, stride, pad = case
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, h, w, c, generator=g)
+    ho, wo = (h + 2 * pad - r) // stride + 1, (w + 2 * pad - r) // stride + 1
+    dy = torch.randn(n, ho, wo, k, generator=g)
+    wd = torch.zeros(k, c, r, r, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.permute(0, 3, 1, 2).double(), wd, None, stride=stride, padding=pad)
+    y.backward(dy.permute(0, 3, 1, 2).double())
+    return x, dy, wd.grad.float()                                   # (K, C, R, S)
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv2d_wgrad_every_kernel_and_split(hip, case):
+    """Filter gradient through every plan the library can choose - conv_wgrad_f32 (register-staged; separate reduction /
+    accumulation kernels) and conv_wgrad_dma_f32 (LDS-DMA ring, b64 fragments, last-arriver reduction + accumulation in the
+    epilogue), 64 and 128 tiles, 1 / 2 / 5 / 64 pixel splits - in both forms: dw (K,R,S,C) overwritten, and accumulated into a
+    parameter-layout gradient (K, c_real, R, S) that already holds values (c_real < c for the padded stem).  Against float64
+    autograd (lib/model/train_val.py:458 -> loss.backward()).  The 128-tile DMA kernel keeps conv_wgrad_f32<2>'s summation
+    order: bit-identical to it at equal splits.  Every plan is deterministic, and the tile counters are zero again afterwards."""
+    ops = _ops()
+    n, h, w, c, k, r, stride, pad = case
+    x, dy, ref = _wgrad_reference(case, 100 + sum(case))
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    c_real = 3 if c == 4 else c
+    g = torch.Generator().manual_seed(5)
+    base = torch.randn(k, c_real, r, r, generator=g)
+    base_b = torch.randn(k, generator=g)
+    ref_krsc = ref.permute(0, 2, 3, 1).contiguous().numpy()
+    ref_acc = (base.double() + ref[:, :c_real].double()).float().numpy()
+    ref_b = (base_b.double() + dy.double().sum((0, 1, 2))).float().numpy()
+    seen = {}
+    try:
+        for kernel in (1, 2, 3, 4):
+            for splits in (1, 2, 5, 64):
+                ops.set_wgrad_plan(kernel, splits)
+                dw, db = ops.conv2d_bwd_weight(xd, dyd, r, r, stride=stride, pad=pad, want_bias=True)
+                what = "wgrad %s kernel %d splits %d" % (case, kernel, splits)
+                _close_feat(dw.cpu().numpy(), ref_krsc, what, frac=2e-5)
+                dw2, _ = ops.conv2d_bwd_weight(xd, dyd, r, r, stride=stride, pad=pad)
+                assert torch.equal(dw, dw2), what
+                seen[(kernel, splits)] = dw
+                gw, gb = base.to(DEV).clone(), base_b.to(DEV).clone()
+                ops.conv2d_bwd_weight_acc(xd, dyd, r, r, gw, gb, stride=stride, pad=pad)
+                _close_feat(gw.cpu().numpy(), ref_acc, what + " accumulated", frac=2e-5)
+                _close_feat(gb.cpu().numpy(), ref_b, what + " bias accumulated", frac=2e-5)
+                gw2 = base.to(DEV).clone()
+                ops.conv2d_bwd_weight_acc(xd, dyd, r, r, gw2, None, stride=stride, pad=pad)
+                assert torch.equal(gw, gw2), what
+        for splits in (1, 2, 5, 64):
+            assert torch.equal(seen[(2, splits)], seen[(4, splits)]), (case, splits)
+    finally:
+        ops.set_wgrad_plan(0)
+    torch.cuda.synchronize()
+    for ring in ops._COUNTER_RINGS.values():
+        assert int(ring.ints.abs().max()) == 0
+
+
+def test_conv2d_wgrad_variants_tuned_and_without_counters(hip):
+    """frcnn_conv2d_wgrad_set_variant + the tuner: with autotuning on, each variant (every kernel / register-staged only / DMA
+    wherever it applies) tunes its own candidates and stays within tolerance; a call WITHOUT tile counters (counters = NULL
+    through the C ABI) still works - it is planned without a split DMA launch."""
+    import ctypes
+    from faster_rcnn_pytorch_multimodal_amd import _hip
+    ops = _ops()
+    lib = _hip.load()
+    case = (1, 40, 60, 256, 256, 3, 1, 1)
+    n, h, w, c, k, r, stride, pad = case
+    x, dy, ref = _wgrad_reference(case, 77)
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    ref_krsc = ref.permute(0, 2, 3, 1).contiguous().numpy()
+    try:
+        for variant in (0, 1, 2):
+            ops.set_wgrad_variant(variant)
+            ops.set_conv_autotune(True)
+            try:
+                dw, _ = ops.conv2d_bwd_weight(xd, dyd, r, r, stride=stride, pad=pad)
+            finally:
+                torch.cuda.synchronize()
+                ops.set_conv_autotune(False)
+            _close_feat(dw.cpu().numpy(), ref_krsc, "tuned wgrad, variant %d" % variant, frac=2e-5)
+            dw2, _ = ops.conv2d_bwd_weight(xd, dyd, r, r, stride=stride, pad=pad)     # the cached plan
+            assert torch.equal(dw, dw2)
+            # no counters: C ABI directly
+            ws_bytes = lib.frcnn_conv2d_bwd_weight_ws_bytes(n, h, w, c, k, r, r, stride, pad)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+            out = torch.empty(k, r, r, c, device=DEV)
+            rc = lib.frcnn_conv2d_bwd_weight(xd.data_ptr(), dyd.data_ptr(), out.data_ptr(), None, n, h, w, c, k, r, r, stride, pad,
+                                             ws.data_ptr(), ws_bytes, None, torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, lib.frcnn_last_error()
+            _close_feat(out.cpu().numpy(), ref_krsc, "wgrad without counters, variant %d" % variant, frac=2e-5)
+        ops.set_wgrad_variant(0)
+        ops.set_wgrad_plan(3, 4)
+        rc = lib.frcnn_conv2d_bwd_weight(xd.data_ptr(), dyd.data_ptr(), out.data_ptr(), None, n, h, w, c, k, r, r, stride, pad,
+                                         ws.data_ptr(), ws_bytes, None, torch.cuda.current_stream().cuda_stream)
+        assert rc != 0 and b"does not apply" in lib.frcnn_last_error()
+    finally:
+        ops.set_wgrad_plan(0)
+        ops.set_wgrad_variant(0)
+
+
 # ------------------------------------------------------------------------------------------------
 # other training-path kernels
 # ------------------------------------------------------------------------------------------------
