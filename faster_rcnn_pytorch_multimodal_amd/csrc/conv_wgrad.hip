@@ -351,7 +351,13 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const WgradParams& p, const 
         if (c + e < p.c_real) ptarget[(((size_t)k * p.c_real + c + e) * p.R + r) * p.S + s2] += v[e];
     }
   };
-  float* slab = p.out + (size_t)blockIdx.z * KQ;
+  // Slabs travel between workgroups on different XCDs (one L2 each): they are stored and loaded at AGENT scope (sc1: written
+  // through / read past the XCD's L2) instead of bracketing plain accesses with device-scope fences - a release fence writes
+  // back and an acquire fence invalidates the WHOLE L2 of the XCD, once per workgroup (measured: 24 splits of layer3's
+  // 1x1 took 202 us with the fences, the unsplit launch 52 us).
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((size_t)p.splits * KQ * 4), 0x00020000);
+  const unsigned zoff = (unsigned)((size_t)blockIdx.z * KQ * 4);
 #pragma unroll
   for (int u = 0; u < NCH; ++u) {
     const int c = t + 256 * u;
@@ -371,37 +377,37 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const WgradParams& p, const 
     const int k = k0 + kl, q = q0 + qc * 4;
     if (k < p.K && q < p.Q) {
       if (p.splits == 1) emit(k, q, v);
-      else *reinterpret_cast<f32x4*>(slab + (size_t)k * p.Q + q) = v;
+      else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rS, zoff + (unsigned)((k * p.Q + q) * 4), 0, 16);
     }
   }
   if (p.splits == 1) return;
   // ---- last arriver of this tile adds the slabs in z order --------------------------------------------------------------------
   __shared__ int s_last;
-  __threadfence();                       // release this workgroup's slab stores at device scope
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's slab stores have reached the coherence point
   __syncthreads();
   if (t == 0) {
     int* ctr = p.counters + blockIdx.x;
-    const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = old == p.splits - 1;
     if (s_last) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
   }
   __syncthreads();
   if (!s_last) return;
-  __threadfence();                       // acquire the other workgroups' slabs
 #pragma unroll 1
   for (int u = 0; u < NCH; ++u) {
     const int c = t + 256 * u;
     const int kl = c / CH, qc = c - kl * CH;
     const int k = k0 + kl, q = q0 + qc * 4;
     if (k >= p.K || q >= p.Q) continue;
-    const float* src = p.out + (size_t)k * p.Q + q;
+    const unsigned off = (unsigned)((k * p.Q + q) * 4);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     // eight slab loads in flight at a time; added in z order
     for (int z0 = 0; z0 < p.splits; z0 += 8) {
       f32x4 o[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        if (z0 + i < p.splits) o[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)(z0 + i) * KQ));
+        if (z0 + i < p.splits)
+          o[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rS, off + (unsigned)((size_t)(z0 + i) * KQ * 4), 0, 16));
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         if (z0 + i < p.splits) {
@@ -687,6 +693,8 @@ int run_wgrad(WgradParams p, const WgradPlan& pl, int mode, float* target, int c
   const dim3 grid(p.tiles_k * p.tiles_q, 1, pl.splits);
   if (pl.ti >= 3) {
     if (pl.splits > 1 && !counters) return frcnn::fail(FRCNN_ERR_ARG, "conv_wgrad_dma_f32: split plan without tile counters");
+    if ((size_t)pl.splits * p.K * p.Q * sizeof(float) >= ((size_t)1 << 31))
+      return frcnn::fail(FRCNN_ERR_ARG, "conv_wgrad_dma_f32: %d slabs of %d x %d floats exceed a 2 GB buffer", pl.splits, p.K, p.Q);
     p.out = static_cast<float*>(ws);
     p.target = target;
     p.counters = counters;

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256) void atl_label_kernel(const float* __restrict_
   if (seed_dev) seed += *seed_dev;      // per-step seed from device memory (a replayed hipGraph keeps `seed` itself)
   if (g_dev) g = max(1, min(g, *g_dev));
   const float eps = 1.1920929e-07f;  // torch.finfo(float32).eps (:62)
+  int n_fg = 0, n_bg = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float mo = max_ov[i];
     float lab = -1.f;
@@ -136,8 +137,18 @@ __global__ __launch_bounds__(256) void atl_label_kernel(const float* __restrict_
     // selection keys: candidates get a uniform key in (0,1], everything else -1 so it sorts last
     key_fg[i] = lab == 1.f ? (float)((rand_key(seed, 1, i) >> 8) + 1) * (1.0f / 16777216.0f) : -1.f;
     key_bg[i] = lab == 0.f ? (float)((rand_key(seed, 2, i) >> 8) + 1) * (1.0f / 16777216.0f) : -1.f;
-    if (lab == 1.f) atomicAdd(counters + 0, 1);
-    if (lab == 0.f) atomicAdd(counters + 1, 1);
+    n_fg += lab == 1.f;
+    n_bg += lab == 0.f;
+  }
+  // candidate counts: one global atomic per wave and label (an atomic per candidate was ~250 K same-address atomics for the
+  // background anchors of a 1000x600 FPN frame: 167 us; integer sums, any order)
+  for (int off = 32; off > 0; off >>= 1) {
+    n_fg += __shfl_xor(n_fg, off);
+    n_bg += __shfl_xor(n_bg, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (n_fg) atomicAdd(counters + 0, n_fg);
+    if (n_bg) atomicAdd(counters + 1, n_bg);
   }
 }
 

@@ -167,6 +167,8 @@ class TrainStepRunner:
         self.dc_far = torch.tensor([DC_FAR], dtype=torch.float32, device=dev).repeat(DC_CAPACITY, 1) if cfg.TRAIN.IGNORE_DC else None
         self.static_dc = self.dc_far.clone() if self.dc_far is not None else None
         self.seed_dev = torch.zeros((2,), dtype=torch.int32, device=dev)
+        from .. import ops as _ops
+        self.wgrad_counters = _ops.CounterArena(dev)      # tile counters of this runner's filter-gradient launches (_step)
         from ..nets import uncertainty
         self.uc_seed_dev = torch.zeros((1,), dtype=torch.int32, device=dev) if uncertainty.enabled() else None
         self.key = (height, width, channels, self.gt_cap, tuple(float(v) for v in self.info))
@@ -257,16 +259,22 @@ class TrainStepRunner:
         self.gt_count.fill_(1)
 
     def _step(self):
+        from .. import ops
         net = self.net
         net._seed_dev, net._gt_count_dev, net._uc_seed_dev = self.seed_dev, self.gt_count, self.uc_seed_dev
-        try:
-            gt = (self.static_gt, self.static_true_gt) if self.lidar else self.static_gt
-            net.forward(self.static_in, self.info, gt, self.static_dc, mode='TRAIN')
-        finally:
-            net._seed_dev = net._gt_count_dev = net._uc_seed_dev = None
-        loss = net._losses['total_loss']
-        counts = net._proposal_targets.get('counts')
-        net.backward(loss)
+        # the filter-gradient launches of this runner count their pixel-split workgroups in tile counters of the runner's
+        # own (ops.wgrad_counter_arena): the same range for the same launch in every pass, baked into the graph, shared
+        # with no other graph or eager launch
+        self.wgrad_counters.rewind()
+        with ops.wgrad_counter_arena(self.wgrad_counters):
+            try:
+                gt = (self.static_gt, self.static_true_gt) if self.lidar else self.static_gt
+                net.forward(self.static_in, self.info, gt, self.static_dc, mode='TRAIN')
+            finally:
+                net._seed_dev = net._gt_count_dev = net._uc_seed_dev = None
+            loss = net._losses['total_loss']
+            counts = net._proposal_targets.get('counts')
+            net.backward(loss)
         self.losses = dict(net._losses)
         return loss, counts
 

@@ -62,6 +62,12 @@ def test_one_captured_step_serves_every_gt_count(hip):
         assert worst <= 1e-4, (it, len(gt), name, worst)
     keys = sorted(k[3] for k in net_g._train_graphs)
     assert keys == [32, 64], keys
+    # every runner counted its filter-gradient tiles in counters of its own, and every launch left them zero again
+    torch.cuda.synchronize()
+    arenas = [r.wgrad_counters for r in net_g._train_graphs.values()]
+    assert len({a.ints.data_ptr() for a in arenas}) == 2
+    for a in arenas:
+        assert a.cursor > 0 and int(a.ints.abs().max()) == 0
     C.reset_cfg()
 
 

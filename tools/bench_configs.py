@@ -309,7 +309,11 @@ def main():
     ap.add_argument("--no-fuse-act-bwd", action="store_true", help="A/B: separate frcnn_act_bwd passes inside the Bottleneck backward")
     ap.add_argument("--group-wgrad", action="store_true", help="A/B: grouped filter-gradient launches per ResNet stage (autograd_ops.GROUP_WGRAD)")
     ap.add_argument("--group-wgrad-size", type=int, default=0, help="A/B: layers per grouped filter-gradient launch")
+    ap.add_argument("--wgrad-variant", type=int, default=0, help="A/B: frcnn_conv2d_wgrad_set_variant (1 register-staged kernels, 2 LDS-DMA)")
     args = ap.parse_args()
+    if args.wgrad_variant:
+        from faster_rcnn_pytorch_multimodal_amd import ops as _o2
+        _o2.set_wgrad_variant(args.wgrad_variant)
     if args.roi_bwd_per_sample:
         from faster_rcnn_pytorch_multimodal_amd import ops as _o
         _o.ROI_ALIGN_BWD_PLANNED = False
