@@ -242,3 +242,44 @@ def test_fuzz_filter_per_class(hip, seed, r, thresh, max_dets, score_kind, mix):
         finally:
             ops.set_nms_suppress_at_equal(old_dev)
             O.NMS_SUPPRESS_AT_EQUAL = old_cpu
+
+
+# ------------------------------------------------------------------------------------------------
+# filter gradient: the addressing of the LDS-DMA kernel (range-checked buffer loads, incremental (img, ho, wo), tile tails)
+# ------------------------------------------------------------------------------------------------
+WGRAD_SHAPE = st.tuples(st.integers(1, 3), st.integers(1, 41), st.integers(1, 41), st.sampled_from([4, 8, 36, 64, 68, 132]),
+                        st.sampled_from([4, 12, 64, 72, 136]), st.sampled_from([1, 3, 5, 7]), st.integers(1, 3),
+                        st.integers(0, 3), st.sampled_from([1, 2, 7]))
+
+
+@settings(max_examples=40, **SETTINGS)
+@given(shape=WGRAD_SHAPE, seed=st.integers(0, 2 ** 16))
+def test_fuzz_wgrad_dma_addressing_against_register_staged_kernel(shape, seed):
+    """conv_wgrad_dma_f32 against conv_wgrad_f32 on random shapes (images smaller than a 32-pixel step, strides 1..3, every
+    padding, channel / filter counts off the tile sizes): the 128-tile DMA kernel keeps the register-staged kernel's summation
+    order, so ANY addressing slip - a wrong carry in (img, ho, wo), a row past M that is not zero, a tail chunk - shows as a
+    bit difference; the 64-tile kernel (other order) is held to 2e-5 of the result's scale, and both to float64 autograd."""
+    ops = _ops()
+    n, h, w, c, k, r, stride, pad, splits = shape
+    pad = min(pad, r - 1)
+    if h + 2 * pad < r or w + 2 * pad < r:
+        return
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, h, w, c, generator=g)
+    ho, wo = (h + 2 * pad - r) // stride + 1, (w + 2 * pad - r) // stride + 1
+    dy = torch.randn(n, ho, wo, k, generator=g)
+    wd = torch.zeros(k, c, r, r, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.permute(0, 3, 1, 2).double(), wd, None, stride=stride, padding=pad).backward(dy.permute(0, 3, 1, 2).double())
+    ref = wd.grad.permute(0, 2, 3, 1).float()
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    got = {}
+    try:
+        for kernel in (1, 2, 3, 4):
+            ops.set_wgrad_plan(kernel, splits)
+            got[kernel] = ops.conv2d_bwd_weight(xd, dyd, r, r, stride=stride, pad=pad)[0].cpu()
+    finally:
+        ops.set_wgrad_plan(0)
+    assert torch.equal(got[2], got[4]), shape
+    scale = max(float(ref.abs().max()), 1e-6)
+    for kernel in (1, 3, 4):
+        assert float((got[kernel] - ref).abs().max()) <= 2e-5 * scale + 1e-6, (shape, kernel)
