@@ -642,6 +642,7 @@ def main(argv=None):
         n_resident += 1
     gather_every = max(1, args.gather_every)
     net = sd = None
+    distinct_queues = None
     if not rehearsal:
         from faster_rcnn_pytorch_multimodal_amd.model.frame_graph import FrameRunner
         from faster_rcnn_pytorch_multimodal_amd import ops as _ops
@@ -662,7 +663,13 @@ def main(argv=None):
                 _ops.import_conv_plans(json.load(f))
             plans_loaded = True
         runners = [FrameRunner(net, H, W, C, info, THRESH, MAX_DETS, use_graph=not args.no_graph) for _ in range(n_streams)]
-        streams = [masked_stream(device, k, n_streams, args.cu_mask) for k in range(n_streams)]
+        if args.cu_mask != "none" or os.environ.get("FRCNN_STREAM_POLICY", "measured") == "pool":
+            streams = [masked_stream(device, k, n_streams, args.cu_mask) for k in range(n_streams)]
+            distinct_queues = None
+        else:
+            # streams chosen by measurement: a HIP stream is not a hardware queue (model/streams.py)
+            from faster_rcnn_pytorch_multimodal_amd.model.streams import concurrent_streams
+            streams, distinct_queues = concurrent_streams(n_streams, device)
         for st in streams:
             st.wait_stream(torch.cuda.current_stream())
 
@@ -839,6 +846,7 @@ def main(argv=None):
                                    "thresh %.1f max_dets %d; weights seeded random init (BN tame)" % (THRESH, MAX_DETS),
                        "frames_per_step": world, "parallelism": "frame-sharded x%d, all-gather of detections" % world,
                        "launch": "eager" if args.no_graph else "hipGraph replay", "frames_in_flight": n_streams,
+                       "streams_on_distinct_hardware_queues": distinct_queues,
                        "input": "frames resident in HBM before the timed region (with_host_upload: the same steps with every "
                                 "frame uploaded from pinned host memory inside the step)"},
             "timed_regions": {"count": n_regions, "reported": "median", "steps_each": args.steps,

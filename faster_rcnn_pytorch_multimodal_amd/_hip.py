@@ -87,9 +87,11 @@ PROTOTYPES = {
     "frcnn_bev_voxelize": (c_int, [_P, c_int, c_int, POINTER(c_float), POINTER(c_float), c_float, c_int, c_int, c_int,
                                    c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "frcnn_bn_train_ws_bytes": (c_size_t, [c_int]),
+    "frcnn_bn_train_counters": (c_int, [c_int]),
     "frcnn_bn_train_fwd": (c_int, [_P, c_int64, c_int, _P, _P, c_float, c_float, _P, _P, _P, c_int, _P, _P, _P, _P,
-                                   c_size_t, _P]),
-    "frcnn_bn_train_bwd": (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
+                                   c_size_t, _P, _P]),
+    "frcnn_bn_train_bwd": (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, _P, c_size_t, _P,
+                                   _P]),
     "frcnn_spatial_mean_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "frcnn_spatial_mean_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "frcnn_upsample_bilinear_add_fwd": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P]),

@@ -20,6 +20,53 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BN_GROUPS = 64;
 
+// What the pass behind the column sums needs (bn_fwd_final_kernel / bn_bwd_final_kernel).  With `counters` (one int per
+// 64-channel column block, zero on entry and on exit) the LAST of a column block's BN_GROUPS workgroups runs that pass itself
+// at the end of bn_partial_kernel: one launch fewer per BatchNorm and direction (168 of the LiDAR step's 1290 launches).  The
+// partial sums then travel at agent scope (sc1: the workgroups of a column sit on different XCDs, one L2 each).
+struct BnFinal {
+  int* counters;
+  long M;
+  const float* gamma;
+  const float* beta;
+  float eps, momentum;
+  float* running_mean;
+  float* running_var;
+  float* save_mean;
+  float* save_invstd;   // bwd: input
+  float* alpha;         // fwd: alpha / shift; bwd: coef (3 C floats)
+  float* shift;
+  float* dgamma;
+  float* dbeta;
+  int accumulate;       // bwd: dgamma / dbeta += instead of =
+};
+
+__device__ __forceinline__ void bn_fwd_final(double s, double q, int c, const BnFinal& f) {
+  const double mean = s / (double)f.M;
+  double var = q / (double)f.M - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float mean_f = (float)mean, var_f = (float)var;
+  const float invstd = 1.0f / sqrtf(var_f + f.eps);
+  f.save_mean[c] = mean_f;
+  f.save_invstd[c] = invstd;
+  f.alpha[c] = invstd * (f.gamma ? f.gamma[c] : 1.f);
+  f.shift[c] = f.beta ? f.beta[c] : 0.f;
+  if (f.running_mean) f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * mean_f;
+  if (f.running_var) {
+    const float unbiased = f.M > 1 ? (float)(var * (double)f.M / (double)(f.M - 1)) : var_f;
+    f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * unbiased;
+  }
+}
+
+__device__ __forceinline__ void bn_bwd_final(double s, double q, int c, int C, const BnFinal& f) {
+  if (f.dbeta) f.dbeta[c] = f.accumulate ? f.dbeta[c] + (float)s : (float)s;
+  if (f.dgamma) f.dgamma[c] = f.accumulate ? f.dgamma[c] + (float)q : (float)q;
+  float* coef = f.alpha;
+  coef[c] = (f.gamma ? f.gamma[c] : 1.f) * f.save_invstd[c];
+  coef[C + c] = (float)(s / (double)f.M);
+  coef[2 * C + c] = (float)(q / (double)f.M);
+}
+
 // part[g][c] = (sum_m a[m][c], sum_m b[m][c]) over the rows of group g, where
 //   forward : a = y,  b = y*y
 //   backward: a = g,  b = g * xhat     with g = relu ? (out > 0 ? dout : 0) : dout,  xhat = (y - mean) * invstd
@@ -27,8 +74,9 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ y, const float* __restrict__ dout,
                                                         const float* __restrict__ out, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, int relu, long M, int C,
-                                                        double* __restrict__ part) {
+                                                        double* __restrict__ part, const BnFinal fin) {
   __shared__ double sa[4][64], sb[4][64];
+  __shared__ int s_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   double a = 0.0, b = 0.0;
@@ -53,20 +101,43 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   sb[wave][lane] = b;
   __syncthreads();
   if (wave == 0 && c < C) {
-    part[((size_t)blockIdx.y * C + c) * 2 + 0] = ((sa[0][lane] + sa[1][lane]) + sa[2][lane]) + sa[3][lane];
-    part[((size_t)blockIdx.y * C + c) * 2 + 1] = ((sb[0][lane] + sb[1][lane]) + sb[2][lane]) + sb[3][lane];
+    const double ta = ((sa[0][lane] + sa[1][lane]) + sa[2][lane]) + sa[3][lane];
+    const double tb = ((sb[0][lane] + sb[1][lane]) + sb[2][lane]) + sb[3][lane];
+    double* dst = part + ((size_t)blockIdx.y * C + c) * 2;
+    if (fin.counters) {
+      __hip_atomic_store(dst, ta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + 1, tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      dst[0] = ta;
+      dst[1] = tb;
+    }
   }
+  if (!fin.counters) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the partial sums have reached the coherence point
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int* ctr = fin.counters + blockIdx.x;
+    const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = old == BN_GROUPS - 1;
+    if (s_last) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last || wave != 0 || c >= C) return;
+  // the last workgroup of this column block: group order, like the stand-alone pass
+  double s = 0.0, q = 0.0;
+#pragma unroll 8
+  for (int g = 0; g < BN_GROUPS; ++g) {
+    const double* src = part + ((size_t)g * C + c) * 2;
+    s += __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    q += __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (BWD) bn_bwd_final(s, q, c, C, fin);
+  else bn_fwd_final(s, q, c, fin);
 }
 
 // mean / biased variance -> saved statistics, the affine coefficients of the apply pass, running statistics
 // (torch.nn.functional.batch_norm(training=True): running_var takes the UNBIASED variance).
-__global__ __launch_bounds__(256) void bn_fwd_final_kernel(const double* __restrict__ part, long M, int C,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float eps, float momentum,
-                                                          float* __restrict__ running_mean,
-                                                          float* __restrict__ running_var, float* __restrict__ save_mean,
-                                                          float* __restrict__ save_invstd, float* __restrict__ alpha,
-                                                          float* __restrict__ shift) {
+__global__ __launch_bounds__(256) void bn_fwd_final_kernel(const double* __restrict__ part, int C, const BnFinal fin) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s = 0.0, q = 0.0;
@@ -74,21 +145,7 @@ __global__ __launch_bounds__(256) void bn_fwd_final_kernel(const double* __restr
     s += part[((size_t)g * C + c) * 2 + 0];
     q += part[((size_t)g * C + c) * 2 + 1];
   }
-  const double mean = s / (double)M;
-  double var = q / (double)M - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const float mean_f = (float)mean, var_f = (float)var;
-  const float invstd = 1.0f / sqrtf(var_f + eps);
-  save_mean[c] = mean_f;
-  save_invstd[c] = invstd;
-  const float a = invstd * (gamma ? gamma[c] : 1.f);
-  alpha[c] = a;
-  shift[c] = beta ? beta[c] : 0.f;
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean_f;
-  if (running_var) {
-    const float unbiased = M > 1 ? (float)(var * (double)M / (double)(M - 1)) : var_f;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-  }
+  bn_fwd_final(s, q, c, fin);
 }
 
 // out = act((y - mean[c]) * alpha[c] + beta[c] (+ residual)); centred first, so a degenerate channel (variance << mean^2)
@@ -116,10 +173,7 @@ __global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const float* __restri
 }
 
 // d_beta = sum g, d_gamma = sum g*xhat; coefficients of  dy = a * (g - b - xhat * k)
-__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restrict__ part, long M, int C,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta, float* __restrict__ coef) {
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restrict__ part, int C, const BnFinal fin) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s = 0.0, q = 0.0;
@@ -127,11 +181,7 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restr
     s += part[((size_t)g * C + c) * 2 + 0];
     q += part[((size_t)g * C + c) * 2 + 1];
   }
-  if (dbeta) dbeta[c] = (float)s;
-  if (dgamma) dgamma[c] = (float)q;
-  coef[c] = (gamma ? gamma[c] : 1.f) * invstd[c];
-  coef[C + c] = (float)(s / (double)M);
-  coef[2 * C + c] = (float)(q / (double)M);
+  bn_bwd_final(s, q, c, C, fin);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ out,
@@ -171,10 +221,12 @@ size_t ws_need(int c) { return (size_t)BN_GROUPS * c * 2 * sizeof(double) + (siz
 
 extern "C" size_t frcnn_bn_train_ws_bytes(int c) { return c > 0 ? ws_need(c) : 0; }
 
+extern "C" int frcnn_bn_train_counters(int c) { return c > 0 ? (c + 63) / 64 : 0; }
+
 extern "C" int frcnn_bn_train_fwd(const float* y, int64_t rows, int c, const float* gamma, const float* beta, float eps,
                                   float momentum, float* running_mean, float* running_var, const float* residual,
                                   int relu, float* out, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
-                                  void* stream_) {
+                                  int* counters, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   FRCNN_REQUIRE(y && out && save_mean && save_invstd && rows > 0 && c > 0 && c % 4 == 0,
                 "bn_train_fwd: bad arguments (c%%4==0)");
@@ -182,14 +234,19 @@ extern "C" int frcnn_bn_train_fwd(const float* y, int64_t rows, int c, const flo
   double* part = static_cast<double*>(ws);
   float* alpha = reinterpret_cast<float*>(part + (size_t)BN_GROUPS * c * 2);
   float* shift = alpha + c;
+  BnFinal fin;
+  fin.counters = counters; fin.M = (long)rows; fin.gamma = gamma; fin.beta = beta; fin.eps = eps; fin.momentum = momentum;
+  fin.running_mean = running_mean; fin.running_var = running_var; fin.save_mean = save_mean; fin.save_invstd = save_invstd;
+  fin.alpha = alpha; fin.shift = shift; fin.dgamma = nullptr; fin.dbeta = nullptr; fin.accumulate = 0;
   hipLaunchKernelGGL(bn_partial_kernel<false>, dim3((c + 63) / 64, BN_GROUPS), dim3(256), 0, stream, y, nullptr, nullptr,
-                     nullptr, nullptr, 0, (long)rows, c, part);
+                     nullptr, nullptr, 0, (long)rows, c, part, fin);
   int rc = check_launch("bn_partial_kernel<fwd>");
   if (rc != FRCNN_OK) return rc;
-  hipLaunchKernelGGL(bn_fwd_final_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, part, (long)rows, c, gamma, beta,
-                     eps, momentum, running_mean, running_var, save_mean, save_invstd, alpha, shift);
-  rc = check_launch("bn_fwd_final_kernel");
-  if (rc != FRCNN_OK) return rc;
+  if (!counters) {
+    hipLaunchKernelGGL(bn_fwd_final_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, part, c, fin);
+    rc = check_launch("bn_fwd_final_kernel");
+    if (rc != FRCNN_OK) return rc;
+  }
   const size_t n4 = (size_t)rows * (c / 4);
   hipLaunchKernelGGL(bn_fwd_apply_kernel, dim3(grid_for(n4)), dim3(256), 0, stream, y, save_mean, alpha, shift, residual,
                      relu, n4, c / 4, out);
@@ -198,22 +255,28 @@ extern "C" int frcnn_bn_train_fwd(const float* y, int64_t rows, int c, const flo
 
 extern "C" int frcnn_bn_train_bwd(const float* dout, const float* out, const float* y, int64_t rows, int c,
                                   const float* gamma, const float* save_mean, const float* save_invstd, int relu,
-                                  float* dy, float* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                                  void* stream_) {
+                                  float* dy, float* dres, float* dgamma, float* dbeta, int accumulate, void* ws,
+                                  size_t ws_bytes, int* counters, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   FRCNN_REQUIRE(dout && y && save_mean && save_invstd && dy && rows > 0 && c > 0 && c % 4 == 0 && (!relu || out),
                 "bn_train_bwd: bad arguments (c%%4==0, out needed for the ReLU mask)");
   if (!ws || ws_bytes < ws_need(c)) return fail(FRCNN_ERR_WS, "bn_train_bwd: workspace %zu < %zu bytes", ws_bytes, ws_need(c));
   double* part = static_cast<double*>(ws);
   float* coef = reinterpret_cast<float*>(part + (size_t)BN_GROUPS * c * 2);
+  BnFinal fin;
+  fin.counters = counters; fin.M = (long)rows; fin.gamma = gamma; fin.beta = nullptr; fin.eps = 0.f; fin.momentum = 0.f;
+  fin.running_mean = nullptr; fin.running_var = nullptr; fin.save_mean = nullptr;
+  fin.save_invstd = const_cast<float*>(save_invstd); fin.alpha = coef; fin.shift = nullptr; fin.dgamma = dgamma;
+  fin.dbeta = dbeta; fin.accumulate = accumulate ? 1 : 0;
   hipLaunchKernelGGL(bn_partial_kernel<true>, dim3((c + 63) / 64, BN_GROUPS), dim3(256), 0, stream, y, dout, out,
-                     save_mean, save_invstd, relu, (long)rows, c, part);
+                     save_mean, save_invstd, relu, (long)rows, c, part, fin);
   int rc = check_launch("bn_partial_kernel<bwd>");
   if (rc != FRCNN_OK) return rc;
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, part, (long)rows, c, gamma,
-                     save_invstd, dgamma, dbeta, coef);
-  rc = check_launch("bn_bwd_final_kernel");
-  if (rc != FRCNN_OK) return rc;
+  if (!counters) {
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, part, c, fin);
+    rc = check_launch("bn_bwd_final_kernel");
+    if (rc != FRCNN_OK) return rc;
+  }
   const size_t n4 = (size_t)rows * (c / 4);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(256), 0, stream, dout, out, y, save_mean, save_invstd,
                      coef, relu, n4, c / 4, dy, dres);

@@ -196,7 +196,8 @@ class FramePool:
         self.max_keys = max(1, int(max_keys))
         self.capture_after = max(0, int(capture_after))
         self.autotune, self.warmup, self.use_graph = bool(autotune), int(warmup), bool(use_graph)
-        self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_streams)]
+        from .streams import concurrent_streams      # streams that overlap by measurement, not by hope (model/streams.py)
+        self.streams, self.distinct_queues = concurrent_streams(self.n_streams, self.dev)
         self.runners = {}             # key -> [runner or None] * streams
         self.sightings = {}           # key -> frames seen
         self.uncapturable = set()     # problems whose capture failed: eager from then on

@@ -394,7 +394,10 @@ class TrainPipeline:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         self.grads = [[torch.zeros_like(p) for p in self.params] for _ in range(self.slots)]
-        self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.slots)]
+        # one stream per slot, chosen by MEASUREMENT to overlap (model/streams.py: HIP streams share four hardware queues, and
+        # which ones collide depends on the process's history - the same pipeline ran at 9.5 or 11.4 ms per step with pool streams)
+        from .streams import concurrent_streams
+        self.streams, self.distinct_queues = concurrent_streams(self.slots, self.dev)
         self.runners = [dict() for _ in range(self.slots)]
         self.pending = [None] * self.slots         # per slot: [runner, event, loss value or None, counts or None]
         self.order = []                            # slots in submission order, not collected yet

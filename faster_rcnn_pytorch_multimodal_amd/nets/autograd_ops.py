@@ -10,6 +10,8 @@ convolution output that receives no gradient.  The LiDAR backbone trains its Bat
 (lib/nets/lidarnet.py:110,152-175): ``_BnTrainFn`` = ``frcnn_bn_train_fwd / _bwd``.  Activations are NHWC; parameters keep the reference's layouts
 (Conv2d (K,C,R,S), Linear (out,in)) and are re-laid out as KRSC through ``hip_modules.prepared_conv`` caches.
 """
+import os
+
 import torch
 
 from .. import ops
@@ -35,13 +37,28 @@ _KEEP = []      # operands of side-stream launches, held until the main stream h
 WGRAD_ON_SIDE_STREAM = True
 
 
-def _side_stream(device):
+# Side streams per device.  Every parameter is pinned to ONE of them (first come, round robin): launches that accumulate into the
+# same gradient buffer - the RPN head applied to five pyramid levels - stay ordered, launches of different parameters may overlap.
+WGRAD_SIDE_STREAMS = 1
+# captured steps: the BatchNorm backward adds d_gamma / d_beta into param.grad itself (False: temporaries + add_ launches; A/B)
+BN_GRADS_IN_KERNEL = os.environ.get('FRCNN_BN_GRADS_IN_KERNEL', '1') != '0'
+_STREAM_OF = {}    # (device, id of the gradient's owner) -> index
+
+
+def _side_stream(device, owner=None):
     if not WGRAD_ON_SIDE_STREAM:
         return torch.cuda.current_stream(device)
     key = str(device)
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device)
-    return _SIDE[key]
+    pool = _SIDE.setdefault(key, [])
+    want = max(1, int(WGRAD_SIDE_STREAMS))
+    while len(pool) < want:
+        pool.append(torch.cuda.Stream(device=device))
+    if want == 1 or owner is None:
+        return pool[0]
+    idx = _STREAM_OF.get((key, owner))
+    if idx is None:
+        idx = _STREAM_OF[(key, owner)] = len(_STREAM_OF) % want
+    return pool[idx % want]
 
 
 # Deferred filter gradients (ASYNC_WGRAD and GROUP_WGRAD): repeated layers of identical shape - the 22 equal Bottlenecks of
@@ -69,7 +86,7 @@ def _flush_group(key):
     x0 = entries[0][0]
     r, s, stride, pad = key[2:6]
     main = torch.cuda.current_stream(x0.device)
-    side = _side_stream(x0.device)
+    side = _side_stream(x0.device, id(entries[0][2]))
     if WGRAD_ON_SIDE_STREAM:
         side.wait_stream(main)
     with torch.cuda.stream(side):
@@ -110,9 +127,10 @@ def join_weight_grads(device=None):
     for k in list(_DEFER):
         if device is None or k[-1] == str(torch.device(device)):
             _flush_group(k)
-    for key, side in _SIDE.items():
+    for key, pool in _SIDE.items():
         if device is None or key == str(torch.device(device)):
-            torch.cuda.current_stream(side.device).wait_stream(side)
+            for side in pool:
+                torch.cuda.current_stream(side.device).wait_stream(side)
     _KEEP.clear()
 
 
@@ -138,7 +156,7 @@ def _wgrad(x, d_conv, r, s, stride, pad, targets):
         _defer_wgrad(x, d_conv, r, s, stride, pad, targets[0][0].grad)
         return [None]
     main = torch.cuda.current_stream(x.device)
-    side = _side_stream(x.device)
+    side = _side_stream(x.device, id(targets[0][0]))
     if WGRAD_ON_SIDE_STREAM:
         side.wait_stream(main)
     with torch.cuda.stream(side):
@@ -296,6 +314,15 @@ class _BnTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         y, out, gamma, mean, invstd = ctx.saved_tensors
+        wprm, bprm = ctx.affine
+        if (ASYNC_WGRAD and BN_GRADS_IN_KERNEL and ctx.needs_input_grad[2] and ctx.needs_input_grad[3] and wprm is not None and bprm is not None
+                and wprm.grad is not None and bprm.grad is not None and wprm.grad.is_contiguous() and bprm.grad.is_contiguous()):
+            # captured steps: d_gamma / d_beta are added into the parameters' gradient buffers by the BatchNorm backward's own
+            # statistics pass (no temporaries, no add_ launches: 168 of the LiDAR step's launches)
+            dy, dres, _, _ = ops.bn_train_bwd(dout.contiguous(), out, y, gamma.detach() if gamma is not None else None, mean, invstd,
+                                              relu=ctx.relu, want_res=ctx.has_res and ctx.needs_input_grad[1],
+                                              grad_gamma=wprm.grad.view(-1), grad_beta=bprm.grad.view(-1))
+            return dy if ctx.needs_input_grad[0] else None, dres, None, None, None, None
         dy, dres, dgamma, dbeta = ops.bn_train_bwd(dout.contiguous(), out, y, gamma.detach() if gamma is not None else None,
                                                    mean, invstd, relu=ctx.relu,
                                                    want_res=ctx.has_res and ctx.needs_input_grad[1])

@@ -818,6 +818,11 @@ def act_bwd(dy, y=None, scale=None, relu=False, want_res=False):
     return d_conv, d_res
 
 
+# True: the statistics / coefficient pass of frcnn_bn_train_fwd / _bwd runs inside the column-sum kernel (tile counters as for
+# the filter gradients); False: as a launch of its own (A/B, and the arithmetic is the same code: bit-identical)
+BN_FUSED_FINAL = os.environ.get('FRCNN_BN_FUSED_FINAL', '1') != '0'
+
+
 def bn_train_fwd(y, gamma, beta, eps, momentum, running_mean=None, running_var=None, residual=None, relu=False):
     """BatchNorm with batch statistics over the rows of an NHWC tensor (+ residual, ReLU); the running statistics are
     updated in place.  Returns (out, save_mean, save_invstd)."""
@@ -839,14 +844,17 @@ def bn_train_fwd(y, gamma, beta, eps, momentum, running_mean=None, running_var=N
     invstd = torch.empty_like(mean)
     nbytes = lib.frcnn_bn_train_ws_bytes(c)
     ws = _workspace(nbytes, y.device)
+    counters = _wgrad_counters(y.device, lib.frcnn_bn_train_counters(c)) if BN_FUSED_FINAL else None
     _hip.check(lib.frcnn_bn_train_fwd(_ptr(y), rows, c, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
                                       _ptr(running_mean), _ptr(running_var), _ptr(residual), int(bool(relu)), _ptr(out),
-                                      _ptr(mean), _ptr(invstd), _ptr(ws), nbytes, _stream()), "frcnn_bn_train_fwd")
+                                      _ptr(mean), _ptr(invstd), _ptr(ws), nbytes, _ptr(counters), _stream()),
+               "frcnn_bn_train_fwd")
     return out, mean, invstd
 
 
-def bn_train_bwd(dout, out, y, gamma, save_mean, save_invstd, relu=False, want_res=False):
-    """Backward of bn_train_fwd: returns (dy, dres or None, dgamma, dbeta)."""
+def bn_train_bwd(dout, out, y, gamma, save_mean, save_invstd, relu=False, want_res=False, grad_gamma=None, grad_beta=None):
+    """Backward of bn_train_fwd: returns (dy, dres or None, dgamma, dbeta).  ``grad_gamma`` / ``grad_beta`` (both or neither):
+    the parameters' own (c,) gradient buffers - the sums are ADDED into them and returned as dgamma / dbeta."""
     lib = _hip.load()
     _dev_f32(dout, "dout"); _dev_f32(y, "y"); _dev_f32(save_mean, "save_mean"); _dev_f32(save_invstd, "save_invstd")
     if relu:
@@ -857,13 +865,21 @@ def bn_train_bwd(dout, out, y, gamma, save_mean, save_invstd, relu=False, want_r
         raise _hip.HipError("bn_train_bwd: shape mismatch")
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_res else None
-    dgamma = torch.empty((c,), dtype=torch.float32, device=y.device)
-    dbeta = torch.empty_like(dgamma)
+    accumulate = grad_gamma is not None
+    if accumulate:
+        if grad_beta is None or grad_gamma.numel() != c or grad_beta.numel() != c:
+            raise _hip.HipError("bn_train_bwd: grad_gamma and grad_beta must both be (c,) gradient buffers")
+        dgamma, dbeta = _dev_f32(grad_gamma, "grad_gamma"), _dev_f32(grad_beta, "grad_beta")
+    else:
+        dgamma = torch.empty((c,), dtype=torch.float32, device=y.device)
+        dbeta = torch.empty_like(dgamma)
     nbytes = lib.frcnn_bn_train_ws_bytes(c)
     ws = _workspace(nbytes, y.device)
+    counters = _wgrad_counters(y.device, lib.frcnn_bn_train_counters(c)) if BN_FUSED_FINAL else None
     _hip.check(lib.frcnn_bn_train_bwd(_ptr(dout), _ptr(out) if relu else None, _ptr(y), rows, c, _ptr(gamma),
                                       _ptr(save_mean), _ptr(save_invstd), int(bool(relu)), _ptr(dy), _ptr(dres),
-                                      _ptr(dgamma), _ptr(dbeta), _ptr(ws), nbytes, _stream()), "frcnn_bn_train_bwd")
+                                      _ptr(dgamma), _ptr(dbeta), int(accumulate), _ptr(ws), nbytes, _ptr(counters), _stream()),
+               "frcnn_bn_train_bwd")
     return dy, dres, dgamma, dbeta
 
 

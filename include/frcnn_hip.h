@@ -415,14 +415,21 @@ int frcnn_act_bwd(const float* dy, const float* y, const float* scale, int relu,
  *        running_mean/var (may be NULL) <- (1-momentum)*running + momentum*(mean | UNBIASED var).
  *   bwd: g = relu ? (out > 0 ? dout : 0) : dout; dbeta = sum g; dgamma = sum g*xhat;
  *        dy = gamma*invstd*(g - dbeta/rows - xhat*dgamma/rows); dres = g (may be NULL).
- * Column sums are carried in fp64 and added in a fixed order. */
+ *        accumulate != 0: dgamma / dbeta are the parameters' own gradient buffers and are added into.
+ * Column sums are carried in fp64 and added in a fixed order.
+ * counters: frcnn_bn_train_counters(c) ints, zero on entry and left zero, not shared by launches that can be in flight
+ * together (the rule of frcnn_conv2d_bwd_weight's counters): the last workgroup of a 64-channel column block turns the column
+ * sums into the statistics / coefficients itself - two launches per call instead of three.  NULL: a separate pass does. */
 size_t frcnn_bn_train_ws_bytes(int c);
+int frcnn_bn_train_counters(int c);
 int frcnn_bn_train_fwd(const float* y, int64_t rows, int c, const float* gamma, const float* beta, float eps,
                        float momentum, float* running_mean, float* running_var, const float* residual, int relu,
-                       float* out, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, void* stream);
+                       float* out, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, int* counters,
+                       void* stream);
 int frcnn_bn_train_bwd(const float* dout, const float* out, const float* y, int64_t rows, int c, const float* gamma,
                        const float* save_mean, const float* save_invstd, int relu, float* dy, float* dres,
-                       float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+                       float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, int* counters,
+                       void* stream);
 
 /* fc7 = x.mean(3).mean(2) (_head_to_tail of the non-FPN detector; x (rows,P,P,c) NHWC -> out (rows,c)) and its
  * backward dx = dout / P^2 broadcast over the P x P positions. */

@@ -2633,6 +2633,29 @@ def test_batchnorm_batch_statistics_fwd_bwd(hip, rows, c, relu, res):
         np.testing.assert_array_equal(dres.cpu().numpy(), resid.grad.numpy())
     else:
         assert dres is None
+    # the statistics / coefficient pass inside the column-sum kernel (last workgroup of a column block, the default above)
+    # and as a launch of its own are the same arithmetic: every output bit for bit; and the accumulating form adds d_gamma /
+    # d_beta into buffers that already hold values
+    assert ops.BN_FUSED_FINAL
+    ops.BN_FUSED_FINAL = False
+    try:
+        rm2, rv2 = rm.to(DEV), rv.to(DEV)
+        out2, mean2, invstd2 = ops.bn_train_fwd(y.detach().to(DEV), gamma.detach().to(DEV), beta.detach().to(DEV), eps, mom, rm2, rv2,
+                                                resid.detach().to(DEV) if res else None, relu)
+        dy2, dres2, dgamma2, dbeta2 = ops.bn_train_bwd(dout.to(DEV), out2, y.detach().to(DEV), gamma.detach().to(DEV), mean2, invstd2,
+                                                       relu=relu, want_res=res)
+    finally:
+        ops.BN_FUSED_FINAL = True
+    for a, b in ((out, out2), (mean, mean2), (invstd, invstd2), (rm_d, rm2), (rv_d, rv2), (dy, dy2), (dgamma, dgamma2), (dbeta, dbeta2)):
+        assert torch.equal(a, b)
+    acc_g, acc_b = torch.full((c,), 2.0, device=DEV), torch.full((c,), -1.0, device=DEV)
+    dy3, _, g3, b3 = ops.bn_train_bwd(dout.to(DEV), out, y.detach().to(DEV), gamma.detach().to(DEV), mean, invstd, relu=relu,
+                                      want_res=res, grad_gamma=acc_g, grad_beta=acc_b)
+    assert g3.data_ptr() == acc_g.data_ptr() and torch.equal(dy3, dy)
+    assert torch.equal(acc_g, 2.0 + dgamma) and torch.equal(acc_b, -1.0 + dbeta)
+    torch.cuda.synchronize()
+    for ring in ops._COUNTER_RINGS.values():
+        assert int(ring.ints.abs().max()) == 0
 
 
 def test_conv_plan_autotune_export_import(hip):

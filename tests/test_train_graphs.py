@@ -414,3 +414,56 @@ def test_capture_collects_dead_graphs_first_and_holds_the_collector_off(hip):
         assert not gc.isenabled()                                 # a caller that runs with the collector off stays that way
     finally:
         gc.enable() if was else gc.disable()
+
+
+def test_filter_gradients_on_two_side_streams_equal_the_eager_step(hip):
+    """autograd_ops.WGRAD_SIDE_STREAMS = 2: every parameter is pinned to one of two side streams, so launches into the same
+    gradient buffer (the RPN head on five pyramid levels) stay ordered while different layers' filter gradients may overlap;
+    their tile counters come from the runner's arena, one range per launch.  Losses and gradients of the replayed step follow
+    the eager step over three frames."""
+    from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.nets import autograd_ops
+    net_e, _ = T._build_fpn_pair(seed=29)
+    net_g, _ = T._build_fpn_pair(seed=29)
+    data, info, gt, _, _ = T._fpn_case()
+    for n in (net_e, net_g):
+        n.train()
+    net_g.enable_train_graphs(True)
+    opts = [torch.optim.SGD([p for p in n.parameters() if p.requires_grad], lr=1e-3) for n in (net_e, net_g)]
+    prev = autograd_ops.WGRAD_SIDE_STREAMS
+    autograd_ops.WGRAD_SIDE_STREAMS = 2
+    try:
+        for it in range(3):
+            blobs = {"data": data * (1.0 + 0.1 * it), "info": info, "gt_boxes": gt, "gt_boxes_dc": np.zeros((0, 4), np.float32)}
+            for o in opts:
+                o.zero_grad(set_to_none=False)
+            losses = [None, None]
+            for idx in (1, 0):
+                torch.manual_seed(400 + it)
+                losses[idx] = (net_e, net_g)[idx].train_step(blobs, opts[idx], update_weights=False)
+            assert abs(losses[0] - losses[1]) <= 2e-5 * max(1.0, abs(losses[0])), (it, losses)
+            worst, name = _grad_dev(net_e, net_g)
+            assert worst <= 1e-4, (it, name, worst)
+        assert len(autograd_ops._SIDE[str(torch.device(DEV))]) == 2
+    finally:
+        autograd_ops.WGRAD_SIDE_STREAMS = prev
+        C.reset_cfg()
+
+
+def test_concurrent_streams_are_chosen_by_measurement(hip):
+    """model/streams.concurrent_streams: HIP streams share GPU_MAX_HW_QUEUES (4) hardware queues, and two streams on one
+    queue run one after the other.  Of the streams torch hands out, some pairs are serialised (the probe must see that, or
+    the premise is gone); the three / four streams picked for the pipelines overlap pairwise, measured again here with a
+    longer kernel."""
+    from faster_rcnn_pytorch_multimodal_amd.model import streams as S
+    pool = [torch.cuda.Stream() for _ in range(10)]
+    ser = S.serialised_pairs(pool)
+    assert any(ser.values()) and not all(ser.values()), ser       # ten streams on four queues: some share, some do not
+    for n in (3, 4):
+        chosen, distinct = S.concurrent_streams(n, DEV)
+        assert len(chosen) == n and len({s.cuda_stream for s in chosen}) == n
+        assert distinct == n, (n, distinct)
+        again = S.serialised_pairs(chosen, cycles=4 * S.PROBE_CYCLES)
+        assert not any(again.values()), again
+    seven, distinct = S.concurrent_streams(7, DEV)                 # more streams than queues: as many distinct as there are
+    assert len(seven) == 7 and 3 <= distinct <= 7

@@ -310,7 +310,17 @@ def main():
     ap.add_argument("--group-wgrad", action="store_true", help="A/B: grouped filter-gradient launches per ResNet stage (autograd_ops.GROUP_WGRAD)")
     ap.add_argument("--group-wgrad-size", type=int, default=0, help="A/B: layers per grouped filter-gradient launch")
     ap.add_argument("--wgrad-variant", type=int, default=0, help="A/B: frcnn_conv2d_wgrad_set_variant (1 register-staged kernels, 2 LDS-DMA)")
+    ap.add_argument("--plans", default="", help="import a convolution plan table (bench.py --plans / profiles/r05_plans.json) before running")
+    ap.add_argument("--export-plans", default="", help="write the convolution plan table after the run")
+    ap.add_argument("--wgrad-streams", type=int, default=0, help="A/B: side streams of the filter gradients (autograd_ops.WGRAD_SIDE_STREAMS)")
     args = ap.parse_args()
+    if args.plans:
+        from faster_rcnn_pytorch_multimodal_amd import ops as _o3
+        with open(args.plans) as f:
+            _o3.import_conv_plans(json.load(f))
+    if args.wgrad_streams:
+        from faster_rcnn_pytorch_multimodal_amd.nets import autograd_ops as _a5
+        _a5.WGRAD_SIDE_STREAMS = args.wgrad_streams
     if args.wgrad_variant:
         from faster_rcnn_pytorch_multimodal_amd import ops as _o2
         _o2.set_wgrad_variant(args.wgrad_variant)
@@ -344,6 +354,10 @@ def main():
         res = lidar_train(args.steps or 64, modes=tuple(args.modes.split(",")) if args.modes else ("eager", "graph", "pipeline"))
         for r in (res if isinstance(res, list) else [res]):
             print(json.dumps(r))
+    if args.export_plans:
+        from faster_rcnn_pytorch_multimodal_amd import ops as _o4
+        with open(args.export_plans, "w") as f:
+            json.dump(_o4.export_conv_plans(), f)
 
 
 if __name__ == "__main__":
