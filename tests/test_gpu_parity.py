@@ -1297,11 +1297,21 @@ def test_lidar_fpn_detector_stagewise_against_oracle(hip):
     C.reset_cfg()
 
 
+def _forget_tuned_plans():
+    """The fp64-yardstick tests below compare two samples of fp32 rounding pushed through dozens of batch-statistics BatchNorms:
+    which convolution plans (summation orders) an EARLIER test's autotuning happened to leave in the process-wide cache moved
+    the device's median between 0.8x and 1.9x of the oracle's from run to run (round 5: one failure in six suite runs).  With
+    the caches emptied the step runs on the modelled plans: the same arithmetic in every run."""
+    from faster_rcnn_pytorch_multimodal_amd import _hip
+    _hip.load().frcnn_conv2d_clear_plans()
+
+
 def test_lidar_fpn_train_step_matches_oracle_autograd(hip):
     """LiDAR detector on the FPN backbone, FIXED_BLOCKS = 1: layer2..4 BatchNorm on batch statistics (layer4 is part of
     the backbone here and keeps its BatchNorm), pyramid + multi-level RoIAlign backward, 7-element targets and the
     sin(ry) loss.  Losses vs the fp32 oracle, gradients vs the fp64 oracle with the fp32 oracle's distance as yardstick."""
     from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    _forget_tuned_plans()
     net, oracle = _build_lidar_fpn_pair(seed=43)
     oracle.set_trainable(1)
     oracle.train_mode(1)
@@ -2911,6 +2921,7 @@ def test_lidar_train_step_matches_oracle_autograd(hip):
     second stage regresses 7 elements with the sin(ry) Huber term.  Forward losses, every parameter gradient and the
     updated running statistics against torch-CPU autograd on identical (injected) targets."""
     from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    _forget_tuned_plans()
     net, oracle = _build_lidar_pair(seed=41)
     oracle.set_trainable(1)
     oracle.train_mode(1)
@@ -3049,6 +3060,7 @@ def test_image_train_step_all_blocks_trainable(hip):
     layers.  Losses against the fp32 oracle; the 321 parameter gradients against the fp64 oracle with the fp32
     oracle's own distance as the yardstick (same criterion as the LiDAR step)."""
     from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    _forget_tuned_plans()
     net, _ = _build_pair(seed=51, fixed_blocks=-1)
     oracle = _image_oracle_all_trainable(51)
     data, info, gt, rois, scores = _fpn_case()

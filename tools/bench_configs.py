@@ -222,7 +222,7 @@ def fpn_train(steps, autotune=True, graph=False, inflight=1, modes=None):
         elif mode == "graph":
             net.enable_train_graphs(True)        # model/train_graph.py: the step replayed as one hipGraph
             losses, dt = _timed_train_windows(net, blobs, opt, steps)
-            launch, wg = "hipGraph replay of the whole step, one frame at a time", "on a side stream"
+            launch, wg = "hipGraph replay of the whole step, one frame at a time", "on a side stream, grouped per ResNet stage"
         else:
             losses, dt = _timed_train_windows(net, blobs, opt, steps)
             launch, wg = "eager (autograd)", "per layer inside autograd's backward (synchronous)"
