@@ -283,3 +283,30 @@ def test_fuzz_wgrad_dma_addressing_against_register_staged_kernel(shape, seed):
     scale = max(float(ref.abs().max()), 1e-6)
     for kernel in (1, 3, 4):
         assert float((got[kernel] - ref).abs().max()) <= 2e-5 * scale + 1e-6, (shape, kernel)
+
+
+def test_wgrad_split_slabs_are_fresh_in_every_launch():
+    """The pixel-split slabs of conv_wgrad_dma_f32 cross XCDs at agent scope (sc1 stores / loads, no device-scope fence): a
+    launch must never read a slab line that an earlier launch left in some L2.  Six launches of one shape with DIFFERENT operands,
+    back to back on one stream - the caching allocator hands every launch the same workspace block, a replayed graph would too -
+    each against float64 autograd; the counters end at zero."""
+    ops = _ops()
+    n, h, w, c, k, r = 1, 38, 63, 256, 256, 1
+    g = torch.Generator().manual_seed(7)
+    try:
+        for kernel, splits in ((3, 16), (4, 16), (3, 64)):
+            ops.set_wgrad_plan(kernel, splits)
+            outs, refs, ptrs = [], [], set()
+            for it in range(6):
+                x = torch.randn(n, h, w, c, generator=g) * (1.0 + it)
+                dy = torch.randn(n, h, w, k, generator=g)
+                refs.append((dy.reshape(-1, k).double().t() @ x.reshape(-1, c).double()).float())       # (K, C): 1x1 filter gradient
+                outs.append(ops.conv2d_bwd_weight(x.to(DEV), dy.to(DEV), r, r)[0])
+            torch.cuda.synchronize()
+            for it, (o, ref) in enumerate(zip(outs, refs)):
+                scale = float(ref.abs().max())
+                assert float((o.cpu().reshape(k, c) - ref).abs().max()) <= 2e-5 * scale, (kernel, splits, it)
+    finally:
+        ops.set_wgrad_plan(0)
+    for ring in ops._COUNTER_RINGS.values():
+        assert int(ring.ints.abs().max()) == 0
