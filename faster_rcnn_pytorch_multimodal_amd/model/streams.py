@@ -48,6 +48,32 @@ def serialised_pairs(streams, cycles=PROBE_CYCLES, reps=3):
     return out
 
 
+def choose_overlapping(serialised, count, n):
+    """Indices of ``n`` of ``count`` candidates given ``serialised[(i, j)]`` (i < j): the largest mutually overlapping set of at
+    most ``n`` first (smallest indices among equals), then - when the process has fewer queues than ``n`` - one more candidate per
+    chosen queue in turn, so that the surplus is spread evenly.  Returns (indices, size of the overlapping set)."""
+    def overlap(i, j):
+        return not serialised[(min(i, j), max(i, j))]
+    best = []
+    for size in range(min(n, count), 0, -1):
+        for combo in itertools.combinations(range(count), size):
+            if all(overlap(i, j) for i, j in itertools.combinations(combo, 2)):
+                best = list(combo)
+                break
+        if best:
+            break
+    chosen = list(best)
+    rest = [i for i in range(count) if i not in chosen]
+    k = 0
+    while len(chosen) < n and rest:
+        target = best[k % len(best)]
+        pick = next((i for i in rest if not overlap(i, target)), rest[0])
+        chosen.append(pick)
+        rest.remove(pick)
+        k += 1
+    return chosen, len(best)
+
+
 def concurrent_streams(n, device=None, candidates=CANDIDATES):
     """``n`` torch streams on ``device`` chosen so that as many of them as possible run concurrently (see the module text).
     Returns (streams, distinct) where ``distinct`` is the size of the mutually concurrent set found (== n when all overlap)."""
@@ -58,25 +84,5 @@ def concurrent_streams(n, device=None, candidates=CANDIDATES):
     with torch.cuda.device(device):
         pool = [torch.cuda.Stream(device=device) for _ in range(max(candidates, n))]
         ser = serialised_pairs(pool)
-
-    def overlap(i, j):
-        return not ser[(min(i, j), max(i, j))]
-    best = []
-    for size in range(n, 0, -1):
-        for combo in itertools.combinations(range(len(pool)), size):
-            if all(overlap(i, j) for i, j in itertools.combinations(combo, 2)):
-                best = list(combo)
-                break
-        if best:
-            break
-    chosen = list(best)
-    # fewer queues than streams asked for: spread the rest over the chosen queues, one more stream per queue in turn
-    k = 0
-    rest = [i for i in range(len(pool)) if i not in chosen]
-    while len(chosen) < n and rest:
-        target = best[k % len(best)]
-        pick = next((i for i in rest if not overlap(i, target)), rest[0])
-        chosen.append(pick)
-        rest.remove(pick)
-        k += 1
-    return [pool[i] for i in chosen], len(best)
+    chosen, distinct = choose_overlapping(ser, len(pool), n)
+    return [pool[i] for i in chosen], distinct

@@ -336,3 +336,26 @@ def test_committed_profiles_describe_the_committed_plan_table():
     # every plan of the table is one the library accepts: tile index < 13, algorithm code <= 2
     for r in rows:
         assert len(r) == 13 and (r[10] & 15) < 14 and (r[10] >> 4) <= 2 and r[11] >= 1
+
+
+def test_stream_selection_from_a_measured_collision_matrix():
+    """model/streams.choose_overlapping (the host half of concurrent_streams): given which candidate pairs were measured to run
+    one after the other - here the pattern of a fresh process on four hardware queues, tools/stream_concurrency_probe.py:
+    candidates {2,3,7,11}, {0,5,9}, {1,4,8}, {6,10} share a queue - it returns a mutually overlapping set of the size asked
+    for when there is one, and otherwise the largest one padded evenly over its queues."""
+    import itertools
+    from faster_rcnn_pytorch_multimodal_amd.model.streams import choose_overlapping
+    queue = {2: 0, 3: 0, 7: 0, 11: 0, 0: 1, 5: 1, 9: 1, 1: 2, 4: 2, 8: 2, 6: 3, 10: 3}
+    ser = {(i, j): queue[i] == queue[j] for i, j in itertools.combinations(range(12), 2)}
+    for n in (2, 3, 4):
+        chosen, distinct = choose_overlapping(ser, 12, n)
+        assert distinct == n == len(chosen) == len({queue[i] for i in chosen}), (n, chosen)
+    chosen, distinct = choose_overlapping(ser, 12, 4)
+    assert chosen == [0, 1, 2, 6]                                    # smallest indices among equal choices
+    chosen, distinct = choose_overlapping(ser, 12, 7)                # more streams than queues: 4 distinct, 3 more, one per queue
+    assert distinct == 4 and len(set(chosen)) == 7
+    load = [sum(queue[i] == q for i in chosen) for q in range(4)]
+    assert sorted(load) == [1, 2, 2, 2], load
+    everything_collides = {(i, j): True for i, j in itertools.combinations(range(5), 2)}       # GPU_MAX_HW_QUEUES=1
+    chosen, distinct = choose_overlapping(everything_collides, 5, 3)
+    assert distinct == 1 and len(set(chosen)) == 3
