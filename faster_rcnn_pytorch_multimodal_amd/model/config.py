@@ -64,7 +64,7 @@ def _defaults():
         TOD_FILTER_LIST=['Day', 'Night', 'Dawn/Dusk'],
         # not in the reference: how SolverWrapper executes a step (model/train_graph.py)
         GRAPHS=True,             # replay each training step as a captured hipGraph (False: eager autograd launches)
-        FRAMES_IN_FLIGHT=3,      # frames of a pseudo batch in flight as single-chain graphs (1: one captured step at a time)
+        FRAMES_IN_FLIGHT=4,      # frames of a pseudo batch in flight as single-chain graphs, one per hardware queue (1: one captured step at a time)
         LIDAR=dict(BBOX_NORMALIZE_MEANS=(0.0,) * 7, BBOX_NORMALIZE_STDS=(0.1, 0.1, 0.1, 0.2, 0.2, 0.2, 1.0)),
         IMAGE=dict(BBOX_NORMALIZE_MEANS=(0.0, 0.0, 0.0, 0.0), BBOX_NORMALIZE_STDS=(0.1, 0.1, 0.2, 0.2)))
     c.TEST = dict(SCALES=(1.0,), NMS_THRESH=0.6, BBOX_REG=True, HAS_RPN=True, RPN_NMS_THRESH=0.7,

@@ -205,8 +205,8 @@ def test_solver_validation_replays_captured_frames(hip, tmp_path):
 
 
 def test_train_pipeline_updates_batchnorm_statistics_in_frame_order(hip):
-    """BatchNorm on batch statistics (LiDAR layer2/3, lib/nets/lidarnet.py:152-175) with three captured steps in flight
-    (cfg.TRAIN.FRAMES_IN_FLIGHT, the solver's default): the slots' replays overlap, so the running statistics must not be
+    """BatchNorm on batch statistics (LiDAR layer2/3, lib/nets/lidarnet.py:152-175) with four captured steps in flight
+    (cfg.TRAIN.FRAMES_IN_FLIGHT, the solver's default: one per hardware queue): the slots' replays overlap, so the running statistics must not be
     read-modify-written by the captured launches themselves (lost updates, lost counts).  Every slot leaves its frame's batch
     statistics in private buffers and the pipeline folds them in submission order - after 7 strongly different frames the
     running statistics and num_batches_tracked equal those of the sequential eager loop (the reference's per-frame update)."""
@@ -219,7 +219,9 @@ def test_train_pipeline_updates_batchnorm_statistics_in_frame_order(hip):
         n.train()
     frames = [{"data": data * (1.0 + 0.6 * it), "info": info, "gt_boxes": (gt, gt[:2], gt[1:4])[it % 3],
                "gt_boxes_dc": np.zeros((0, 4), np.float32)} for it in range(7)]
-    pipe = TrainPipeline(net_p, slots=3)
+    assert C.cfg.TRAIN.FRAMES_IN_FLIGHT == 4
+    pipe = TrainPipeline(net_p, slots=int(C.cfg.TRAIN.FRAMES_IN_FLIGHT))
+    assert pipe.distinct_queues == 4                          # every slot's stream on a hardware queue of its own
     torch.manual_seed(91)
     for b in frames:
         if pipe.in_flight() >= pipe.slots:

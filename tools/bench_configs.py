@@ -215,7 +215,7 @@ def fpn_train(steps, autotune=True, graph=False, inflight=1, modes=None):
     for mode in modes:
         _restore(net, opt, start)          # every mode starts from the SAME weights and an empty optimizer state
         if mode == "pipeline":
-            n_in = inflight if inflight > 1 else 3
+            n_in = inflight if inflight > 1 else 4
             losses, dt = _timed_pipeline_windows(net, blobs, opt, steps, n_in)
             launch = "hipGraph replay of the whole step, %d frames of a pseudo batch in flight (TrainPipeline, single-chain graphs)" % n_in
             wg = "in line, grouped per ResNet stage"
@@ -277,7 +277,7 @@ def lidar_train(steps, modes=("eager",)):
         if mode == "graph":
             net.enable_train_graphs(True)
         if mode == "pipeline":
-            losses, dt = _timed_pipeline_windows(net, blobs, opt, steps, 3)
+            losses, dt = _timed_pipeline_windows(net, blobs, opt, steps, 4)
         else:
             losses, dt = _timed_train_windows(net, blobs, opt, steps)
         out.append({"metric": "train steps/sec res101 LiDAR-BEV Faster-RCNN 400x350x15 forward+backward", "value": steps / dt,
@@ -286,7 +286,7 @@ def lidar_train(steps, modes=("eager",)):
                     "config": {"workload": "training counterpart of BASELINE.json configs[2]: 8 gt boxes, 256 sampled RoIs, "
                                            "FIXED_BLOCKS=1 (layer2/3 BatchNorm on batch statistics)",
                                "launch": {"graph": "hipGraph replay of the whole step, one frame at a time",
-                                          "pipeline": "hipGraph replay, 3 frames of a pseudo batch in flight (TrainPipeline, single-chain graphs)",
+                                          "pipeline": "hipGraph replay, 4 frames of a pseudo batch in flight (TrainPipeline, single-chain graphs)",
                                           "eager": "eager (autograd)"}[mode],
                                "loss_first": losses[0], "loss_last": losses[-1]}})
     C.reset_cfg()
