@@ -65,9 +65,10 @@ def _side_stream(device, owner=None):
 # layer3 - are collected per shape and launched TOGETHER (ops.conv2d_bwd_weight_acc_grouped): one launch pair per shape instead
 # of a pixel-split launch + a slab reduction per layer.  A group is flushed to the side stream when it is full, when its shape
 # has not come up for _STALE calls (its stage's backward is over), and at join_weight_grads().
-# OFF by default: the grouped launches are far more efficient (128 TFLOP/s against ~35 for the per-layer launches; 828 -> 678
-# launches and 17.5 -> 16.2 ms of kernel time per FPN step) but they run AFTER their stage's data-gradient chain instead of
-# next to it, and the step is bound by that chain: 15.3-15.4 ms against 15.0-15.2 ms per replayed step (same-box A/B).
+# OFF for the eager step; ON in every captured step since round 5 (model/train_graph.TrainStepRunner).  The grouped launches
+# are far more efficient (one unsplit launch per shape and stage) but run AFTER their stage's data-gradient chain instead of
+# next to it: with the register-staged kernel and its accumulation kernel they lost (15.3-15.4 against 15.0-15.2 ms per replayed
+# step, round 3); with conv_wgrad_dma_f32, which adds into param.grad itself, they win (14.7 -> 14.3 ms, round 5).
 GROUP_WGRAD = False
 # {id(BatchNorm module): (mean buffer, variance buffer)} while a training step with DEFERRED running statistics is captured
 # (model/train_graph.TrainStepRunner(defer_bn_stats=True)), else None: see _BnTrainFn.forward
