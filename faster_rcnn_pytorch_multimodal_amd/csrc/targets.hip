@@ -58,6 +58,7 @@ struct AtlFrame {
 };
 
 constexpr int ATL_MAX_GT_LDS = 512;
+constexpr unsigned ATL_LABEL_BLOCKS = 1024;   // atl_label_kernel: grid-stride over the anchors, one atomic pair per workgroup
 
 __global__ __launch_bounds__(256) void atl_overlap_kernel(const float* __restrict__ anchors, int n,
                                                          const float* __restrict__ gt, int g,
@@ -140,15 +141,22 @@ __global__ __launch_bounds__(256) void atl_label_kernel(const float* __restrict_
     n_fg += lab == 1.f;
     n_bg += lab == 0.f;
   }
-  // candidate counts: one global atomic per wave and label (an atomic per candidate was ~250 K same-address atomics for the
-  // background anchors of a 1000x600 FPN frame: 167 us; integer sums, any order)
+  // candidate counts: ONE global atomic per workgroup and label, and at most ATL_LABEL_BLOCKS workgroups.  Same-address
+  // atomics retire ~10 ns apart: one per candidate (~250 K background anchors of a 1000x600 FPN frame) and then one per wave
+  // (14 600 waves) both left the kernel at 167 us, all of it the atomic queue.  Integer sums, any order.
+  __shared__ int s_cnt[2][4];
   for (int off = 32; off > 0; off >>= 1) {
     n_fg += __shfl_xor(n_fg, off);
     n_bg += __shfl_xor(n_bg, off);
   }
   if ((threadIdx.x & 63) == 0) {
-    if (n_fg) atomicAdd(counters + 0, n_fg);
-    if (n_bg) atomicAdd(counters + 1, n_bg);
+    s_cnt[0][threadIdx.x >> 6] = n_fg;
+    s_cnt[1][threadIdx.x >> 6] = n_bg;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int total = ((s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1]) + s_cnt[threadIdx.x][2]) + s_cnt[threadIdx.x][3];
+    if (total) atomicAdd(counters + threadIdx.x, total);
   }
 }
 
@@ -454,7 +462,7 @@ extern "C" int frcnn_anchor_target_layer(const float* anchors, int n, const floa
                      argmax, gt_max);
   int rc = check_launch("atl_overlap_kernel");
   if (rc != FRCNN_OK) return rc;
-  hipLaunchKernelGGL(atl_label_kernel, dim3(grid), dim3(256), 0, stream, anchors, n, gt_boxes, num_gt, num_gt_dev, max_ov,
+  hipLaunchKernelGGL(atl_label_kernel, dim3(std::min(grid, ATL_LABEL_BLOCKS)), dim3(256), 0, stream, anchors, n, gt_boxes, num_gt, num_gt_dev, max_ov,
                      gt_max, negative_overlap, positive_overlap, seed, seed_dev, labels, key_fg, key_bg, counters);
   rc = check_launch("atl_label_kernel");
   if (rc != FRCNN_OK) return rc;
