@@ -44,6 +44,15 @@ def gt_capacity(num_gt):
     return cap
 
 
+def capture_switches():
+    """The process-wide switches a captured training step bakes in, as a hashable part of every runner key: a holder of
+    captured steps (Network._train_graphs, SolverWrapper, TrainPipeline) then never replays a step that was captured under
+    other settings."""
+    from .. import _hip, ops
+    return (bool(cfg.TRAIN.IGNORE_DC), bool(ops.BN_FUSED_FINAL), bool(autograd_ops.BN_GRADS_IN_KERNEL),
+            int(autograd_ops.WGRAD_SIDE_STREAMS), int(_hip.load().frcnn_settings_signature()))
+
+
 def packet_capture_disabled():
     """Was the HIP runtime started with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (the general replay path for every graph)?"""
     import os
@@ -426,7 +435,7 @@ class TrainPipeline:
                                "%d frames)" % (s, self.slots))
         data, info = blobs['data'], np.asarray(blobs['info'], dtype=np.float32)
         key = (int(data.shape[1]), int(data.shape[2]), int(data.shape[3]), gt_capacity(len(blobs['gt_boxes'])),
-               tuple(float(v) for v in info), bool(cfg.TRAIN.IGNORE_DC))
+               tuple(float(v) for v in info), capture_switches())
         runner = self.runners[s].get(key)
         if runner is None:
             if len(self.runners[s]) >= self.max_graphs:

@@ -414,7 +414,7 @@ class SolverWrapper:
         from . import train_graph
         data, info = blobs['data'], np.asarray(blobs['info'], dtype=np.float32)
         key = (int(data.shape[1]), int(data.shape[2]), int(data.shape[3]), train_graph.gt_capacity(len(blobs['gt_boxes'])),
-               tuple(float(v) for v in info), bool(cfg.TRAIN.IGNORE_DC))
+               tuple(float(v) for v in info), train_graph.capture_switches())
         slot = pipe.runners[pipe.next_slot]
         return key in slot or len(slot) < pipe.max_graphs
 

@@ -704,7 +704,7 @@ class Network(nn.Module):
             data, info = blobs['data'], np.asarray(blobs['info'], dtype=np.float32)
             # one graph per frame geometry; the number of gt boxes only selects the capacity of its gt buffer (32, 64, ...)
             key = (int(data.shape[1]), int(data.shape[2]), int(data.shape[3]), train_graph.gt_capacity(len(blobs['gt_boxes'])),
-                   tuple(float(v) for v in info), bool(cfg.TRAIN.IGNORE_DC))
+                   tuple(float(v) for v in info), train_graph.capture_switches())
             runner = graphs.get(key)
             if runner is not None:
                 return runner

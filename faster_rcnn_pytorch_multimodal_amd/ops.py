@@ -286,7 +286,8 @@ def conv2d_bwd_data(dy, w_t, x_shape, stride=1, pad=0, add=None, w_winograd=None
     return dx
 
 
-# Tile counters of the filter-gradient kernels (`counters` of frcnn_conv2d_bwd_weight[_acc]): device ints that are zero when a
+# Tile counters of the filter-gradient and BatchNorm kernels (`counters` of frcnn_conv2d_bwd_weight[_acc], frcnn_bn_train_fwd /
+# _bwd: the last workgroup of a tile / column block finishes the reduction): device ints that are zero when a
 # launch starts and zero again when it ends; launches that may be in flight together must not share them.
 #   * eager launches take consecutive ranges of a per-device ring: a range comes round again only after WGRAD_COUNTER_RING
 #     ints of later launches - far more launches than can be in flight;
@@ -332,7 +333,7 @@ class wgrad_counter_arena:
         return False
 
 
-def _wgrad_counters(device, count):
+def _tile_counters(device, count):
     if WGRAD_ARENA is not None:
         if WGRAD_ARENA.ints.device != device:
             raise _hip.HipError("filter-gradient counter arena is on %s, the launch on %s" % (WGRAD_ARENA.ints.device, device))
@@ -370,7 +371,7 @@ def conv2d_bwd_weight(x, dy, r, s, stride=1, pad=0, want_bias=False):
     _log_flops('wgrad', 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * k * r * s * c)
     ws_bytes = lib.frcnn_conv2d_bwd_weight_ws_bytes(n, h, w, c, k, r, s, stride, pad)
     ws = _workspace(ws_bytes, x.device) if ws_bytes else None
-    counters = _wgrad_counters(x.device, lib.frcnn_conv2d_bwd_weight_counters(c, k, r, s))
+    counters = _tile_counters(x.device, lib.frcnn_conv2d_bwd_weight_counters(c, k, r, s))
     _hip.check(lib.frcnn_conv2d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), n, h, w, c, k, r, s, stride, pad,
                                            _ptr(ws), ws_bytes, counters.data_ptr(), _stream()), "frcnn_conv2d_bwd_weight")
     return dw, db
@@ -393,7 +394,7 @@ def conv2d_bwd_weight_acc(x, dy, r, s, grad_w, grad_b=None, stride=1, pad=0):
     _log_flops('wgrad', 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * k * r * s * c)
     ws_bytes = lib.frcnn_conv2d_bwd_weight_ws_bytes(n, h, w, c, k, r, s, stride, pad)
     ws = _workspace(ws_bytes, x.device)
-    counters = _wgrad_counters(x.device, lib.frcnn_conv2d_bwd_weight_counters(c, k, r, s))
+    counters = _tile_counters(x.device, lib.frcnn_conv2d_bwd_weight_counters(c, k, r, s))
     _hip.check(lib.frcnn_conv2d_bwd_weight_acc(_ptr(x), _ptr(dy), _ptr(grad_w), c_real, _ptr(grad_b), n, h, w, c, k, r, s,
                                                stride, pad, _ptr(ws), ws_bytes, counters.data_ptr(), _stream()),
                "frcnn_conv2d_bwd_weight_acc")
@@ -844,7 +845,7 @@ def bn_train_fwd(y, gamma, beta, eps, momentum, running_mean=None, running_var=N
     invstd = torch.empty_like(mean)
     nbytes = lib.frcnn_bn_train_ws_bytes(c)
     ws = _workspace(nbytes, y.device)
-    counters = _wgrad_counters(y.device, lib.frcnn_bn_train_counters(c)) if BN_FUSED_FINAL else None
+    counters = _tile_counters(y.device, lib.frcnn_bn_train_counters(c)) if BN_FUSED_FINAL else None
     _hip.check(lib.frcnn_bn_train_fwd(_ptr(y), rows, c, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
                                       _ptr(running_mean), _ptr(running_var), _ptr(residual), int(bool(relu)), _ptr(out),
                                       _ptr(mean), _ptr(invstd), _ptr(ws), nbytes, _ptr(counters), _stream()),
@@ -875,7 +876,7 @@ def bn_train_bwd(dout, out, y, gamma, save_mean, save_invstd, relu=False, want_r
         dbeta = torch.empty_like(dgamma)
     nbytes = lib.frcnn_bn_train_ws_bytes(c)
     ws = _workspace(nbytes, y.device)
-    counters = _wgrad_counters(y.device, lib.frcnn_bn_train_counters(c)) if BN_FUSED_FINAL else None
+    counters = _tile_counters(y.device, lib.frcnn_bn_train_counters(c)) if BN_FUSED_FINAL else None
     _hip.check(lib.frcnn_bn_train_bwd(_ptr(dout), _ptr(out) if relu else None, _ptr(y), rows, c, _ptr(gamma),
                                       _ptr(save_mean), _ptr(save_invstd), int(bool(relu)), _ptr(dy), _ptr(dres),
                                       _ptr(dgamma), _ptr(dbeta), int(accumulate), _ptr(ws), nbytes, _ptr(counters), _stream()),
