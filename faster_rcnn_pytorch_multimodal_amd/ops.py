@@ -338,7 +338,7 @@ def _tile_counters(device, count):
         if WGRAD_ARENA.ints.device != device:
             raise _hip.HipError("filter-gradient counter arena is on %s, the launch on %s" % (WGRAD_ARENA.ints.device, device))
         return WGRAD_ARENA.take(count)
-    if torch.cuda.is_current_stream_capturing():
+    if torch.device(device).type == 'cuda' and torch.cuda.is_current_stream_capturing():
         return torch.zeros(count, dtype=torch.int32, device=device)
     ring = _COUNTER_RINGS.get(str(device))
     if ring is None:

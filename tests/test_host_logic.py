@@ -359,3 +359,35 @@ def test_stream_selection_from_a_measured_collision_matrix():
     everything_collides = {(i, j): True for i, j in itertools.combinations(range(5), 2)}       # GPU_MAX_HW_QUEUES=1
     chosen, distinct = choose_overlapping(everything_collides, 5, 3)
     assert distinct == 1 and len(set(chosen)) == 3
+
+
+def test_tile_counter_arenas():
+    """ops.CounterArena / wgrad_counter_arena / _tile_counters (host logic of the `counters` argument of frcnn_conv2d_bwd_weight
+    and frcnn_bn_train_*): a runner's arena hands every launch of a pass its own range, the same ranges again after rewind(),
+    and refuses to overrun; without an arena eager launches walk a per-device ring that wraps instead of growing."""
+    from faster_rcnn_pytorch_multimodal_amd import _hip, ops
+    cpu = torch.device("cpu")
+    arena = ops.CounterArena(cpu, 16)
+    assert int(arena.ints.abs().max()) == 0 and arena.ints.dtype == torch.int32
+    with ops.wgrad_counter_arena(arena) as inside:
+        assert inside is arena and ops.WGRAD_ARENA is arena
+        a = ops._tile_counters(cpu, 6)
+        b = ops._tile_counters(cpu, 6)
+        assert a.numel() == b.numel() == 6 and b.data_ptr() == a.data_ptr() + 6 * 4
+        with pytest.raises(_hip.HipError, match="exhausted"):
+            ops._tile_counters(cpu, 6)
+        arena.rewind()                                             # the next pass over the same launch sequence
+        assert ops._tile_counters(cpu, 6).data_ptr() == a.data_ptr()
+        with ops.wgrad_counter_arena(ops.CounterArena(cpu, 4)) as inner:      # nests, and restores
+            assert ops.WGRAD_ARENA is inner
+        assert ops.WGRAD_ARENA is arena
+    assert ops.WGRAD_ARENA is None
+    saved, ops.WGRAD_COUNTER_RING = ops.WGRAD_COUNTER_RING, 8
+    ops._COUNTER_RINGS.pop("cpu", None)
+    try:
+        first = ops._tile_counters(cpu, 5)
+        second = ops._tile_counters(cpu, 5)                        # 5 + 5 > 8: the ring wraps to its start
+        assert second.data_ptr() == first.data_ptr() and ops._COUNTER_RINGS["cpu"].ints.numel() == 8
+    finally:
+        ops.WGRAD_COUNTER_RING = saved
+        ops._COUNTER_RINGS.pop("cpu", None)
