@@ -45,7 +45,8 @@ def lidar_forward(steps, streams=4):
     detect_frame_device(net, frames[0], info, 0.5, 100, 100)
     torch.cuda.synchronize()
     fl = ops.flops_end()
-    sts = [torch.cuda.Stream() for _ in range(streams)]
+    from faster_rcnn_pytorch_multimodal_amd.model.streams import concurrent_streams
+    sts, distinct = concurrent_streams(streams, "cuda:0")      # streams that overlap by measurement (model/streams.py)
     outs = [None] * streams
 
     def step(i):
@@ -65,6 +66,7 @@ def lidar_forward(steps, streams=4):
             "unit": "frames/s", "ms_per_step": 1e3 * dt / steps, "n_gpus": 1, "steps": steps, "dtype": "f32",
             "roofline": _roofline(fl, dt / steps, ("fwd",)),
             "config": {"workload": "BASELINE.json configs[2]", "frames_in_flight": streams, "launch": "hipGraph replay",
+                       "streams_on_distinct_hardware_queues": distinct,
                        "detections_last_frame": outs[0][1].cpu().tolist()}}
 
 
