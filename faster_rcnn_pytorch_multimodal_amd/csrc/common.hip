@@ -84,5 +84,5 @@ extern "C" int frcnn_set_memops_mode(int mode) {
 }
 extern "C" int frcnn_get_memops_mode(void) { return frcnn::g_memops_mode.load(); }
 
-extern "C" int frcnn_version(void) { return 108; }
+extern "C" int frcnn_version(void) { return 109; }
 extern "C" const char* frcnn_last_error(void) { return frcnn::error_buffer(); }
