@@ -709,7 +709,7 @@ class Network(nn.Module):
             if runner is not None:
                 return runner
             if len(graphs) < self._train_graph_max:
-                runner = graphs[key] = train_graph.TrainStepRunner(self, key[0], key[1], key[2], len(blobs['gt_boxes']), info)
+                runner = graphs[key] = train_graph.captured_step(self, key[0], key[1], key[2], len(blobs['gt_boxes']), info, blobs)
                 return runner
             why = "more than %d distinct frame geometries are held as graphs (enable_train_graphs(max_graphs=...))" % self._train_graph_max
         warned = self.__dict__.setdefault('_train_graph_warned', set())

@@ -64,6 +64,7 @@ def test_one_captured_step_serves_every_gt_count(hip):
     assert keys == [32, 64], keys
     # every runner counted its filter-gradient tiles in counters of its own, and every launch left them zero again
     torch.cuda.synchronize()
+    assert all(r.inline and r.edges == r.nodes - 1 for r in net_g._train_graphs.values())     # train_step's graphs are ONE chain
     arenas = [r.wgrad_counters for r in net_g._train_graphs.values()]
     assert len({a.ints.data_ptr() for a in arenas}) == 2
     for a in arenas:
@@ -424,6 +425,7 @@ def test_filter_gradients_on_two_side_streams_equal_the_eager_step(hip):
     their tile counters come from the runner's arena, one range per launch.  Losses and gradients of the replayed step follow
     the eager step over three frames."""
     from faster_rcnn_pytorch_multimodal_amd.model import config as C
+    from faster_rcnn_pytorch_multimodal_amd.model import train_graph
     from faster_rcnn_pytorch_multimodal_amd.nets import autograd_ops
     net_e, _ = T._build_fpn_pair(seed=29)
     net_g, _ = T._build_fpn_pair(seed=29)
@@ -432,8 +434,9 @@ def test_filter_gradients_on_two_side_streams_equal_the_eager_step(hip):
         n.train()
     net_g.enable_train_graphs(True)
     opts = [torch.optim.SGD([p for p in n.parameters() if p.requires_grad], lr=1e-3) for n in (net_e, net_g)]
-    prev = autograd_ops.WGRAD_SIDE_STREAMS
+    prev, supported = autograd_ops.WGRAD_SIDE_STREAMS, train_graph.inline_graphs_supported
     autograd_ops.WGRAD_SIDE_STREAMS = 2
+    train_graph.inline_graphs_supported = lambda: False           # the FORKED capture (train_step's default is the single chain)
     try:
         for it in range(3):
             blobs = {"data": data * (1.0 + 0.1 * it), "info": info, "gt_boxes": gt, "gt_boxes_dc": np.zeros((0, 4), np.float32)}
@@ -447,8 +450,10 @@ def test_filter_gradients_on_two_side_streams_equal_the_eager_step(hip):
             worst, name = _grad_dev(net_e, net_g)
             assert worst <= 1e-4, (it, name, worst)
         assert len(autograd_ops._SIDE[str(torch.device(DEV))]) == 2
+        assert all(not r.inline for r in net_g._train_graphs.values())
     finally:
         autograd_ops.WGRAD_SIDE_STREAMS = prev
+        train_graph.inline_graphs_supported = supported
         C.reset_cfg()
 
 

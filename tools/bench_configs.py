@@ -217,14 +217,14 @@ def fpn_train(steps, autotune=True, graph=False, inflight=1, modes=None):
     for mode in modes:
         _restore(net, opt, start)          # every mode starts from the SAME weights and an empty optimizer state
         if mode == "pipeline":
-            n_in = inflight if inflight > 1 else 4
+            n_in = int(os.environ.get("FRCNN_PIPE_SLOTS", inflight if inflight > 1 else 4))
             losses, dt = _timed_pipeline_windows(net, blobs, opt, steps, n_in)
             launch = "hipGraph replay of the whole step, %d frames of a pseudo batch in flight (TrainPipeline, single-chain graphs)" % n_in
             wg = "in line, grouped per ResNet stage"
         elif mode == "graph":
             net.enable_train_graphs(True)        # model/train_graph.py: the step replayed as one hipGraph
             losses, dt = _timed_train_windows(net, blobs, opt, steps)
-            launch, wg = "hipGraph replay of the whole step, one frame at a time", "on a side stream, grouped per ResNet stage"
+            launch, wg = "hipGraph replay of the whole step as one chain, one frame at a time", "in line, grouped per ResNet stage"
         else:
             losses, dt = _timed_train_windows(net, blobs, opt, steps)
             launch, wg = "eager (autograd)", "per layer inside autograd's backward (synchronous)"
