@@ -11,8 +11,11 @@
 // 16-byte chunks along k / q and the MFMA fragments are ds_read_b32 with the lanes running along k / q
 // (32 consecutive floats per half wave: conflict-free without padding).  A thread's q chunk — hence its
 // filter tap (r, s) and channel c — is fixed for the whole kernel; only the pixel advances.
-// The pixel range is split over gridDim.z; partial sums go to slabs that a second kernel adds in z order,
-// so the result is deterministic.
+// The pixel range is split over gridDim.z; partial sums go to slabs that are added in z order, so the result is
+// deterministic.
+// Two kernels: conv_wgrad_f32 (rounds 1-4: register-staged tiles, slabs added by wgrad_reduce_kernel / wgrad_accumulate_kernel;
+// plans 1 / 2, kept for operands beyond 2 GB, callers without tile counters and A/B) and conv_wgrad_dma_f32 (round 5: LDS-DMA
+// ring, ds_read_b64 fragments, the LAST workgroup of a tile adds the slabs and stores / accumulates itself; plans 3 / 4).
 #include "common.h"
 
 #include <algorithm>
